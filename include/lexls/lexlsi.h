@@ -1,0 +1,570 @@
+// Primal active-set driver for lexicographic least-squares with inequalities (host side).
+//
+// North star: "LexLSI's outer active-set loop is kept on the host"; the equality solver it calls
+// once per iteration is the accelerated hot path.  The driver is therefore a template over the
+// equality-solver type LSE:
+//     LexLS::internal::LexLSI            = LexLSI_T<LexLS::internal::LexLSE>  (HIP-backed, lexlse.h)
+//     oracle: LexLSI_T<lexls_oracle::LexLSE>                                  (CPU restatement)
+// so the very same driver logic runs on both sides of a parity test.
+//
+// Behaviour restated from the reference include/lexls/lexlsi.h (cited per method).  Known oddities
+// of the reference are kept on purpose: reset() does not clear
+// x_guess_is_specified (lexlsi.h:97 shadows it).
+#pragma once
+
+#include <lexls/cycling.h>
+#include <lexls/objective.h>
+
+namespace LexLS
+{
+    namespace internal
+    {
+        template <class LSE>
+        class LexLSI_T
+        {
+        public:
+            /// lexlsi.h:51-58
+            LexLSI_T(Index nVar_, Index nObj_, Index *ObjDim_, ObjectiveType *ObjType_)
+            : nVar(nVar_), nObj(nObj_), x_guess_is_specified(false), status(TERMINATION_STATUS_UNKNOWN)
+            {
+                parameters.setDefaults();
+                setParameters(parameters);
+                resize(ObjDim_, ObjType_);
+            }
+
+            /// lexlsi.h:63-67
+            LexLSI_T() : nVar(0), nObj(0), x_guess_is_specified(false), status(TERMINATION_STATUS_UNKNOWN)
+            {
+                parameters.setDefaults();
+                setParameters(parameters);
+            }
+
+            /// lexlsi.h:77-83
+            void resize(Index nVar_, Index nObj_, Index *ObjDim_, ObjectiveType *ObjType_)
+            {
+                nVar = nVar_;
+                nObj = nObj_;
+                resize(ObjDim_, ObjType_);
+            }
+
+            /// lexlsi.h:88-104 (x_guess_is_specified intentionally NOT cleared: reference quirk)
+            void reset()
+            {
+                for (Index k = 0; k < nObj; k++) objectives[k].resetActiveSet();
+                initialize();
+                std::fill(nActive.begin(), nActive.end(), 0u);
+                status = TERMINATION_STATUS_UNKNOWN;
+                working_set_log.clear();
+                cycling_handler.reset();
+                WS.clear();
+            }
+
+            /// lexlsi.h:120-136
+            void api_activate(Index ObjIndex, Index CtrIndex, ConstraintActivationType type)
+            {
+                if (objectives[ObjIndex].isActive(CtrIndex)) return;
+                if (type == CTR_ACTIVE_LB || type == CTR_ACTIVE_UB)
+                    activate(ObjIndex, CtrIndex, type, false);
+                else
+                    printf("WARNING: the user cannot define explicitly which constraints are of type CTR_ACTIVE_EQ \n\n");
+            }
+
+            /// lexlsi.h:148-173
+            void activate(Index ObjIndex, Index CtrIndex, ConstraintActivationType type, bool CountActivation = true)
+            {
+                if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");
+                WS.push_back(ConstraintInfo(ObjIndex, CtrIndex));
+                objectives[ObjIndex].activate(CtrIndex, type);
+                if (CountActivation)
+                {
+                    nActivations++;
+                    if (objectives[ObjIndex].isZeroNormal(CtrIndex))
+                        printf("WARNING: activated inequality constraint (0*x = b): (obj_index = %d, ctr_index = %d) \n", ObjIndex, CtrIndex);
+                }
+            }
+
+            /// lexlsi.h:181-198
+            void deactivate(Index ObjIndex, Index CtrIndexActive)
+            {
+                if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");
+                typename std::vector<ConstraintInfo>::iterator it =
+                    std::find(WS.begin(), WS.end(), ConstraintInfo(ObjIndex, objectives[ObjIndex].getActiveCtrIndex(CtrIndexActive)));
+                WS.erase(it);
+                objectives[ObjIndex].deactivate(CtrIndexActive);
+                nDeactivations++;
+            }
+
+            /// lexlsi.h:205-246
+            TerminationStatus solve()
+            {
+                if (parameters.use_phase1_v0)
+                    phase1_v0();
+                else
+                    phase1();
+
+                while (true)
+                {
+                    verifyWorkingSet();
+                    if (status == PROBLEM_SOLVED || status == PROBLEM_SOLVED_CYCLING_HANDLING) break;
+                    if (nFactorizations >= parameters.max_number_of_factorizations)
+                    {
+                        status = MAX_NUMBER_OF_FACTORIZATIONS_EXCEEDED;
+                        break;
+                    }
+                }
+                return status;
+            }
+
+            /// lexlsi.h:306-310
+            void set_x0(const dVectorType &x0)
+            {
+                x                    = x0;
+                x_guess_is_specified = true;
+            }
+
+            /// lexlsi.h:317-320
+            void set_v0(Index ObjIndex, dVectorType &v0_) { objectives[ObjIndex].set_v0(v0_); }
+
+            /// lexlsi.h:325-342
+            void setParameters(const ParametersLexLSI &parameters_)
+            {
+                parameters = parameters_;
+                ParametersLexLSE p;
+                p.tol_linear_dependence          = parameters.tol_linear_dependence;
+                p.regularization_type            = parameters.regularization_type;
+                p.max_number_of_CG_iterations    = parameters.max_number_of_CG_iterations;
+                p.variable_regularization_factor = parameters.variable_regularization_factor;
+                lexlse.setParameters(p);
+                if (parameters.cycling_handling_enabled)
+                {
+                    cycling_handler.set_max_counter(parameters.cycling_max_counter);
+                    cycling_handler.set_relax_step(parameters.cycling_relax_step);
+                }
+            }
+
+            /// lexlsi.h:350-435: general objective, data = [A, lb, ub]; rows with |lb-ub| < 1e-15 and a
+            /// non-zero normal are activated as equalities
+            void setData(Index ObjIndex, const dMatrixConstRef &data)
+            {
+                if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");
+                if (objectives[ObjIndex].getObjType() != GENERAL_OBJECTIVE) throw Exception("ObjType = GENERAL_OBJECTIVE is assumed");
+                if (objectives[ObjIndex].getDim() != data.rows()) throw Exception("Incorrect number of equations");
+
+                for (Index c = 0; c < objectives[ObjIndex].getDim(); c++)
+                {
+                    const RealScalar bl = data(c, nVar);
+                    const RealScalar bu = data(c, nVar + 1);
+                    if (isEqual(bl, bu))
+                    {
+                        RealScalar s = 0.0;
+                        for (Index j = 0; j < nVar; j++) s = std::fma(data(c, j), data(c, j), s);
+                        if (s > 0) activate(ObjIndex, c, CTR_ACTIVE_EQ, false);
+                    }
+                    else if (bl > bu)
+                    {
+                        throw Exception("(general) Lower bound is greater than upper bound.");
+                    }
+                }
+                objectives[ObjIndex].setData(data);
+            }
+
+            /// lexlsi.h:444-491: simple bounds, data = [lb, ub], VarIndex 0-based and unique
+            void setData(Index ObjIndex, Index *VarIndex, const dMatrixConstRef &data)
+            {
+                if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");
+                if (objectives[ObjIndex].getObjType() != SIMPLE_BOUNDS_OBJECTIVE) throw Exception("ObjType = SIMPLE_BOUNDS_OBJECTIVE is assumed");
+                if (objectives[ObjIndex].getDim() != data.rows()) throw Exception("Incorrect number of equations");
+
+                const Index dim = objectives[ObjIndex].getDim();
+                for (Index c = 0; c < dim; c++)
+                {
+                    const RealScalar bl = data(c, 0);
+                    const RealScalar bu = data(c, 1);
+                    if (isEqual(bl, bu))
+                        activate(ObjIndex, c, CTR_ACTIVE_EQ, false);
+                    else if (bl > bu)
+                        throw Exception("(simple) Lower bound is greater than upper bound.");
+                }
+                for (Index k = 0; k < dim; k++)
+                    for (Index j = 0; j < dim; j++)
+                        if (VarIndex[k] == VarIndex[j] && j != k) throw Exception("Elements of VarIndex are not unique.");
+
+                objectives[ObjIndex].setData(VarIndex, data);
+            }
+
+            void setRegularizationFactor(Index ObjIndex, RealScalar factor) { objectives[ObjIndex].setRegularization(factor); }
+
+            const dVectorType &get_x() const { return x; }
+
+            /// lexlsi.h:519-526
+            const dVectorType &get_xStar()
+            {
+                formLexLSE();
+                lexlse.factorize();
+                lexlse.solve();
+                return lexlse.get_x();
+            }
+
+            const dVectorType &get_v(Index ObjIndex) const { return objectives[ObjIndex].get_v(); }
+            void getConstraintViolation(Index ObjIndex, dVectorType &ctr_violation) const { objectives[ObjIndex].getConstraintViolation(ctr_violation); }
+
+            /// lexlsi.h:552-605: Lagrange multipliers of every objective w.r.t. every constraint, in
+            /// the user's constraint order; vec_lambda[k] is (dim_k x nObj)
+            void getLambda(std::vector<dMatrixType> &vec_lambda)
+            {
+                Index nActiveCtr = 0;
+                vec_lambda.resize(nObj);
+                for (Index k = 0; k < nObj; k++)
+                {
+                    nActiveCtr += objectives[k].getActiveCtrCount();
+                    vec_lambda[k].resize(getObjDim(k), nObj);
+                }
+                if (status != PROBLEM_SOLVED)
+                {
+                    formLexLSE();
+                    lexlse.factorize();
+                }
+
+                dMatrixType L_active(nActiveCtr, nObj);
+                Index nMeaningful = lexlse.getFixedVariablesCount();
+                Index CtrIndex2Remove;
+                int ObjIndex2Remove;
+                RealScalar maxAbsValue;
+                for (Index k = 0; k < nObj - nObjOffset; k++)
+                {
+                    lexlse.ObjectiveSensitivity(k, CtrIndex2Remove, ObjIndex2Remove, parameters.tol_wrong_sign_lambda, parameters.tol_correct_sign_lambda,
+                                                maxAbsValue);
+                    nMeaningful += lexlse.getDim(k);
+                    const dVectorType &w = lexlse.getWorkspace();
+                    for (Index i = 0; i < nMeaningful; i++) L_active(i, nObjOffset + k) = w(i);
+                }
+
+                Index accumulate_active_ctr = 0;
+                for (Index k = 0; k < nObj; k++)
+                {
+                    for (Index a = 0; a < objectives[k].getActiveCtrCount(); a++)
+                    {
+                        const Index ind = objectives[k].getActiveCtrIndex(a);
+                        for (Index j = 0; j < nObj; j++) vec_lambda[k](ind, j) = L_active(accumulate_active_ctr + a, j);
+                    }
+                    accumulate_active_ctr += objectives[k].getActiveCtrCount();
+                }
+            }
+
+            const dMatrixType &get_lexqr() { return lexlse.get_lexqr(); }
+            const dMatrixType &get_data() { return lexlse.get_data(); }
+
+            Index getCyclingCounter() const { return cycling_handler.get_counter(); }
+            Index getFactorizationsCount() const { return nFactorizations; }
+            Index getActivationsCount() const { return nActivations; }
+            Index getDeactivationsCount() const { return nDeactivations; }
+            Index getIterationsCount() const { return nIterations; }
+            Index getActiveCtrCount(Index ObjIndex) const { return objectives[ObjIndex].getActiveCtrCount(); }
+            Index getActiveCtrCount() const
+            {
+                Index n = 0;
+                for (Index k = 0; k < nObj; k++) n += objectives[k].getActiveCtrCount();
+                return n;
+            }
+
+            /// lexlsi.h:688-698
+            void getActiveCtr(Index ObjIndex, std::vector<ConstraintActivationType> &ctr_type) const
+            {
+                ctr_type.assign(objectives[ObjIndex].getDim(), CTR_INACTIVE);
+                for (Index k = 0; k < objectives[ObjIndex].getActiveCtrCount(); k++)
+                    ctr_type[objectives[ObjIndex].getActiveCtrIndex(k)] = objectives[ObjIndex].getActiveCtrType(k);
+            }
+
+            /// lexlsi.h:703-716
+            void getActiveCtr_order(std::vector<ConstraintIdentifier> &ctr) const
+            {
+                for (Index o = 0; o < nObj; o++)
+                    for (Index k = 0; k < objectives[o].getActiveCtrCount(); k++)
+                        ctr.push_back(ConstraintIdentifier(o, objectives[o].getActiveCtrIndex(k), objectives[o].getActiveCtrType(k)));
+            }
+
+            Index getObjectivesCount() const { return nObj; }
+            Index getObjDim(Index ObjIndex) const { return objectives[ObjIndex].getDim(); }
+            std::vector<WorkingSetLogEntry> &getWorkingSetLog() { return working_set_log; }
+            Index getTotalRank() { return lexlse.getTotalRank(); }
+            TerminationStatus getStatus() const { return status; }
+            LSE &getLexLSE() { return lexlse; }
+            const ParametersLexLSI &getParameters() const { return parameters; }
+
+            // -------------------------------------------------------------------------------------
+            // The steps of one active-set iteration, public so that a lock-step batched driver can
+            // interleave the device calls of many instances (lexls_amd BatchedLexLSI).
+            // -------------------------------------------------------------------------------------
+
+            /// lexlsi.h:968-982
+            void formLexLSE()
+            {
+                for (Index k = 0; k < nObj; k++) nActive[k] = objectives[k].getActiveCtrCount();
+                lexlse.setObjDim(&nActive[0] + nObjOffset);
+                Index counter = 0;
+                for (Index k = 0; k < nObj; k++) objectives[k].formLexLSE(lexlse, counter, k - nObjOffset);
+            }
+
+            /// lexlsi.h:987-994
+            void formStep()
+            {
+                const dVectorType &xs = lexlse.get_x();
+                for (Index i = 0; i < nVar; i++) dx(i) = xs(i) - x(i);
+                for (Index k = 0; k < nObj; k++) objectives[k].formStep(dx);
+            }
+
+            /// lexlsi.h:1006-1029: shared alpha across objectives, ascending objective index
+            bool checkBlockingConstraints(Index &ObjIndexBlocking, Index &CtrIndexBlocking, ConstraintActivationType &CtrTypeBlocking, RealScalar &alpha)
+            {
+                alpha = 1;
+                for (Index k = 0; k < nObj; k++)
+                    if (objectives[k].checkBlockingConstraints(CtrIndexBlocking, CtrTypeBlocking, alpha, parameters.tol_feasibility)) ObjIndexBlocking = k;
+                return alpha < 1;
+            }
+
+            /// lexlsi.h:816-869
+            void phase1()
+            {
+                hot_start_related_tests();
+                if (!x_guess_is_specified)
+                {
+                    formLexLSE();
+                    lexlse.factorize();
+                    lexlse.solve();
+                    lexlse_rank = getTotalRank();
+                    x           = lexlse.get_x();
+                }
+                for (Index k = 0; k < nObj; k++)
+                    objectives[k].phase1(x, x_guess_is_specified, parameters.modify_type_active_enabled, parameters.modify_type_inactive_enabled,
+                                         parameters.modify_x_guess_enabled, parameters.set_min_init_ctr_violation, parameters.tol_feasibility);
+                if (x_guess_is_specified)
+                {
+                    formLexLSE();
+                    lexlse.factorize();
+                    lexlse.solve();
+                    lexlse_rank = getTotalRank();
+                    const dVectorType &xs = lexlse.get_x();
+                    for (Index i = 0; i < nVar; i++) dx(i) = xs(i) - x(i);
+                }
+                for (Index k = 0; k < nObj; k++) objectives[k].formStep(dx);
+                nFactorizations++;
+            }
+
+            /// lexlsi.h:880-915
+            void phase1_v0()
+            {
+                if (!x_guess_is_specified) throw Exception("when use_phase1_v0 = true, x_guess has to be specified");
+                hot_start_related_tests();
+                for (Index k = 0; k < nObj; k++)
+                    objectives[k].phase1(x, x_guess_is_specified, parameters.modify_type_active_enabled, parameters.modify_type_inactive_enabled,
+                                         parameters.modify_x_guess_enabled, parameters.set_min_init_ctr_violation, parameters.tol_feasibility);
+                for (Index k = 0; k < nObj; k++) objectives[k].formStep(dx);
+            }
+
+            /// lexlsi.h:1144-1265: one iteration of the active-set method
+            OperationType verifyWorkingSet()
+            {
+                Index ObjIndex2Manipulate = 0, CtrIndex2Manipulate = 0;
+                ConstraintActivationType CtrType2Manipulate = CTR_INACTIVE;
+                bool normalIteration                        = true;
+                OperationType operation                     = OPERATION_UNDEFINED;
+                ConstraintIdentifier constraint_identifier(0, 0, CTR_INACTIVE, 0);
+                RealScalar alpha;
+                bool cycling_detected;
+
+                if (nIterations != 0)
+                {
+                    formLexLSE();
+                    lexlse.factorize();
+                    lexlse.solve();
+                    lexlse_rank = getTotalRank();
+                    formStep();
+                    nFactorizations++;
+                }
+                else if (parameters.use_phase1_v0)
+                {
+                    normalIteration = false;
+                }
+
+                if (checkBlockingConstraints(ObjIndex2Manipulate, CtrIndex2Manipulate, CtrType2Manipulate, alpha))
+                {
+                    if (parameters.cycling_handling_enabled) constraint_identifier.set(ObjIndex2Manipulate, CtrIndex2Manipulate, CtrType2Manipulate);
+                    if (parameters.log_working_set_enabled)
+                        working_set_log.push_back(WorkingSetLogEntry(ObjIndex2Manipulate, CtrIndex2Manipulate, CtrType2Manipulate, alpha, lexlse_rank));
+                    operation = OPERATION_ADD;
+                    activate(ObjIndex2Manipulate, CtrIndex2Manipulate, CtrType2Manipulate);
+                }
+                else if (normalIteration)
+                {
+                    RealScalar lambda_wrong_sign;
+                    if (findActiveCtr2Remove(ObjIndex2Manipulate, CtrIndex2Manipulate, lambda_wrong_sign))
+                    {
+                        if (parameters.cycling_handling_enabled)
+                            constraint_identifier.set(ObjIndex2Manipulate, objectives[ObjIndex2Manipulate].getActiveCtrIndex(CtrIndex2Manipulate),
+                                                      objectives[ObjIndex2Manipulate].getActiveCtrType(CtrIndex2Manipulate));
+                        if (parameters.log_working_set_enabled)
+                            working_set_log.push_back(WorkingSetLogEntry(ObjIndex2Manipulate,
+                                                                         objectives[ObjIndex2Manipulate].getActiveCtrIndex(CtrIndex2Manipulate),
+                                                                         CTR_INACTIVE, lambda_wrong_sign, lexlse_rank));
+                        operation = OPERATION_REMOVE;
+                        deactivate(ObjIndex2Manipulate, CtrIndex2Manipulate);
+                    }
+                    else
+                    {
+                        status = PROBLEM_SOLVED;
+                    }
+                }
+
+                step_length = (operation == OPERATION_ADD) ? alpha : -1;
+
+                if (alpha > 0)
+                {
+                    for (Index i = 0; i < nVar; i++) x(i) += alpha * dx(i);
+                    for (Index k = 0; k < nObj; k++) objectives[k].step(alpha);
+                }
+
+                if (parameters.cycling_handling_enabled && operation != OPERATION_UNDEFINED)
+                {
+                    status = cycling_handler.update(operation, constraint_identifier, objectives, cycling_detected);
+                    if (parameters.log_working_set_enabled) working_set_log.back().cycling_detected = cycling_detected;
+                }
+
+                nIterations++;
+                return operation;
+            }
+
+        private:
+            /// lexlsi.h:758-793
+            void hot_start_related_tests()
+            {
+                bool v0_is_only_partially_specified = false;
+                bool user_attempted_to_specify_v0   = objectives[0].getFlag_v0_is_specified();
+                for (Index k = 1; k < nObj; k++)
+                {
+                    if (objectives[k].getFlag_v0_is_specified() != user_attempted_to_specify_v0)
+                    {
+                        printf("WARNING: disregarding v0 because it is only partially initialized. \n");
+                        user_attempted_to_specify_v0   = true;
+                        v0_is_only_partially_specified = true;
+                        break;
+                    }
+                }
+                bool forgot_x_guess = false;
+                if (!x_guess_is_specified && user_attempted_to_specify_v0)
+                {
+                    printf("WARNING: disregarding v0 because x_guess is not set. \n");
+                    forgot_x_guess = true;
+                }
+                if (v0_is_only_partially_specified || forgot_x_guess)
+                    for (Index k = 0; k < nObj; k++) objectives[k].setFlag_v0_is_specified(false);
+            }
+
+            /// lexlsi.h:923-946
+            void resize(Index *ObjDim_, ObjectiveType *ObjType_)
+            {
+                nObjOffset = (ObjType_[0] == SIMPLE_BOUNDS_OBJECTIVE) ? 1 : 0;
+                lexlse.resize(nVar, nObj - nObjOffset, ObjDim_ + nObjOffset);
+                nActive.assign(nObj, 0);
+                objectives.resize(nObj);
+                for (Index k = 0; k < nObj; k++) objectives[k].resize(ObjDim_[k], nVar, ObjType_[k]);
+                x.resize(nVar);
+                dx.resize(nVar);
+                initialize();
+            }
+
+            /// lexlsi.h:951-963
+            void initialize()
+            {
+                nIterations     = 0;
+                nActivations    = 0;
+                nDeactivations  = 0;
+                nFactorizations = 0;
+                lexlse_rank     = 0;
+                step_length     = 0;
+                x.setZero();
+                dx.setZero();
+            }
+
+            /// lexlsi.h:1034-1046
+            Index findFirstCtrWrongSign(std::vector<ConstraintInfo> &ctr_wrong_sign)
+            {
+                Index k = 0;
+                while (std::find(ctr_wrong_sign.begin(), ctr_wrong_sign.end(), WS[k]) == ctr_wrong_sign.end()) k++;
+                return k;
+            }
+
+            /// lexlsi.h:1048-1060
+            bool findActiveCtr2Remove(Index &ObjIndex2Remove, Index &CtrIndex2Remove, RealScalar &lambda_wrong_sign)
+            {
+                if (parameters.deactivate_first_wrong_sign) return findActiveCtr2Remove_first(ObjIndex2Remove, CtrIndex2Remove, lambda_wrong_sign);
+                return findActiveCtr2Remove_largest(ObjIndex2Remove, CtrIndex2Remove, lambda_wrong_sign);
+            }
+
+            /// lexlsi.h:1063-1105
+            bool findActiveCtr2Remove_first(Index &ObjIndex2Remove, Index &CtrIndex2Remove, RealScalar &lambda_wrong_sign)
+            {
+                std::vector<ConstraintInfo> ctr_wrong_sign;
+                lambda_wrong_sign = 0;
+                bool found        = false;
+                for (Index k = 0; k < nObj - nObjOffset; k++)
+                {
+                    lexlse.ObjectiveSensitivity(k, parameters.tol_wrong_sign_lambda, parameters.tol_correct_sign_lambda, ctr_wrong_sign);
+                    if (!ctr_wrong_sign.empty())
+                    {
+                        found = true;
+                        break;
+                    }
+                }
+                if (found)
+                {
+                    for (size_t k = 0; k < ctr_wrong_sign.size(); k++)
+                    {
+                        ctr_wrong_sign[k].increment_obj_index(nObjOffset);
+                        const int o = ctr_wrong_sign[k].get_obj_index();
+                        ctr_wrong_sign[k].set_ctr_index(objectives[o].getActiveCtrIndex(ctr_wrong_sign[k].get_ctr_index()));
+                    }
+                    const Index k   = findFirstCtrWrongSign(ctr_wrong_sign);
+                    ObjIndex2Remove = static_cast<Index>(WS[k].get_obj_index());
+                    CtrIndex2Remove = objectives[ObjIndex2Remove].getCtrIndex(static_cast<Index>(WS[k].get_ctr_index()));
+                }
+                return found;
+            }
+
+            /// lexlsi.h:1115-1139: stop at the FIRST objective that reports a wrong-sign multiplier
+            bool findActiveCtr2Remove_largest(Index &ObjIndex2Remove, Index &CtrIndex2Remove, RealScalar &lambda_wrong_sign)
+            {
+                bool found              = false;
+                int ObjIndex2Remove_int = 0;
+                for (Index k = 0; k < nObj - nObjOffset; k++)
+                {
+                    found = lexlse.ObjectiveSensitivity(k, CtrIndex2Remove, ObjIndex2Remove_int, parameters.tol_wrong_sign_lambda,
+                                                        parameters.tol_correct_sign_lambda, lambda_wrong_sign);
+                    if (found) break;
+                }
+                ObjIndex2Remove = static_cast<Index>(ObjIndex2Remove_int + static_cast<int>(nObjOffset));
+                return found;
+            }
+
+            Index nVar;
+            Index nObj;
+            Index nObjOffset;
+            Index nIterations;
+            Index nActivations;
+            Index nDeactivations;
+            Index nFactorizations;
+            Index lexlse_rank;
+            RealScalar step_length;
+            bool x_guess_is_specified;
+            TerminationStatus status;
+            dVectorType x;
+            dVectorType dx;
+            std::vector<Index> nActive;
+            LSE lexlse;
+            std::vector<Objective> objectives;
+            ParametersLexLSI parameters;
+            std::vector<WorkingSetLogEntry> working_set_log;
+            CyclingHandler cycling_handler;
+            std::vector<ConstraintInfo> WS;
+        };
+    } // namespace internal
+} // namespace LexLS

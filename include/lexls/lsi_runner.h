@@ -1,0 +1,144 @@
+// Flat-array front end for the host active-set driver: builds a LexLSI_T<LSE> from plain buffers,
+// solves it and flattens the results.  Shared by the product C ABI (lexls_amd/csrc) and by the
+// oracle's C API (oracle/oracle_capi.cpp) so that both sides of a parity test are driven by the
+// same call sequence — the sequence of the reference's own front end
+// (interfaces/matlab-octave/lexlsi.cpp:527-625: setParameters, setData per objective, set_x0,
+// api_activate per guessed constraint, solve).
+#pragma once
+
+#include <cstdint>
+#include <lexls/lexlsi.h>
+#include <lexls/tools.h>
+
+namespace LexLS
+{
+    namespace runner
+    {
+        struct LsiProblem
+        {
+            Index nVar, nObj;
+            const Index *dims;           // nObj
+            const int32_t *types;        // nObj: 0 general, 1 simple bounds (objective 0 only)
+            const double *data;          // objectives concatenated, each column-major: general dim x (nVar+2) [A lb ub], simple dim x 2 [lb ub]
+            const Index *var_index;      // dims[0] 0-based indices when objective 0 is simple bounds, else unused
+            const uint8_t *active_guess; // sum(dims) activation flags (0..3) or NULL
+            const double *x0;            // nVar or NULL
+        };
+
+        struct LsiInfo
+        {
+            int32_t status, iterations, activations, deactivations, factorizations, total_rank;
+        };
+
+        inline size_t objective_size(const LsiProblem &p, Index k) { return static_cast<size_t>(p.dims[k]) * (p.types[k] == 1 ? 2 : p.nVar + 2); }
+
+        template <class LSI>
+        void setup(LSI &lsi, const LsiProblem &p, const ParametersLexLSI &par)
+        {
+            std::vector<Index> dims(p.dims, p.dims + p.nObj);
+            std::vector<ObjectiveType> types(p.nObj);
+            for (Index k = 0; k < p.nObj; k++) types[k] = p.types[k] == 1 ? SIMPLE_BOUNDS_OBJECTIVE : GENERAL_OBJECTIVE;
+            lsi.resize(p.nVar, p.nObj, dims.data(), types.data());
+            lsi.setParameters(par);
+
+            size_t off = 0;
+            for (Index k = 0; k < p.nObj; k++)
+            {
+                if (types[k] == SIMPLE_BOUNDS_OBJECTIVE)
+                {
+                    std::vector<Index> vi(p.var_index, p.var_index + dims[k]);
+                    lsi.setData(k, vi.data(), dMatrixConstRef(p.data + off, dims[k], 2));
+                }
+                else
+                {
+                    lsi.setData(k, dMatrixConstRef(p.data + off, dims[k], p.nVar + 2));
+                }
+                off += objective_size(p, k);
+            }
+            if (p.x0) lsi.set_x0(dVectorType(p.x0, p.nVar));
+            if (p.active_guess)
+            {
+                size_t r = 0;
+                for (Index k = 0; k < p.nObj; k++)
+                    for (Index j = 0; j < dims[k]; j++, r++)
+                        if (p.active_guess[r] != CTR_INACTIVE) lsi.api_activate(k, j, static_cast<ConstraintActivationType>(p.active_guess[r]));
+            }
+        }
+
+        /// x_out: nVar; active_out / v_out: sum(dims) (either may be NULL)
+        template <class LSI>
+        void collect(LSI &lsi, const LsiProblem &p, double *x_out, LsiInfo *info, uint8_t *active_out, double *v_out)
+        {
+            const dVectorType &x = lsi.get_x();
+            for (Index i = 0; i < p.nVar; i++) x_out[i] = x(i);
+            if (info)
+            {
+                info->status         = static_cast<int32_t>(lsi.getStatus());
+                info->iterations     = static_cast<int32_t>(lsi.getIterationsCount());
+                info->activations    = static_cast<int32_t>(lsi.getActivationsCount());
+                info->deactivations  = static_cast<int32_t>(lsi.getDeactivationsCount());
+                info->factorizations = static_cast<int32_t>(lsi.getFactorizationsCount());
+                info->total_rank     = static_cast<int32_t>(lsi.getTotalRank());
+            }
+            size_t r = 0;
+            for (Index k = 0; k < p.nObj; k++)
+            {
+                std::vector<ConstraintActivationType> t;
+                lsi.getActiveCtr(k, t);
+                const dVectorType &v = lsi.get_v(k);
+                for (Index j = 0; j < p.dims[k]; j++, r++)
+                {
+                    if (active_out) active_out[r] = static_cast<uint8_t>(t[j]);
+                    if (v_out) v_out[r] = v(j);
+                }
+            }
+        }
+
+        template <class LSI>
+        void solve(const LsiProblem &p, const ParametersLexLSI &par, double *x_out, LsiInfo *info, uint8_t *active_out, double *v_out)
+        {
+            LSI lsi;
+            setup(lsi, p, par);
+            lsi.solve();
+            collect(lsi, p, x_out, info, active_out, v_out);
+        }
+
+        /// flatten a parsed .dat hierarchy (tools.h) into an LsiProblem; storage keeps the buffers alive
+        struct FlatHierarchy
+        {
+            std::vector<Index> dims, var_index;
+            std::vector<int32_t> types;
+            std::vector<double> data;
+            std::vector<uint8_t> guess;
+            LsiProblem problem;
+        };
+
+        inline void flatten(const tools::Hierarchy &h, bool one_based_simple_bounds, bool use_active_set_guess, bool use_solution_guess, FlatHierarchy &f)
+        {
+            if (h.type_of_hierarchy != tools::HIERARCHY_TYPE_INEQUALITY) throw Exception("flatten: inequality hierarchy expected");
+            f.dims.assign(h.number_of_constraints.begin(), h.number_of_constraints.end());
+            f.types.clear();
+            f.data.clear();
+            f.guess.clear();
+            for (Index k = 0; k < h.number_of_objectives; k++)
+            {
+                const bool simple = h.types_of_objectives[k] == SIMPLE_BOUNDS_OBJECTIVE;
+                f.types.push_back(simple ? 1 : 0);
+                const dMatrixType &m = h.objectives[k];
+                for (Index j = simple ? 1 : 0; j < m.cols(); j++)
+                    for (Index i = 0; i < m.rows(); i++) f.data.push_back(m(i, j));
+                if (h.type_header == 210)
+                    for (Index i = 0; i < m.rows(); i++) f.guess.push_back(static_cast<uint8_t>(h.active_set_guess[k][i]));
+            }
+            f.var_index            = tools::HierarchyFileProcessor::simple_bound_indices(h, one_based_simple_bounds);
+            f.problem.nVar         = h.number_of_variables;
+            f.problem.nObj         = h.number_of_objectives;
+            f.problem.dims         = f.dims.data();
+            f.problem.types        = f.types.data();
+            f.problem.data         = f.data.data();
+            f.problem.var_index    = f.var_index.empty() ? NULL : f.var_index.data();
+            f.problem.active_guess = (use_active_set_guess && !f.guess.empty()) ? f.guess.data() : NULL;
+            f.problem.x0           = (use_solution_guess && h.solution_guess.size() == h.number_of_variables) ? h.solution_guess.data() : NULL;
+        }
+    } // namespace runner
+} // namespace LexLS

@@ -1,0 +1,699 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product: only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may use anything under oracle/.
+//
+// Scalar CPU restatement of the reference's equality solver LexLS::internal::LexLSE
+// (/root/reference/include/lexls/lexlse.h), REGULARIZATION_NONE path: factorize() :117-506,
+// solve() :1015-1045, solveLeastNorm_1() :1052-1131, ObjectiveSensitivity() :511-602 and :611-762,
+// findDescentDirection() :866-987, get_v() :1560-1582, setters :1381-1552, initialize() :1672-1693.
+//
+// PINNING STATUS.  The reference executes every arithmetic statement inside Eigen 3, which is not
+// vendored and not installed here, so the reference cannot be compiled in this environment; its
+// test-suite stores no factor / pivot / multiplier vectors.  What pins this oracle:
+//   * tests/golden/test_01.dat `#Solution` (the reference's own fixture): x* of a 5-level LexLSI
+//     problem, reproduced through this class + the host driver (tests/test_oracle_golden.py);
+//   * the reference's closed-form multiplier KAT (interfaces/matlab-octave/tests/lexlsi/lambda_test.m);
+//   * an independent numpy solver that does not follow the l-QR algorithm (oracle/oracle_np.py).
+// Factor internals (pivot order, Householder scalars, Gauss multipliers) are "parity unpinned":
+// this file DEFINES them.  Eigen primitive semantics follow the reference's in-tree MATLAB
+// restatements (interfaces/matlab-octave/tests/implementation/lexqr/eigen_like_syntax/*.m).
+//
+// ARITHMETIC CONTRACT (what the HIP kernels reproduce bit-for-bit; compile with -ffp-contract=off):
+//   dot / squaredNorm : s = 0; s = fma(a_i, b_i, s) for i ascending
+//   "c -= a*b"        : c = fma(-a, b, c), inner index ascending, accumulating INTO c
+//   division, sqrt    : IEEE correctly rounded
+//   argmax            : first occurrence of the maximum (Eigen maxCoeff, eigen_like_syntax/maxCoeff.m:11)
+#pragma once
+
+#include <cfloat>
+#include <cmath>
+#include <lexls/typedefs.h>
+
+namespace lexls_oracle
+{
+    using namespace LexLS;
+
+    // ---- Eigen primitives (real double), restated -------------------------------------------------
+
+    /// squaredNorm of n strided values
+    inline double sqnorm(const double *v, Index n)
+    {
+        double s = 0.0;
+        for (Index i = 0; i < n; i++) s = std::fma(v[i], v[i], s);
+        return s;
+    }
+
+    /// Eigen makeHouseholderInPlace on v[0..n) (makeHouseholderInPlace.m:32-55; Eigen >= 3.3 uses
+    /// "tailSqNorm <= DBL_MIN" instead of "== 0").  On exit v[0] is untouched (caller stores beta),
+    /// v[1..n) = essential part.
+    inline void make_householder(double *v, Index n, double &tau, double &beta)
+    {
+        const double tailSq = (n <= 1) ? 0.0 : sqnorm(v + 1, n - 1);
+        const double c0     = v[0];
+        if (tailSq <= DBL_MIN)
+        {
+            tau  = 0.0;
+            beta = c0;
+            for (Index i = 1; i < n; i++) v[i] = 0.0;
+        }
+        else
+        {
+            beta = std::sqrt(std::fma(c0, c0, tailSq));
+            if (c0 >= 0.0) beta = -beta;
+            const double den = c0 - beta;
+            for (Index i = 1; i < n; i++) v[i] = v[i] / den;
+            tau = (beta - c0) / beta;
+        }
+    }
+
+    /// Eigen applyHouseholderOnTheLeft on one column a[0..n) (applyHouseholderOnTheLeft.m:11-17)
+    inline void apply_householder(const double *ess, double tau, double *a, Index n)
+    {
+        if (n == 1)
+        {
+            a[0] *= (1.0 - tau);
+        }
+        else if (tau != 0.0)
+        {
+            double tmp = 0.0;
+            for (Index i = 1; i < n; i++) tmp = std::fma(ess[i - 1], a[i], tmp);
+            tmp += a[0];
+            a[0] = std::fma(-tau, tmp, a[0]);
+            for (Index i = 1; i < n; i++) a[i] = std::fma(-(tau * ess[i - 1]), tmp, a[i]);
+        }
+    }
+
+    /// Eigen JacobiRotation::makeGivens for reals (semantics: SURVEY.md section 8(a))
+    inline void make_givens(double p, double q, double &c, double &s)
+    {
+        if (q == 0.0)
+        {
+            c = p < 0.0 ? -1.0 : 1.0;
+            s = 0.0;
+        }
+        else if (p == 0.0)
+        {
+            c = 0.0;
+            s = q < 0.0 ? 1.0 : -1.0;
+        }
+        else if (std::abs(p) > std::abs(q))
+        {
+            const double t = q / p;
+            double u       = std::sqrt(std::fma(t, t, 1.0));
+            if (p < 0.0) u = -u;
+            c = 1.0 / u;
+            s = -t * c;
+        }
+        else
+        {
+            const double t = p / q;
+            double u       = std::sqrt(std::fma(t, t, 1.0));
+            if (q < 0.0) u = -u;
+            s = -1.0 / u;
+            c = -t * s;
+        }
+    }
+
+    // ---- the class --------------------------------------------------------------------------------
+
+    class LexLSE
+    {
+    public:
+        LexLSE() : nVar(0), nObj(0), nCtr(0), nVarFixed(0), nVarFixedInit(0), TotalRank(0) {}
+        LexLSE(Index nVar_, Index nObj_, Index *ObjDim_) : nVarFixed(0), nVarFixedInit(0)
+        {
+            resize(nVar_, nObj_, ObjDim_);
+            setObjDim(ObjDim_);
+        }
+
+        /// lexlse.h:67-103
+        void resize(Index nVar_, Index nObj_, Index *maxObjDim)
+        {
+            nVar = nVar_;
+            nObj = nObj_;
+            obj_info.assign(nObj, internal::ObjectiveInfo());
+            x.resize(nVar);
+            Index cap = 0;
+            for (Index k = 0; k < nObj; k++) cap += maxObjDim[k];
+            hh_scalars.resize(cap);
+            ctr_type.assign(cap, CTR_INACTIVE);
+            LOD.resize(cap, nVar + 1);
+            PROBLEM_DATA.resize(cap, nVar + 1);
+            dWorkspace.resize(2 * std::max(cap, nVar) + nVar + 1);
+            column_permutations.resize(nVar);
+            nCtr      = 0;
+            TotalRank = 0;
+        }
+
+        /// lexlse.h:1426-1442 (calls initialize(), :1672-1693)
+        void setObjDim(Index *ObjDim_)
+        {
+            nCtr = 0;
+            for (Index k = 0; k < nObj; k++)
+            {
+                nCtr += ObjDim_[k];
+                obj_info[k].dim = ObjDim_[k];
+                if (k > 0) obj_info[k].first_row_index = obj_info[k - 1].first_row_index + obj_info[k - 1].dim;
+            }
+            initialize();
+        }
+
+        void setParameters(const ParametersLexLSE &p) { parameters = p; }
+        void setRegularizationFactor(Index ObjIndex, RealScalar factor) { obj_info[ObjIndex].regularization_factor = factor; }
+
+        /// lexlse.h:1449-1462
+        void setFixedVariablesCount(Index nVarFixed_)
+        {
+            if (nVarFixed_ > nVar) throw Exception("Cannot fix more than nVar variables");
+            nVarFixed = nVarFixed_;
+            fixed_var_index.resize(nVarFixed);
+            fixed_var_type.assign(nVarFixed, CTR_INACTIVE);
+        }
+
+        /// lexlse.h:1381-1388
+        void fixVariable(Index VarIndex, RealScalar VarValue, ConstraintActivationType type = CTR_ACTIVE_UB)
+        {
+            fixed_var_index(nVarFixedInit) = VarIndex;
+            x(nVarFixedInit)               = VarValue;
+            fixed_var_type[nVarFixedInit]  = type;
+            nVarFixedInit++;
+        }
+
+        /// lexlse.h:1398-1419
+        void fixVariables(Index nVarFixed_, Index *VarIndex, RealScalar *VarValue, ConstraintActivationType *type)
+        {
+            setFixedVariablesCount(nVarFixed_);
+            for (Index k = 0; k < nVarFixed; k++)
+            {
+                fixed_var_index(k) = VarIndex[k];
+                x(k)               = VarValue[k];
+                fixed_var_type[k]  = type[k];
+            }
+        }
+
+        /// lexlse.h:1511-1514 (data: capacity-rows x (nVar+1), or nCtr rows)
+        void setProblem(const dMatrixConstRef &data)
+        {
+            for (Index j = 0; j < data.cols(); j++)
+                for (Index i = 0; i < data.rows(); i++) LOD(i, j) = data(i, j);
+        }
+
+        /// lexlse.h:1522-1530
+        void setData(Index ObjIndex, const dMatrixConstRef &data)
+        {
+            if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");
+            const Index F = obj_info[ObjIndex].first_row_index;
+            for (Index j = 0; j <= nVar; j++)
+                for (Index i = 0; i < obj_info[ObjIndex].dim; i++) LOD(F + i, j) = data(i, j);
+        }
+
+        /// lexlse.h:1539-1543 (row given as nVar values with a stride, because objective data is column-major)
+        void setCtrStrided(Index CtrIndex, const RealScalar *row, Index stride, RealScalar rhs)
+        {
+            for (Index j = 0; j < nVar; j++) LOD(CtrIndex, j) = row[static_cast<size_t>(j) * stride];
+            LOD(CtrIndex, nVar) = rhs;
+        }
+        void setCtr(Index CtrIndex, const RealScalar *row, RealScalar rhs) { setCtrStrided(CtrIndex, row, 1, rhs); }
+
+        /// lexlse.h:1548-1552
+        void setCtrType(Index ObjIndex, Index CtrIndex, ConstraintActivationType type) { ctr_type[obj_info[ObjIndex].first_row_index + CtrIndex] = type; }
+
+        // ------------------------------------------------------------------------------------------
+        /// lexlse.h:117-506
+        void factorize()
+        {
+            if (parameters.regularization_type != REGULARIZATION_NONE) throw Exception("oracle: only REGULARIZATION_NONE is restated");
+
+            PROBLEM_DATA = LOD; // :119
+            const Index M  = nCtr;
+            const Index n  = nVar;
+
+            // fixed variables: bring their columns to the front, move their contribution to the RHS (:132-156)
+            if (nVarFixed > 0)
+            {
+                for (Index k = 0; k < nVarFixed; k++)
+                {
+                    const Index coeff      = fixed_var_index(k);
+                    column_permutations(k) = coeff;
+                    if (k != coeff) swap_columns(k, coeff, M);
+                    for (Index i = k + 1; i < nVarFixed; i++)
+                    {
+                        if (fixed_var_index(i) == k)
+                        {
+                            fixed_var_index(i) = coeff;
+                            break;
+                        }
+                    }
+                }
+                for (Index i = 0; i < M; i++)
+                {
+                    double s = 0.0;
+                    for (Index k = 0; k < nVarFixed; k++) s = std::fma(LOD(i, k), x(k), s);
+                    LOD(i, n) -= s;
+                }
+            }
+
+            Index ColIndex         = nVarFixed;
+            Index RemainingColumns = n - nVarFixed;
+            if (ColIndex >= n) // :164-175
+            {
+                TotalRank = nVarFixed;
+                return;
+            }
+
+            double *ColNorms = dWorkspace.data(); // :178
+
+            for (Index ObjIndex = 0; ObjIndex < nObj; ObjIndex++) // :182
+            {
+                const Index F   = obj_info[ObjIndex].first_row_index;
+                const Index Fc  = obj_info[ObjIndex].first_col_index = ColIndex;
+                const Index dim = obj_info[ObjIndex].dim;
+
+                for (Index k = ColIndex; k < n; k++) ColNorms[k] = sqnorm(&LOD(F, k), dim); // :193-196
+
+                for (Index counter = 0; counter < dim; counter++) // :199
+                {
+                    const Index row = F + counter;
+                    const Index R   = dim - counter;
+
+                    // pivot: first maximum of the (down-dated) norms, then a fresh norm (:205-211)
+                    Index piv = ColIndex;
+                    for (Index k = ColIndex + 1; k < n; k++)
+                        if (ColNorms[k] > ColNorms[piv]) piv = k;
+                    const double fresh = sqnorm(&LOD(row, piv), R);
+                    ColNorms[piv]      = fresh;
+
+                    if (fresh < parameters.tol_linear_dependence) break; // :214 (squared norm vs tolerance)
+
+                    column_permutations(ColIndex) = piv; // :222-232 (swap spans ALL nCtr rows)
+                    if (ColIndex != piv)
+                    {
+                        swap_columns(ColIndex, piv, M);
+                        std::swap(ColNorms[ColIndex], ColNorms[piv]);
+                    }
+
+                    if (R > 1) // :239-248 (the RHS column is transformed too)
+                    {
+                        double tau, beta;
+                        make_householder(&LOD(row, ColIndex), R, tau, beta);
+                        LOD(row, ColIndex) = beta;
+                        const double *ess  = &LOD(row + 1, ColIndex);
+                        for (Index j = ColIndex + 1; j <= n; j++) apply_householder(ess, tau, &LOD(row, j), R);
+                        hh_scalars(row) = tau;
+                    }
+
+                    ColIndex++;
+                    RemainingColumns = n - ColIndex;
+                    if (RemainingColumns == 0) break; // :255
+
+                    for (Index k = ColIndex; k < n; k++) ColNorms[k] = std::fma(-LOD(row, k), LOD(row, k), ColNorms[k]); // :262-266
+                }
+
+                const Index rank = obj_info[ObjIndex].rank = ColIndex - Fc; // :272
+
+                // Gauss step (:431-471): L <- L R^-1, Trailing -= L * Up
+                if (ObjIndex < nObj - 1 && rank > 0)
+                {
+                    const Index Fn = F + dim;
+                    for (Index i = Fn; i < M; i++)
+                    {
+                        for (Index p = 0; p < rank; p++)
+                        {
+                            double s = LOD(i, Fc + p);
+                            for (Index q = 0; q < p; q++) s = std::fma(-LOD(i, Fc + q), LOD(F + q, Fc + p), s);
+                            LOD(i, Fc + p) = s / LOD(F + p, Fc + p);
+                        }
+                        for (Index j = ColIndex; j <= n; j++)
+                        {
+                            double t = LOD(i, j);
+                            for (Index p = 0; p < rank; p++) t = std::fma(-LOD(i, Fc + p), LOD(F + p, j), t);
+                            LOD(i, j) = t;
+                        }
+                    }
+                }
+
+                if (RemainingColumns == 0) // :475-490
+                {
+                    for (Index k = ObjIndex + 1; k < nObj; k++) obj_info[k].first_col_index = obj_info[k - 1].first_col_index + obj_info[k - 1].rank;
+                    break;
+                }
+            }
+
+            TotalRank = nVarFixed; // :494-498
+            for (Index k = 0; k < nObj; k++) TotalRank += obj_info[k].rank;
+        }
+
+        /// lexlse.h:1015-1045
+        void solve()
+        {
+            Index acc = 0;
+            for (Index k = nObj; k--;)
+            {
+                const Index rank = obj_info[k].rank;
+                if (rank == 0) continue;
+                const Index F  = obj_info[k].first_row_index;
+                const Index Fc = obj_info[k].first_col_index;
+                for (Index i = 0; i < rank; i++)
+                {
+                    double s = LOD(F + i, nVar);
+                    if (acc > 0)
+                    {
+                        const Index c0 = obj_info[k + 1].first_col_index;
+                        for (Index j = 0; j < acc; j++) s = std::fma(-LOD(F + i, c0 + j), x(c0 + j), s);
+                    }
+                    x(Fc + i) = s;
+                }
+                back_substitute(F, Fc, rank, &x(Fc));
+                acc += rank;
+            }
+            apply_permutation();
+        }
+
+        /// lexlse.h:1052-1131 (least-norm solution through a Givens sweep)
+        void solveLeastNorm_1()
+        {
+            Index nVarRank = 0;
+            for (Index k = 0; k < nObj; k++) nVarRank += obj_info[k].rank;
+            const Index nVarFree = nVar - (nVarRank + nVarFixed);
+            const Index ncol     = nVarRank + nVarFree;
+
+            dMatrixType RT(nVarRank, ncol);
+            std::vector<double> rhs(ncol, 0.0);
+
+            Index counter = 0, col_dim = ncol;
+            for (Index k = 0; k < nObj; k++) // :1081-1094
+            {
+                const Index F = obj_info[k].first_row_index, Fc = obj_info[k].first_col_index, rank = obj_info[k].rank;
+                for (Index i = 0; i < rank; i++)
+                    for (Index j = i; j < col_dim; j++) RT(counter + i, counter + j) = LOD(F + i, Fc + j);
+                for (Index i = 0; i < rank; i++) rhs[counter + i] = LOD(F + i, nVar);
+                counter += rank;
+                col_dim -= rank;
+            }
+
+            struct Rot
+            {
+                double c, s;
+                Index i, j;
+            };
+            std::vector<Rot> gs;
+            gs.reserve(static_cast<size_t>(nVarFree) * nVarRank);
+            for (Index i = 0; i < nVarFree; i++) // :1099-1110
+            {
+                for (Index j = nVarRank; j--;)
+                {
+                    Rot g;
+                    g.i = j;
+                    g.j = nVarRank + i;
+                    make_givens(RT(j, j), RT(j, nVarRank + i), g.c, g.s);
+                    for (Index r = 0; r <= j; r++) // applyOnTheRight on RT.topRows(j+1)
+                    {
+                        const double a = RT(r, g.i), b = RT(r, g.j);
+                        RT(r, g.i) = std::fma(g.c, a, -(g.s * b));
+                        RT(r, g.j) = std::fma(g.c, b, g.s * a);
+                    }
+                    gs.push_back(g);
+                }
+            }
+
+            for (Index i = nVarRank; i--;) // :1115 R^-1 rhs
+            {
+                double s = rhs[i];
+                for (Index j = i + 1; j < nVarRank; j++) s = std::fma(-RT(i, j), rhs[j], s);
+                rhs[i] = s / RT(i, i);
+            }
+
+            for (size_t k = gs.size(); k--;) // :1121-1124 applyOnTheLeft in reverse
+            {
+                const double a = rhs[gs[k].i], b = rhs[gs[k].j];
+                rhs[gs[k].i] = std::fma(gs[k].c, a, gs[k].s * b);
+                rhs[gs[k].j] = std::fma(gs[k].c, b, -(gs[k].s * a));
+            }
+
+            for (Index i = 0; i < ncol; i++) x(nVarFixed + i) = rhs[i]; // :1129
+            apply_permutation();
+        }
+
+        /// lexlse.h:611-762.  On exit dWorkspace.head(nVarFixed+nLambda) = [lambda_fixed; lambda].
+        bool ObjectiveSensitivity(Index ObjIndex, Index &CtrIndex2Remove, int &ObjIndex2Remove, RealScalar tol_wrong_sign_lambda,
+                                  RealScalar tol_correct_sign_lambda, RealScalar &maxAbsValue)
+        {
+            maxAbsValue = 0.0;
+            bool found  = false;
+
+            double *LambdaFixed, *Lambda, *rhs;
+            Index nLambda;
+            dual_begin(ObjIndex, LambdaFixed, Lambda, rhs, nLambda);
+
+            Index F = obj_info[ObjIndex].first_row_index, Fc = obj_info[ObjIndex].first_col_index;
+            Index dim = obj_info[ObjIndex].dim;
+
+            found = findDescentDirection(static_cast<int>(F), dim, maxAbsValue, CtrIndex2Remove, Lambda, tol_wrong_sign_lambda, tol_correct_sign_lambda);
+            if (found) ObjIndex2Remove = static_cast<int>(ObjIndex);
+
+            if (ObjIndex > 0)
+            {
+                dual_accumulate(F, dim, Fc, Lambda, rhs);
+                for (Index k = ObjIndex; k--;)
+                {
+                    F   = obj_info[k].first_row_index;
+                    Fc  = obj_info[k].first_col_index;
+                    dim = obj_info[k].dim;
+                    dual_level(k, Lambda, rhs);
+                    const bool b = findDescentDirection(static_cast<int>(F), dim, maxAbsValue, CtrIndex2Remove, Lambda, tol_wrong_sign_lambda, tol_correct_sign_lambda);
+                    if (b) ObjIndex2Remove = static_cast<int>(k);
+                    found = found || b;
+                }
+            }
+
+            if (nVarFixed > 0)
+            {
+                dual_fixed(nLambda, LambdaFixed, Lambda);
+                const bool b = findDescentDirection(-1, nVarFixed, maxAbsValue, CtrIndex2Remove, LambdaFixed, tol_wrong_sign_lambda, tol_correct_sign_lambda);
+                if (b) ObjIndex2Remove = -1;
+                found = found || b;
+            }
+            return found;
+        }
+
+        /// lexlse.h:511-602 (all wrong-sign multipliers; used with deactivate_first_wrong_sign).
+        /// The reference passes (Lambda, ObjDim) instead of (LambdaFixed, nVarFixed) for the fixed
+        /// variables (:599-600); kept, but the loop is clipped to nVarFixed so it cannot run out of
+        /// fixed_var_type's bounds.
+        void ObjectiveSensitivity(Index ObjIndex, RealScalar tol_wrong_sign_lambda, RealScalar tol_correct_sign_lambda, std::vector<ConstraintInfo> &ctr_wrong_sign)
+        {
+            double *LambdaFixed, *Lambda, *rhs;
+            Index nLambda;
+            dual_begin(ObjIndex, LambdaFixed, Lambda, rhs, nLambda);
+
+            Index F = obj_info[ObjIndex].first_row_index, Fc = obj_info[ObjIndex].first_col_index;
+            Index dim = obj_info[ObjIndex].dim;
+            findDescentDirectionAll(static_cast<int>(ObjIndex), static_cast<int>(F), dim, Lambda, tol_wrong_sign_lambda, tol_correct_sign_lambda, ctr_wrong_sign);
+
+            if (ObjIndex > 0)
+            {
+                dual_accumulate(F, dim, Fc, Lambda, rhs);
+                for (Index k = ObjIndex; k--;)
+                {
+                    F   = obj_info[k].first_row_index;
+                    dim = obj_info[k].dim;
+                    dual_level(k, Lambda, rhs);
+                    findDescentDirectionAll(static_cast<int>(k), static_cast<int>(F), dim, Lambda, tol_wrong_sign_lambda, tol_correct_sign_lambda, ctr_wrong_sign);
+                }
+            }
+            if (nVarFixed > 0)
+            {
+                dual_fixed(nLambda, LambdaFixed, Lambda);
+                findDescentDirectionAll(-1, -1, std::min(dim, nVarFixed), Lambda, tol_wrong_sign_lambda, tol_correct_sign_lambda, ctr_wrong_sign);
+            }
+        }
+
+        /// lexlse.h:1560-1582: residuals v = A x - b recovered through Q; valid in dWorkspace.head(nCtr)
+        dVectorType &get_v()
+        {
+            double *v = dWorkspace.data();
+            for (Index k = 0; k < nObj; k++)
+            {
+                const Index F = obj_info[k].first_row_index, dim = obj_info[k].dim, rank = obj_info[k].rank;
+                for (Index i = 0; i < rank; i++) v[F + i] = 0.0;
+                for (Index i = rank; i < dim; i++) v[F + i] = -LOD(F + i, nVar);
+                apply_q(k, v + F);
+            }
+            return dWorkspace;
+        }
+
+        const dVectorType &get_x() const { return x; }
+        Index getDim(Index k) const { return obj_info[k].dim; }
+        Index getRank(Index k) const { return obj_info[k].rank; }
+        Index getFirstColIndex(Index k) const { return obj_info[k].first_col_index; }
+        Index getFirstRowIndex(Index k) const { return obj_info[k].first_row_index; }
+        Index get_nObj() const { return nObj; }
+        Index get_nVar() const { return nVar; }
+        Index get_nCtr() const { return nCtr; }
+        Index getTotalRank() const { return TotalRank; }
+        Index getFixedVariablesCount() const { return nVarFixed; }
+        const iVectorType &getFixedVarIndex() const { return fixed_var_index; }
+        const dVectorType &getWorkspace() const { return dWorkspace; }
+        const dMatrixType &get_lexqr() const { return LOD; }
+        const dMatrixType &get_data() const { return PROBLEM_DATA; }
+        const dVectorType &get_hh_scalars() const { return hh_scalars; }
+        const iVectorType &get_column_permutations() const { return column_permutations; }
+        const std::vector<ConstraintActivationType> &get_ctr_type() const { return ctr_type; }
+
+        /// lexlse.h:1654-1658
+        void reset()
+        {
+            initialize();
+            for (Index k = 0; k < nVarFixed; k++) x(k) = 0.0;
+        }
+
+    private:
+        /// lexlse.h:1672-1693
+        void initialize()
+        {
+            nVarFixedInit = 0;
+            TotalRank     = 0;
+            for (Index k = 0; k < nObj; k++)
+            {
+                obj_info[k].rank            = 0;
+                obj_info[k].first_col_index = 0;
+            }
+            hh_scalars.setZero();
+            for (Index i = nVarFixed; i < nVar; i++) x(i) = 0.0;
+        }
+
+        void swap_columns(Index a, Index b, Index rows)
+        {
+            for (Index i = 0; i < rows; i++) std::swap(LOD(i, a), LOD(i, b));
+        }
+
+        /// x[0..rank) <- R^-1 x, R = LOD(F.., Fc..) upper triangular
+        void back_substitute(Index F, Index Fc, Index rank, double *xk) const
+        {
+            for (Index i = rank; i--;)
+            {
+                double s = xk[i];
+                for (Index j = i + 1; j < rank; j++) s = std::fma(-LOD(F + i, Fc + j), xk[j], s);
+                xk[i] = s / LOD(F + i, Fc + i);
+            }
+        }
+
+        /// x = P x with P = T(0,p0) T(1,p1) ... (lexlse.h:494-504, :1044, equivalence stated at :1869-1884)
+        void apply_permutation()
+        {
+            for (Index k = TotalRank; k--;) std::swap(x(k), x(column_permutations(k)));
+        }
+
+        /// v <- Q_k v = H_0 H_1 ... H_{r-1} v (householderSequence, applyOnTheLeft.m:11-14)
+        void apply_q(Index k, double *v) const
+        {
+            const Index F = obj_info[k].first_row_index, Fc = obj_info[k].first_col_index, dim = obj_info[k].dim, rank = obj_info[k].rank;
+            for (Index j = rank; j--;) apply_householder(LOD.data() + (F + j + 1) + static_cast<size_t>(Fc + j) * LOD.rows(), hh_scalars(F + j), v + j, dim - j);
+        }
+
+        /// common prologue of the dual solve (:625-664): zero the workspace, residual of ObjIndex
+        void dual_begin(Index ObjIndex, double *&LambdaFixed, double *&Lambda, double *&rhs, Index &nLambda)
+        {
+            nLambda     = 0;
+            Index nRank = 0;
+            for (Index k = 0; k < ObjIndex; k++)
+            {
+                nLambda += obj_info[k].dim;
+                nRank += obj_info[k].rank;
+            }
+            nLambda += obj_info[ObjIndex].dim;
+
+            double *w = dWorkspace.data();
+            for (Index i = 0; i < nVarFixed + nLambda + nRank + nVarFixed; i++) w[i] = 0.0;
+            LambdaFixed = w;
+            Lambda      = w + nVarFixed;
+            rhs         = w + nVarFixed + nLambda;
+
+            const Index F = obj_info[ObjIndex].first_row_index, dim = obj_info[ObjIndex].dim, rank = obj_info[ObjIndex].rank;
+            for (Index i = rank; i < dim; i++) Lambda[F + i] = -LOD(F + i, nVar);
+            apply_q(ObjIndex, Lambda + F);
+        }
+
+        /// rhs.head(ColDim) -= LOD(F:F+dim, 0:ColDim)^T * Lambda.segment(F, dim)   (:706-707, :727-728)
+        void dual_accumulate(Index F, Index dim, Index ColDim, const double *Lambda, double *rhs) const
+        {
+            for (Index c = 0; c < ColDim; c++)
+            {
+                double s = 0.0;
+                for (Index i = 0; i < dim; i++) s = std::fma(LOD(F + i, c), Lambda[F + i], s);
+                rhs[c] -= s;
+            }
+        }
+
+        /// one level of the back-propagation (:712-728)
+        void dual_level(Index k, double *Lambda, double *rhs) const
+        {
+            const Index F = obj_info[k].first_row_index, Fc = obj_info[k].first_col_index, dim = obj_info[k].dim, rank = obj_info[k].rank;
+            for (Index i = 0; i < rank; i++) Lambda[F + i] = rhs[Fc + i];
+            apply_q(k, Lambda + F);
+            dual_accumulate(F, dim, Fc, Lambda, rhs);
+        }
+
+        /// LambdaFixed = -LOD(0:nLambda, 0:nVarFixed)^T * Lambda   (:744)
+        void dual_fixed(Index nLambda, double *LambdaFixed, const double *Lambda) const
+        {
+            for (Index c = 0; c < nVarFixed; c++)
+            {
+                double s = 0.0;
+                for (Index i = 0; i < nLambda; i++) s = std::fma(LOD(i, c), Lambda[i], s);
+                LambdaFixed[c] = -s;
+            }
+        }
+
+        /// lexlse.h:935-987
+        bool findDescentDirection(int FirstRowIndex, Index ObjDim, RealScalar &maxAbsValue, Index &CtrIndex, const double *lambda, RealScalar tol_wrong,
+                                  RealScalar tol_correct)
+        {
+            bool found = false;
+            for (Index k = 0; k < ObjDim; k++)
+            {
+                const Index ind                = (FirstRowIndex < 0) ? k : static_cast<Index>(FirstRowIndex) + k;
+                ConstraintActivationType &type = (FirstRowIndex < 0) ? fixed_var_type[ind] : ctr_type[ind];
+                if (type == CTR_ACTIVE_EQ || type == CORRECT_SIGN_OF_LAMBDA) continue;
+                double a = lambda[ind];
+                if (type == CTR_ACTIVE_LB) a = -a;
+                if (a > tol_correct)
+                {
+                    type = CORRECT_SIGN_OF_LAMBDA;
+                }
+                else if (a < -tol_wrong && a < maxAbsValue)
+                {
+                    found       = true;
+                    maxAbsValue = a;
+                    CtrIndex    = k;
+                }
+            }
+            return found;
+        }
+
+        /// lexlse.h:866-910
+        void findDescentDirectionAll(int ObjIndex, int FirstRowIndex, Index ObjDim, const double *lambda, RealScalar tol_wrong, RealScalar tol_correct,
+                                     std::vector<ConstraintInfo> &out)
+        {
+            for (Index k = 0; k < ObjDim; k++)
+            {
+                const Index ind                = (FirstRowIndex < 0) ? k : static_cast<Index>(FirstRowIndex) + k;
+                ConstraintActivationType &type = (FirstRowIndex < 0) ? fixed_var_type[ind] : ctr_type[ind];
+                if (type == CTR_ACTIVE_EQ || type == CORRECT_SIGN_OF_LAMBDA) continue;
+                double a = lambda[ind];
+                if (type == CTR_ACTIVE_LB) a = -a;
+                if (a > tol_correct)
+                    type = CORRECT_SIGN_OF_LAMBDA;
+                else if (a < -tol_wrong)
+                    out.push_back(ConstraintInfo(ObjIndex, static_cast<int>(k)));
+            }
+        }
+
+        Index nVar, nObj, nCtr, nVarFixed, nVarFixedInit, TotalRank;
+        ParametersLexLSE parameters;
+        std::vector<internal::ObjectiveInfo> obj_info;
+        dMatrixType LOD, PROBLEM_DATA;
+        dVectorType x, hh_scalars, dWorkspace;
+        iVectorType column_permutations, fixed_var_index;
+        std::vector<ConstraintActivationType> ctr_type, fixed_var_type;
+    };
+} // namespace lexls_oracle

@@ -1,0 +1,293 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/lexlse_oracle.h).  Flat C entry points over the
+// CPU restatement so that tests/, smoke() and bench.py's cpu_baseline leg can drive it via ctypes.
+// Nothing in the product links or loads this library.
+#include "lexlse_oracle.h"
+
+#include <chrono>
+#include <cstdint>
+#include <lexls/lsi_runner.h>
+#include <thread>
+
+using namespace LexLS;
+typedef lexls_oracle::LexLSE OLSE;
+typedef internal::LexLSI_T<OLSE> OLSI;
+
+static thread_local std::string g_err;
+
+namespace
+{
+    struct LseBatchArgs
+    {
+        uint32_t batch, nVar, nObj;
+        const uint32_t *maxdim;   // nObj capacities
+        const uint32_t *dims;     // batch x nObj
+        const double *lod;        // batch x cap x (nVar+1), column-major, ld = cap
+        double tol;
+        const uint32_t *nfixed;   // batch or NULL
+        const uint32_t *fixed_idx; // batch x nVar
+        const double *fixed_val;   // batch x nVar
+        const uint8_t *fixed_type; // batch x nVar
+        const uint8_t *ctr_type;   // batch x cap or NULL
+        int solve_option;          // 0 basic solution, 1 least-norm (Givens), <0 factorize only
+        int sens_obj;              // -1: none, else the level passed to ObjectiveSensitivity
+        double tol_wrong, tol_correct;
+        // outputs (any may be NULL)
+        double *x;          // batch x nVar
+        double *factor;     // batch x cap x (nVar+1)
+        double *hh;         // batch x cap
+        uint32_t *perm;     // batch x nVar
+        uint32_t *rank;     // batch x nObj
+        uint32_t *fcol;     // batch x nObj
+        uint32_t *totalrank; // batch
+        double *v;          // batch x cap
+        double *lambda;     // batch x (nVar + cap)   [lambda_fixed; lambda]
+        int32_t *sens;      // batch x 3: found, CtrIndex2Remove, ObjIndex2Remove
+        double *maxabs;     // batch
+        uint8_t *ctr_type_out; // batch x cap
+    };
+
+    void run_one(const LseBatchArgs &a, uint32_t b, OLSE &lse, uint32_t cap)
+    {
+        const uint32_t n = a.nVar;
+        std::vector<Index> dims(a.dims + static_cast<size_t>(b) * a.nObj, a.dims + static_cast<size_t>(b + 1) * a.nObj);
+        if (a.nfixed && a.nfixed[b] > 0) lse.setFixedVariablesCount(a.nfixed[b]);
+        else lse.setFixedVariablesCount(0);
+        lse.setObjDim(dims.data());
+        if (a.nfixed)
+            for (uint32_t k = 0; k < a.nfixed[b]; k++)
+                lse.fixVariable(a.fixed_idx[static_cast<size_t>(b) * n + k], a.fixed_val[static_cast<size_t>(b) * n + k],
+                                a.fixed_type ? static_cast<ConstraintActivationType>(a.fixed_type[static_cast<size_t>(b) * n + k]) : CTR_ACTIVE_UB);
+        lse.setProblem(dMatrixConstRef(a.lod + static_cast<size_t>(b) * cap * (n + 1), cap, n + 1));
+        if (a.ctr_type)
+        {
+            uint32_t r = 0;
+            for (uint32_t k = 0; k < a.nObj; k++)
+                for (uint32_t j = 0; j < dims[k]; j++, r++) lse.setCtrType(k, j, static_cast<ConstraintActivationType>(a.ctr_type[static_cast<size_t>(b) * cap + r]));
+        }
+        lse.factorize();
+        if (a.solve_option == 0) lse.solve();
+        else if (a.solve_option == 1) lse.solveLeastNorm_1();
+
+        if (a.x)
+            for (uint32_t i = 0; i < n; i++) a.x[static_cast<size_t>(b) * n + i] = lse.get_x()(i);
+        if (a.factor)
+        {
+            const dMatrixType &f = lse.get_lexqr();
+            std::memcpy(a.factor + static_cast<size_t>(b) * cap * (n + 1), f.data(), sizeof(double) * cap * (n + 1));
+        }
+        if (a.hh)
+            for (uint32_t i = 0; i < cap; i++) a.hh[static_cast<size_t>(b) * cap + i] = lse.get_hh_scalars()(i);
+        if (a.perm)
+            for (uint32_t i = 0; i < n; i++) a.perm[static_cast<size_t>(b) * n + i] = i < lse.getTotalRank() ? lse.get_column_permutations()(i) : i;
+        for (uint32_t k = 0; k < a.nObj; k++)
+        {
+            if (a.rank) a.rank[static_cast<size_t>(b) * a.nObj + k] = lse.getRank(k);
+            if (a.fcol) a.fcol[static_cast<size_t>(b) * a.nObj + k] = lse.getFirstColIndex(k);
+        }
+        if (a.totalrank) a.totalrank[b] = lse.getTotalRank();
+        if (a.v)
+        {
+            const dVectorType &w = lse.get_v();
+            for (uint32_t i = 0; i < cap; i++) a.v[static_cast<size_t>(b) * cap + i] = i < lse.get_nCtr() ? w(i) : 0.0;
+        }
+        if (a.sens_obj >= 0)
+        {
+            Index ctr = 0;
+            int obj   = -2;
+            double m  = 0;
+            const bool found = lse.ObjectiveSensitivity(static_cast<Index>(a.sens_obj), ctr, obj, a.tol_wrong, a.tol_correct, m);
+            if (a.sens)
+            {
+                a.sens[static_cast<size_t>(b) * 3 + 0] = found ? 1 : 0;
+                a.sens[static_cast<size_t>(b) * 3 + 1] = found ? static_cast<int32_t>(ctr) : -1;
+                a.sens[static_cast<size_t>(b) * 3 + 2] = found ? obj : -2;
+            }
+            if (a.maxabs) a.maxabs[b] = m;
+            if (a.lambda)
+            {
+                Index nLambda = 0;
+                for (int k = 0; k <= a.sens_obj; k++) nLambda += dims[k];
+                const Index nf = lse.getFixedVariablesCount();
+                double *out    = a.lambda + static_cast<size_t>(b) * (n + cap);
+                for (uint32_t i = 0; i < n + cap; i++) out[i] = 0.0;
+                for (Index i = 0; i < nf + nLambda; i++) out[i] = lse.getWorkspace()(i);
+            }
+            if (a.ctr_type_out)
+                for (uint32_t i = 0; i < cap; i++) a.ctr_type_out[static_cast<size_t>(b) * cap + i] = static_cast<uint8_t>(lse.get_ctr_type()[i]);
+        }
+    }
+
+    int run_range(const LseBatchArgs &a, uint32_t b0, uint32_t b1)
+    {
+        std::vector<Index> maxdim(a.maxdim, a.maxdim + a.nObj);
+        uint32_t cap = 0;
+        for (uint32_t k = 0; k < a.nObj; k++) cap += maxdim[k];
+        OLSE lse;
+        lse.resize(a.nVar, a.nObj, maxdim.data());
+        ParametersLexLSE p;
+        p.tol_linear_dependence = a.tol;
+        lse.setParameters(p);
+        for (uint32_t b = b0; b < b1; b++) run_one(a, b, lse, cap);
+        return 0;
+    }
+} // namespace
+
+extern "C"
+{
+    const char *oracle_last_error() { return g_err.c_str(); }
+
+    /// factorize (+ solve, + residual, + sensitivity) of a batch of equality problems, `nthreads` host threads
+    int oracle_lse_run(uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *maxdim, const uint32_t *dims, const double *lod, double tol,
+                       const uint32_t *nfixed, const uint32_t *fixed_idx, const double *fixed_val, const uint8_t *fixed_type, const uint8_t *ctr_type,
+                       int solve_option, int sens_obj, double tol_wrong, double tol_correct, double *x, double *factor, double *hh, uint32_t *perm,
+                       uint32_t *rank, uint32_t *fcol, uint32_t *totalrank, double *v, double *lambda, int32_t *sens, double *maxabs, uint8_t *ctr_type_out,
+                       int nthreads)
+    {
+        try
+        {
+            LseBatchArgs a = {batch, nVar, nObj, maxdim, dims, lod, tol, nfixed, fixed_idx, fixed_val, fixed_type, ctr_type, solve_option, sens_obj,
+                              tol_wrong, tol_correct, x, factor, hh, perm, rank, fcol, totalrank, v, lambda, sens, maxabs, ctr_type_out};
+            if (nthreads <= 1 || batch < 2) return run_range(a, 0, batch);
+            std::vector<std::thread> th;
+            std::vector<int> rc(nthreads, 0);
+            for (int t = 0; t < nthreads; t++)
+            {
+                const uint32_t b0 = static_cast<uint32_t>(static_cast<uint64_t>(batch) * t / nthreads);
+                const uint32_t b1 = static_cast<uint32_t>(static_cast<uint64_t>(batch) * (t + 1) / nthreads);
+                th.emplace_back([&a, &rc, t, b0, b1]() {
+                    try { rc[t] = run_range(a, b0, b1); }
+                    catch (...) { rc[t] = 1; }
+                });
+            }
+            for (auto &t : th) t.join();
+            for (int t = 0; t < nthreads; t++)
+                if (rc[t]) return rc[t];
+            return 0;
+        }
+        catch (const std::exception &e)
+        {
+            g_err = e.what();
+            return 1;
+        }
+    }
+
+    /// wall-clock seconds for `repeats` passes of factorize+solve over the batch (x written to `x`)
+    double oracle_lse_time(uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *maxdim, const uint32_t *dims, const double *lod, double tol,
+                           double *x, int nthreads, int repeats)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < repeats; r++)
+            oracle_lse_run(batch, nVar, nObj, maxdim, dims, lod, tol, NULL, NULL, NULL, NULL, NULL, 0, -1, 0, 0, x, NULL, NULL, NULL, NULL, NULL, NULL, NULL,
+                           NULL, NULL, NULL, NULL, nthreads);
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+    int oracle_hardware_threads() { return static_cast<int>(std::thread::hardware_concurrency()); }
+
+    /// LexLSI on flat arrays (layout: include/lexls/lsi_runner.h).  params: [max_fact, tol_lin_dep, tol_wrong, tol_correct, tol_feas,
+    /// cycling(0/1), cycling_max, cycling_relax, deactivate_first_wrong_sign(0/1)] or NULL for defaults.
+    int oracle_lsi_run(uint32_t nVar, uint32_t nObj, const uint32_t *dims, const int32_t *types, const double *data, const uint32_t *var_index,
+                       const uint8_t *active_guess, const double *x0, const double *params, double *x_out, int32_t *info6, uint8_t *active_out, double *v_out)
+    {
+        try
+        {
+            runner::LsiProblem p = {nVar, nObj, dims, types, data, var_index, active_guess, x0};
+            ParametersLexLSI par;
+            if (params)
+            {
+                par.max_number_of_factorizations = static_cast<Index>(params[0]);
+                par.tol_linear_dependence        = params[1];
+                par.tol_wrong_sign_lambda        = params[2];
+                par.tol_correct_sign_lambda      = params[3];
+                par.tol_feasibility              = params[4];
+                par.cycling_handling_enabled     = params[5] != 0;
+                par.cycling_max_counter          = static_cast<Index>(params[6]);
+                par.cycling_relax_step           = params[7];
+                par.deactivate_first_wrong_sign  = params[8] != 0;
+            }
+            runner::LsiInfo info;
+            runner::solve<OLSI>(p, par, x_out, &info, active_out, v_out);
+            if (info6) std::memcpy(info6, &info, sizeof(info));
+            return 0;
+        }
+        catch (const std::exception &e)
+        {
+            g_err = e.what();
+            return 1;
+        }
+    }
+
+    /// multipliers of a solved-from-scratch LexLSI problem: lambda_out is sum(dims) x nObj, column-major (lexlsi.h:552-605)
+    int oracle_lsi_lambda(uint32_t nVar, uint32_t nObj, const uint32_t *dims, const int32_t *types, const double *data, const uint32_t *var_index,
+                          double *x_out, double *lambda_out)
+    {
+        try
+        {
+            runner::LsiProblem p = {nVar, nObj, dims, types, data, var_index, NULL, NULL};
+            OLSI lsi;
+            runner::setup(lsi, p, ParametersLexLSI());
+            lsi.solve();
+            for (uint32_t i = 0; i < nVar; i++) x_out[i] = lsi.get_x()(i);
+            std::vector<dMatrixType> L;
+            lsi.getLambda(L);
+            uint32_t total = 0;
+            for (uint32_t k = 0; k < nObj; k++) total += dims[k];
+            uint32_t r0 = 0;
+            for (uint32_t k = 0; k < nObj; k++)
+            {
+                for (uint32_t i = 0; i < dims[k]; i++)
+                    for (uint32_t j = 0; j < nObj; j++) lambda_out[(r0 + i) + static_cast<size_t>(j) * total] = L[k](i, j);
+                r0 += dims[k];
+            }
+            return 0;
+        }
+        catch (const std::exception &e)
+        {
+            g_err = e.what();
+            return 1;
+        }
+    }
+
+    /// header of a .dat file: out4 = [nVar, nObj, type_header, has_solution]
+    int oracle_dat_header(const char *path, int32_t *out4)
+    {
+        try
+        {
+            tools::Hierarchy h;
+            tools::HierarchyFileProcessor().import(path, h);
+            out4[0] = static_cast<int32_t>(h.number_of_variables);
+            out4[1] = static_cast<int32_t>(h.number_of_objectives);
+            out4[2] = static_cast<int32_t>(h.type_header);
+            out4[3] = h.solution.size() == h.number_of_variables ? 1 : 0;
+            return 0;
+        }
+        catch (const std::exception &e)
+        {
+            g_err = e.what();
+            return 1;
+        }
+    }
+
+    /// parse a .dat inequality hierarchy and solve it with the host driver over the CPU restatement
+    int oracle_lsi_run_dat(const char *path, int one_based, int use_active_guess, int use_x_guess, double *x_out, int32_t *info6, double *solution_out)
+    {
+        try
+        {
+            tools::Hierarchy h;
+            tools::HierarchyFileProcessor().import(path, h);
+            runner::FlatHierarchy f;
+            runner::flatten(h, one_based != 0, use_active_guess != 0, use_x_guess != 0, f);
+            runner::LsiInfo info;
+            runner::solve<OLSI>(f.problem, ParametersLexLSI(), x_out, &info, NULL, NULL);
+            if (info6) std::memcpy(info6, &info, sizeof(info));
+            if (solution_out)
+                for (Index i = 0; i < h.solution.size(); i++) solution_out[i] = h.solution(i);
+            return 0;
+        }
+        catch (const std::exception &e)
+        {
+            g_err = e.what();
+            return 1;
+        }
+    }
+}

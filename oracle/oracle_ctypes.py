@@ -1,0 +1,172 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes binding of oracle/liblexls_oracle.so (the CPU
+restatement of the reference algorithm).  Imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg — never by the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+_dp = C.POINTER(C.c_double)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liblexls_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.oracle_last_error.restype = C.c_char_p
+        _LIB.oracle_lse_time.restype = C.c_double
+    return _LIB
+
+
+def _p(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+def lse_run(lod, dims, nvar, maxdim=None, tol=1e-12, nfixed=None, fixed_idx=None, fixed_val=None, fixed_type=None,
+            ctr_type=None, solve_option=0, sens_obj=-1, tol_wrong=1e-8, tol_correct=1e-12, nthreads=1):
+    """lod: (batch, nVar+1, cap) C array; dims: (batch, nObj) or (nObj,). Returns dict of numpy outputs."""
+    lod = np.ascontiguousarray(lod, dtype=np.float64)
+    batch, ncol, cap = lod.shape
+    assert ncol == nvar + 1
+    dims = np.asarray(dims, dtype=np.uint32)
+    if dims.ndim == 1:
+        dims = np.tile(dims, (batch, 1))
+    dims = np.ascontiguousarray(dims)
+    nobj = dims.shape[1]
+    if maxdim is None:
+        maxdim = dims.max(axis=0)
+        extra = cap - int(maxdim.sum())
+        maxdim = maxdim.copy()
+        maxdim[-1] += extra
+    maxdim = np.ascontiguousarray(maxdim, dtype=np.uint32)
+    assert int(maxdim.sum()) == cap
+    out = dict(
+        x=np.zeros((batch, nvar)), factor=np.zeros_like(lod), hh=np.zeros((batch, cap)),
+        perm=np.zeros((batch, nvar), np.uint32), rank=np.zeros((batch, nobj), np.uint32),
+        fcol=np.zeros((batch, nobj), np.uint32), totalrank=np.zeros(batch, np.uint32), v=np.zeros((batch, cap)),
+        lam=np.zeros((batch, nvar + cap)), sens=np.zeros((batch, 3), np.int32), maxabs=np.zeros(batch),
+        ctr_type_out=np.zeros((batch, cap), np.uint8))
+    if nfixed is not None:
+        nfixed = np.ascontiguousarray(nfixed, np.uint32)
+        fixed_idx = np.ascontiguousarray(fixed_idx, np.uint32)
+        fixed_val = np.ascontiguousarray(fixed_val, np.float64)
+        fixed_type = None if fixed_type is None else np.ascontiguousarray(fixed_type, np.uint8)
+    if ctr_type is not None:
+        ctr_type = np.ascontiguousarray(ctr_type, np.uint8)
+    rc = lib().oracle_lse_run(
+        C.c_uint32(batch), C.c_uint32(nvar), C.c_uint32(nobj), _p(maxdim, _u32p), _p(dims, _u32p), _p(lod, _dp), C.c_double(tol),
+        _p(nfixed, _u32p), _p(fixed_idx, _u32p), _p(fixed_val, _dp), _p(fixed_type, _u8p), _p(ctr_type, _u8p),
+        C.c_int(solve_option), C.c_int(sens_obj), C.c_double(tol_wrong), C.c_double(tol_correct),
+        _p(out["x"], _dp), _p(out["factor"], _dp), _p(out["hh"], _dp), _p(out["perm"], _u32p), _p(out["rank"], _u32p),
+        _p(out["fcol"], _u32p), _p(out["totalrank"], _u32p), _p(out["v"], _dp), _p(out["lam"], _dp), _p(out["sens"], _i32p),
+        _p(out["maxabs"], _dp), _p(out["ctr_type_out"], _u8p), C.c_int(nthreads))
+    if rc:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    return out
+
+
+def lse_time(lod, dims, nvar, nthreads, repeats, tol=1e-12):
+    lod = np.ascontiguousarray(lod, dtype=np.float64)
+    batch, ncol, cap = lod.shape
+    dims = np.asarray(dims, dtype=np.uint32)
+    if dims.ndim == 1:
+        dims = np.tile(dims, (batch, 1))
+    dims = np.ascontiguousarray(dims)
+    maxdim = np.ascontiguousarray(dims.max(axis=0), dtype=np.uint32)
+    x = np.zeros((batch, nvar))
+    return lib().oracle_lse_time(C.c_uint32(batch), C.c_uint32(nvar), C.c_uint32(dims.shape[1]), _p(maxdim, _u32p), _p(dims, _u32p),
+                                 _p(lod, _dp), C.c_double(tol), _p(x, _dp), C.c_int(nthreads), C.c_int(repeats)), x
+
+
+def hardware_threads():
+    return int(lib().oracle_hardware_threads())
+
+
+_PARAM_KEYS = ["max_number_of_factorizations", "tol_linear_dependence", "tol_wrong_sign_lambda", "tol_correct_sign_lambda",
+               "tol_feasibility", "cycling_handling_enabled", "cycling_max_counter", "cycling_relax_step", "deactivate_first_wrong_sign"]
+_PARAM_DEFAULTS = [200, 1e-12, 1e-8, 1e-12, 1e-13, 0, 50, 1e-8, 0]
+
+
+def pack_params(**kw):
+    vals = list(_PARAM_DEFAULTS)
+    for k, v in kw.items():
+        vals[_PARAM_KEYS.index(k)] = float(v)
+    return np.array(vals, dtype=np.float64)
+
+
+def flatten_lsi(nvar, objectives):
+    """objectives: list of dicts {A (m x n) | var (m,) 0-based, lb, ub}. -> dims, types, data, var_index"""
+    dims, types, chunks, var_index = [], [], [], np.zeros(0, np.uint32)
+    for k, o in enumerate(objectives):
+        lb, ub = np.asarray(o["lb"], float), np.asarray(o["ub"], float)
+        dims.append(lb.size)
+        if "var" in o:
+            assert k == 0
+            types.append(1)
+            var_index = np.asarray(o["var"], np.uint32)
+            m = np.stack([lb, ub], axis=1)
+        else:
+            types.append(0)
+            m = np.hstack([np.asarray(o["A"], float).reshape(lb.size, nvar), lb[:, None], ub[:, None]])
+        chunks.append(np.asfortranarray(m).ravel(order="F"))
+    data = np.concatenate(chunks) if chunks else np.zeros(0)
+    return (np.array(dims, np.uint32), np.array(types, np.int32), np.ascontiguousarray(data), np.ascontiguousarray(var_index))
+
+
+def lsi_run(nvar, objectives, active_guess=None, x0=None, **params):
+    dims, types, data, var_index = flatten_lsi(nvar, objectives)
+    total = int(dims.sum())
+    x = np.zeros(nvar)
+    info = np.zeros(6, np.int32)
+    active = np.zeros(total, np.uint8)
+    v = np.zeros(total)
+    guess = None if active_guess is None else np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint8) for g in active_guess]))
+    x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
+    par = pack_params(**params)
+    rc = lib().oracle_lsi_run(C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, _u32p), _p(types, _i32p), _p(data, _dp),
+                              _p(var_index if var_index.size else None, _u32p), _p(guess, _u8p), _p(x0a, _dp), _p(par, _dp),
+                              _p(x, _dp), _p(info, _i32p), _p(active, _u8p), _p(v, _dp))
+    if rc:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    keys = ["status", "iterations", "activations", "deactivations", "factorizations", "total_rank"]
+    return dict(x=x, info=dict(zip(keys, info.tolist())), active=np.split(active, np.cumsum(dims)[:-1]), v=np.split(v, np.cumsum(dims)[:-1]))
+
+
+def lsi_lambda(nvar, objectives):
+    dims, types, data, var_index = flatten_lsi(nvar, objectives)
+    total = int(dims.sum())
+    x = np.zeros(nvar)
+    lam = np.zeros((len(dims), total))  # column-major total x nObj
+    rc = lib().oracle_lsi_lambda(C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, _u32p), _p(types, _i32p), _p(data, _dp),
+                                 _p(var_index if var_index.size else None, _u32p), _p(x, _dp), _p(lam, _dp))
+    if rc:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    return x, lam.T.copy()
+
+
+def lsi_run_dat(path, one_based=True, use_active_guess=False, use_x_guess=False):
+    hdr = np.zeros(4, np.int32)
+    if lib().oracle_dat_header(path.encode(), _p(hdr, _i32p)):
+        raise RuntimeError(lib().oracle_last_error().decode())
+    nvar = int(hdr[0])
+    x, sol, info = np.zeros(nvar), np.zeros(nvar), np.zeros(6, np.int32)
+    rc = lib().oracle_lsi_run_dat(path.encode(), C.c_int(one_based), C.c_int(use_active_guess), C.c_int(use_x_guess), _p(x, _dp), _p(info, _i32p),
+                                  _p(sol, _dp))
+    if rc:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    keys = ["status", "iterations", "activations", "deactivations", "factorizations", "total_rank"]
+    return dict(x=x, solution=sol if hdr[3] else None, info=dict(zip(keys, info.tolist())), header=hdr)
