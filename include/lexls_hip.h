@@ -1,0 +1,126 @@
+/* lexls_hip.h — C ABI of the MI355X-native lexicographic-QR core (liblexls_hip.so).
+ *
+ * The reference (jrl-umi3218/lexls) has no FFI: its boundary for this path is the C++ class
+ * LexLS::internal::LexLSE (include/lexls/lexlse.h:33-2886), one object = one problem, all buffers
+ * owned by the object.  This ABI is that class turned into a handle over a BATCH of independent
+ * problems of the same capacity (the solver's intended workload: successive IK-style instances),
+ * each entry point citing the member function it replaces.  Plain pointers and sizes only; no C++
+ * or torch types cross the boundary; errors are status codes + lexls_last_error(), never exceptions.
+ *
+ * Data layout (identical to the reference's storage, lexlse.h:85): one problem is a column-major
+ * cap x (nVar+1) array "LOD" with leading dimension cap = sum(maxObjDim); rows [0, nCtr) hold the
+ * stacked levels [A_k | b_k] (column nVar = right-hand side).  A batch is `batch` such arrays
+ * back to back.  Index = uint32_t, RealScalar = double (typedefs.h:16-17).
+ *
+ * Host pointers are named h_*, device pointers d_*.  All device work is enqueued on the handle's
+ * HIP stream (default: the null stream); calls that return data to the host synchronise that stream.
+ */
+#ifndef LEXLS_HIP_H
+#define LEXLS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lexls_lse_s *lexls_lse_t;
+
+enum lexls_status
+{
+    LEXLS_OK              = 0,
+    LEXLS_ERR_INVALID     = 1, /* bad argument / call order (the reference throws LexLS::Exception) */
+    LEXLS_ERR_HIP         = 2, /* a HIP runtime call failed (message has the HIP error string)      */
+    LEXLS_ERR_UNSUPPORTED = 3, /* feature of the reference that has no device path yet              */
+    LEXLS_ERR_NO_DEVICE   = 4  /* no usable GPU: there is NO CPU fallback in this library           */
+};
+
+/* which device array lexls_lse_device_ptr returns */
+enum lexls_array
+{
+    LEXLS_ARRAY_X = 0,      /* double   batch x nVar            solution                              */
+    LEXLS_ARRAY_FACTOR,     /* double   batch x cap x (nVar+1)  factor ("lexqr")                      */
+    LEXLS_ARRAY_HH,         /* double   batch x cap             Householder scalars                   */
+    LEXLS_ARRAY_PERM,       /* uint32   batch x nVar            column_permutations                   */
+    LEXLS_ARRAY_RANK,       /* uint32   batch x nObj            obj_info[k].rank                      */
+    LEXLS_ARRAY_FIRST_COL,  /* uint32   batch x nObj            obj_info[k].first_col_index           */
+    LEXLS_ARRAY_TOTAL_RANK, /* uint32   batch                   TotalRank                             */
+    LEXLS_ARRAY_V,          /* double   batch x cap             residuals (get_v)                     */
+    LEXLS_ARRAY_LAMBDA,     /* double   batch x (nVar+cap)      [lambda_fixed; lambda] of the last sensitivity call */
+    LEXLS_ARRAY_INPUT       /* double   batch x cap x (nVar+1)  library-owned input buffer            */
+};
+
+const char *lexls_last_error(void);
+int lexls_version(void);
+
+/* number of visible HIP devices; LEXLS_ERR_NO_DEVICE if none */
+int lexls_device_count(int *count);
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+
+/* replaces LexLSE::LexLSE(nVar,nObj,ObjDim) / resize() (lexlse.h:50-103): allocates every device
+ * buffer once for `batch` problems of capacity maxObjDim[k] rows per level. */
+int lexls_lse_create(lexls_lse_t *out, int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_maxObjDim);
+int lexls_lse_destroy(lexls_lse_t h);
+/* all later work of this handle runs on `hip_stream` (a hipStream_t; NULL = null stream) */
+int lexls_lse_set_stream(lexls_lse_t h, void *hip_stream);
+int lexls_lse_synchronize(lexls_lse_t h);
+
+/* ---- problem definition ----------------------------------------------------------------------- */
+
+/* replaces setParameters (lexlse.h:1467); only REGULARIZATION_NONE has a device path (typedefs.h:122) */
+int lexls_lse_set_tolerance(lexls_lse_t h, double tol_linear_dependence);
+/* replaces setObjDim (lexlse.h:1426): h_dims is nObj values (per_problem = 0, same for the whole
+ * batch) or batch x nObj values (ragged batch, per_problem = 1); each dims[k] <= maxObjDim[k] */
+int lexls_lse_set_obj_dim(lexls_lse_t h, const uint32_t *h_dims, int per_problem);
+/* replaces setFixedVariablesCount + fixVariable(s) (lexlse.h:1381-1419, :1449): per problem the
+ * number of fixed variables, then (batch x nVar, first nfixed[b] entries used) index / value /
+ * ConstraintActivationType.  h_nfixed == NULL clears all fixed variables. */
+int lexls_lse_set_fixed(lexls_lse_t h, const uint32_t *h_nfixed, const uint32_t *h_index, const double *h_value, const uint8_t *h_type);
+/* replaces setCtrType (lexlse.h:1548): batch x cap ConstraintActivationType bytes, row order of LOD */
+int lexls_lse_set_ctr_type(lexls_lse_t h, const uint8_t *h_types);
+/* replaces setProblem / setData (lexlse.h:1511-1530): copies batch x cap x (nVar+1) doubles H2D */
+int lexls_lse_set_problem_host(lexls_lse_t h, const double *h_lod);
+/* zero-copy variant: the caller's device buffer becomes the (read-only) input of later factorizations */
+int lexls_lse_set_problem_device(lexls_lse_t h, const double *d_lod);
+
+/* ---- the hot path ------------------------------------------------------------------------------ */
+
+/* replaces factorize() (lexlse.h:117-506): factor, Householder scalars, pivots, ranks on device */
+int lexls_lse_factorize(lexls_lse_t h);
+/* replaces solve() (lexlse.h:1015-1045); needs a factorization */
+int lexls_lse_solve(lexls_lse_t h);
+/* factorize()+solve() in one launch per batch; keep_factor = 0 skips writing the factor to HBM
+ * (x, ranks and pivots only — the "x-only" traffic variant of SURVEY.md section 8(d)) */
+int lexls_lse_factorize_solve(lexls_lse_t h, int keep_factor);
+/* replaces solveLeastNorm_1() (lexlse.h:1052-1131, Givens sweep); needs a factorization */
+int lexls_lse_solve_least_norm(lexls_lse_t h);
+/* replaces get_v() (lexlse.h:1560-1582); needs a factorization */
+int lexls_lse_residual(lexls_lse_t h);
+/* replaces bool ObjectiveSensitivity(ObjIndex, CtrIndex2Remove, ObjIndex2Remove, tolWrong, tolCorrect,
+ * maxAbsValue) (lexlse.h:611-762) incl. findDescentDirection (:935-987) and its mutation of ctr_type.
+ * h_obj_index: one level per problem (batch values; a negative value skips that problem), or NULL
+ * with `obj_index_all` applied to every problem.  Results: lexls_lse_get_sensitivity. */
+int lexls_lse_sensitivity(lexls_lse_t h, const int32_t *h_obj_index, int32_t obj_index_all, double tol_wrong_sign_lambda, double tol_correct_sign_lambda);
+
+/* ---- results (synchronise the stream, then D2H) ------------------------------------------------- */
+int lexls_lse_get_x(lexls_lse_t h, double *h_x);                    /* get_x()      lexlse.h:1587 */
+int lexls_lse_get_factor(lexls_lse_t h, double *h_lod);             /* get_lexqr()  lexlse.h:1626 */
+int lexls_lse_get_hh_scalars(lexls_lse_t h, double *h_hh);
+int lexls_lse_get_permutation(lexls_lse_t h, uint32_t *h_perm);
+int lexls_lse_get_ranks(lexls_lse_t h, uint32_t *h_rank, uint32_t *h_first_col, uint32_t *h_total_rank); /* getRank/getTotalRank :1503,:1603 */
+int lexls_lse_get_v(lexls_lse_t h, double *h_v);                    /* get_v()      lexlse.h:1560 */
+int lexls_lse_get_lambda(lexls_lse_t h, double *h_lambda);          /* getWorkspace() after ObjectiveSensitivity, lexlse.h:1621 */
+/* h_found_ctr_obj: batch x 3 int32 {found, CtrIndex2Remove, ObjIndex2Remove}; h_max_abs: batch */
+int lexls_lse_get_sensitivity(lexls_lse_t h, int32_t *h_found_ctr_obj, double *h_max_abs);
+int lexls_lse_get_ctr_type(lexls_lse_t h, uint8_t *h_types);
+/* raw device pointer of one of the handle's arrays (enum lexls_array), for zero-copy consumers */
+int lexls_lse_device_ptr(lexls_lse_t h, int which, void **d_ptr);
+
+/* name of the kernel variant the last factorize/factorize_solve call dispatched to (diagnostics) */
+const char *lexls_lse_last_kernel(lexls_lse_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEXLS_HIP_H */

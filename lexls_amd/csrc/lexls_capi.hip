@@ -1,0 +1,439 @@
+// C ABI of liblexls_hip (include/lexls_hip.h): handle management, H2D/D2H plumbing and kernel
+// dispatch.  There is deliberately NO CPU fallback: without a usable HIP device every entry point
+// that needs one fails with LEXLS_ERR_NO_DEVICE / LEXLS_ERR_HIP.
+#include "../../include/lexls_hip.h"
+#include "lexls_kernels.h"
+#include "lexls_launch.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace lexls;
+
+namespace
+{
+    thread_local std::string g_err;
+
+    int fail(int code, const std::string &msg)
+    {
+        g_err = msg;
+        return code;
+    }
+
+#define HIP_TRY(expr)                                                                                                   \
+    do                                                                                                                  \
+    {                                                                                                                   \
+        hipError_t e_ = (expr);                                                                                         \
+        if (e_ != hipSuccess) return fail(LEXLS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+#define CHECK_HANDLE(h) \
+    if (!(h)) return fail(LEXLS_ERR_INVALID, "null handle")
+} // namespace
+
+struct lexls_lse_s
+{
+    int device;
+    hipStream_t stream;
+    uint32_t batch, nVar, nObj, cap, max_rows;
+    std::vector<uint32_t> maxdim;
+    double tol;
+    bool dims_set, has_fixed, factor_valid, factor_in_hbm;
+    const char *last_kernel;
+
+    double *d_in_owned;
+    const double *d_in;
+    double *d_fac, *d_x, *d_hh, *d_v, *d_lambda, *d_maxabs, *d_scratch, *d_fixed_val;
+    uint32_t *d_perm, *d_rank, *d_fcol, *d_totalrank, *d_dims, *d_nfixed, *d_fixed_idx;
+    uint8_t *d_fixed_type, *d_ctr_type;
+    int32_t *d_sens, *d_objidx;
+
+    LseArgs args() const
+    {
+        LseArgs a;
+        a.batch = batch;
+        a.nVar  = nVar;
+        a.nObj  = nObj;
+        a.cap   = cap;
+        a.ldp   = odd_ld(max_rows);
+        a.tol   = tol;
+        a.in    = d_in;
+        a.fac   = d_fac;
+        a.x     = d_x;
+        a.hh    = d_hh;
+        a.perm  = d_perm;
+        a.rank  = d_rank;
+        a.fcol  = d_fcol;
+        a.totalrank  = d_totalrank;
+        a.dims       = d_dims;
+        a.nfixed     = has_fixed ? d_nfixed : nullptr;
+        a.fixed_idx  = d_fixed_idx;
+        a.fixed_val  = d_fixed_val;
+        a.fixed_type = d_fixed_type;
+        a.ctr_type   = d_ctr_type;
+        a.v          = d_v;
+        a.lambda     = d_lambda;
+        a.sens       = d_sens;
+        a.maxabs     = d_maxabs;
+        a.scratch    = d_scratch;
+        return a;
+    }
+    size_t problem_elems() const { return (size_t)cap * (nVar + 1); }
+};
+
+extern "C"
+{
+    const char *lexls_last_error(void) { return g_err.c_str(); }
+    int lexls_version(void) { return 100; }
+
+    int lexls_device_count(int *count)
+    {
+        int n        = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (count) *count = (e == hipSuccess) ? n : 0;
+        if (e != hipSuccess || n == 0) return fail(LEXLS_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_create(lexls_lse_t *out, int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_maxObjDim)
+    {
+        if (!out || !h_maxObjDim || batch == 0 || nVar == 0 || nObj == 0) return fail(LEXLS_ERR_INVALID, "lexls_lse_create: bad argument");
+        int ndev = 0;
+        if (lexls_device_count(&ndev) != LEXLS_OK) return LEXLS_ERR_NO_DEVICE;
+        if (device < 0 || device >= ndev) return fail(LEXLS_ERR_INVALID, "lexls_lse_create: device index out of range");
+        HIP_TRY(hipSetDevice(device));
+
+        lexls_lse_s *h = new (std::nothrow) lexls_lse_s();
+        if (!h) return fail(LEXLS_ERR_INVALID, "out of host memory");
+        h->device = device;
+        h->stream = nullptr;
+        h->batch  = batch;
+        h->nVar   = nVar;
+        h->nObj   = nObj;
+        h->maxdim.assign(h_maxObjDim, h_maxObjDim + nObj);
+        h->cap = 0;
+        for (uint32_t k = 0; k < nObj; k++) h->cap += h_maxObjDim[k];
+        if (h->cap == 0)
+        {
+            delete h;
+            return fail(LEXLS_ERR_INVALID, "lexls_lse_create: zero capacity");
+        }
+        h->max_rows    = h->cap;
+        h->tol         = 1e-12; // typedefs.h:120
+        h->dims_set    = false;
+        h->has_fixed   = false;
+        h->factor_valid = h->factor_in_hbm = false;
+        h->last_kernel = "";
+        h->d_in_owned  = nullptr;
+        h->d_in        = nullptr;
+        h->d_scratch   = nullptr;
+
+        const size_t B = batch, n = nVar, cap = h->cap;
+        hipError_t e   = hipSuccess;
+        auto alloc     = [&](void **p, size_t bytes) {
+            if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 8);
+        };
+        alloc((void **)&h->d_fac, 8 * B * h->problem_elems());
+        alloc((void **)&h->d_x, 8 * B * n);
+        alloc((void **)&h->d_hh, 8 * B * cap);
+        alloc((void **)&h->d_v, 8 * B * cap);
+        alloc((void **)&h->d_lambda, 8 * B * (n + cap));
+        alloc((void **)&h->d_maxabs, 8 * B);
+        alloc((void **)&h->d_fixed_val, 8 * B * n);
+        alloc((void **)&h->d_perm, 4 * B * n);
+        alloc((void **)&h->d_rank, 4 * B * nObj);
+        alloc((void **)&h->d_fcol, 4 * B * nObj);
+        alloc((void **)&h->d_totalrank, 4 * B);
+        alloc((void **)&h->d_dims, 4 * B * nObj);
+        alloc((void **)&h->d_nfixed, 4 * B);
+        alloc((void **)&h->d_fixed_idx, 4 * B * n);
+        alloc((void **)&h->d_fixed_type, B * n);
+        alloc((void **)&h->d_ctr_type, B * cap);
+        alloc((void **)&h->d_sens, 4 * B * 3);
+        alloc((void **)&h->d_objidx, 4 * B);
+        if (e == hipSuccess) e = hipMemset(h->d_ctr_type, 0, B * cap);
+        if (e == hipSuccess) e = hipMemset(h->d_fixed_type, 0, B * n);
+        if (e == hipSuccess) e = hipMemset(h->d_nfixed, 0, 4 * B);
+        if (e != hipSuccess)
+        {
+            lexls_lse_destroy(h);
+            return fail(LEXLS_ERR_HIP, std::string("lexls_lse_create: ") + hipGetErrorString(e));
+        }
+        // default dims = capacities (LexLSE(nVar,nObj,ObjDim) constructor semantics, lexlse.h:50-54)
+        *out = h;
+        return lexls_lse_set_obj_dim(h, h_maxObjDim, 0);
+    }
+
+    int lexls_lse_destroy(lexls_lse_t h)
+    {
+        if (!h) return LEXLS_OK;
+        (void)hipSetDevice(h->device);
+        void *ptrs[] = {h->d_in_owned, h->d_fac,     h->d_x,      h->d_hh,        h->d_v,        h->d_lambda,     h->d_maxabs,
+                        h->d_scratch,  h->d_fixed_val, h->d_perm,   h->d_rank,      h->d_fcol,     h->d_totalrank,  h->d_dims,
+                        h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx};
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+        delete h;
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_stream(lexls_lse_t h, void *hip_stream)
+    {
+        CHECK_HANDLE(h);
+        h->stream = static_cast<hipStream_t>(hip_stream);
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_synchronize(lexls_lse_t h)
+    {
+        CHECK_HANDLE(h);
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_tolerance(lexls_lse_t h, double tol)
+    {
+        CHECK_HANDLE(h);
+        h->tol = tol;
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_obj_dim(lexls_lse_t h, const uint32_t *h_dims, int per_problem)
+    {
+        CHECK_HANDLE(h);
+        if (!h_dims) return fail(LEXLS_ERR_INVALID, "set_obj_dim: null dims");
+        std::vector<uint32_t> d((size_t)h->batch * h->nObj);
+        uint32_t max_rows = 0;
+        for (uint32_t b = 0; b < h->batch; b++)
+        {
+            uint32_t m = 0;
+            for (uint32_t k = 0; k < h->nObj; k++)
+            {
+                const uint32_t v = per_problem ? h_dims[(size_t)b * h->nObj + k] : h_dims[k];
+                if (v > h->maxdim[k]) return fail(LEXLS_ERR_INVALID, "set_obj_dim: dimension exceeds the capacity given at creation");
+                d[(size_t)b * h->nObj + k] = v;
+                m += v;
+            }
+            if (m > max_rows) max_rows = m;
+        }
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpyAsync(h->d_dims, d.data(), 4 * d.size(), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream)); // d is a temporary
+        h->max_rows     = max_rows ? max_rows : 1;
+        h->dims_set     = true;
+        h->factor_valid = false;
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_fixed(lexls_lse_t h, const uint32_t *h_nfixed, const uint32_t *h_index, const double *h_value, const uint8_t *h_type)
+    {
+        CHECK_HANDLE(h);
+        HIP_TRY(hipSetDevice(h->device));
+        h->factor_valid = false;
+        if (!h_nfixed)
+        {
+            h->has_fixed = false;
+            return LEXLS_OK;
+        }
+        if (!h_index || !h_value) return fail(LEXLS_ERR_INVALID, "set_fixed: null index/value");
+        bool any = false;
+        for (uint32_t b = 0; b < h->batch; b++)
+        {
+            if (h_nfixed[b] > h->nVar) return fail(LEXLS_ERR_INVALID, "Cannot fix more than nVar variables"); // lexlse.h:1453
+            for (uint32_t k = 0; k < h_nfixed[b]; k++)
+                if (h_index[(size_t)b * h->nVar + k] >= h->nVar) return fail(LEXLS_ERR_INVALID, "set_fixed: variable index out of range");
+            any = any || h_nfixed[b] > 0;
+        }
+        const size_t B = h->batch, n = h->nVar;
+        HIP_TRY(hipMemcpyAsync(h->d_nfixed, h_nfixed, 4 * B, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_fixed_idx, h_index, 4 * B * n, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_fixed_val, h_value, 8 * B * n, hipMemcpyHostToDevice, h->stream));
+        if (h_type)
+            HIP_TRY(hipMemcpyAsync(h->d_fixed_type, h_type, B * n, hipMemcpyHostToDevice, h->stream));
+        else
+            HIP_TRY(hipMemsetAsync(h->d_fixed_type, CTR_ACTIVE_UB, B * n, h->stream)); // default of fixVariable, lexlse.h:1381
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->has_fixed = any;
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_ctr_type(lexls_lse_t h, const uint8_t *h_types)
+    {
+        CHECK_HANDLE(h);
+        if (!h_types) return fail(LEXLS_ERR_INVALID, "set_ctr_type: null");
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpyAsync(h->d_ctr_type, h_types, (size_t)h->batch * h->cap, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_problem_host(lexls_lse_t h, const double *h_lod)
+    {
+        CHECK_HANDLE(h);
+        if (!h_lod) return fail(LEXLS_ERR_INVALID, "set_problem_host: null");
+        HIP_TRY(hipSetDevice(h->device));
+        const size_t bytes = 8 * (size_t)h->batch * h->problem_elems();
+        if (!h->d_in_owned) HIP_TRY(hipMalloc((void **)&h->d_in_owned, bytes));
+        HIP_TRY(hipMemcpyAsync(h->d_in_owned, h_lod, bytes, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->d_in         = h->d_in_owned;
+        h->factor_valid = false;
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_problem_device(lexls_lse_t h, const double *d_lod)
+    {
+        CHECK_HANDLE(h);
+        if (!d_lod) return fail(LEXLS_ERR_INVALID, "set_problem_device: null");
+        h->d_in         = d_lod;
+        h->factor_valid = false;
+        return LEXLS_OK;
+    }
+
+    static int run_lqr(lexls_lse_t h, bool write_factor, bool do_solve)
+    {
+        CHECK_HANDLE(h);
+        if (!h->d_in) return fail(LEXLS_ERR_INVALID, "no problem data: call lexls_lse_set_problem_host/device first");
+        HIP_TRY(hipSetDevice(h->device));
+        const char *variant = "";
+        HIP_TRY(launch_lqr_generic(h->args(), h->max_rows, write_factor, do_solve, h->stream, &variant));
+        h->last_kernel   = variant;
+        h->factor_valid  = true;
+        h->factor_in_hbm = write_factor || std::strstr(variant, "hbm") != nullptr;
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_factorize(lexls_lse_t h) { return run_lqr(h, true, false); }
+    int lexls_lse_factorize_solve(lexls_lse_t h, int keep_factor) { return run_lqr(h, keep_factor != 0, true); }
+
+    static int need_factor(lexls_lse_t h, const char *who)
+    {
+        CHECK_HANDLE(h);
+        if (!h->factor_valid || !h->factor_in_hbm) return fail(LEXLS_ERR_INVALID, std::string(who) + ": needs a factorization whose factor was kept");
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_solve(lexls_lse_t h)
+    {
+        if (int rc = need_factor(h, "lexls_lse_solve")) return rc;
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(launch_solve_generic(h->args(), h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_solve_least_norm(lexls_lse_t h)
+    {
+        if (int rc = need_factor(h, "lexls_lse_solve_least_norm")) return rc;
+        HIP_TRY(hipSetDevice(h->device));
+        if (!h->d_scratch) HIP_TRY(hipMalloc((void **)&h->d_scratch, 8 * (size_t)h->batch * 2 * h->nVar * h->nVar));
+        HIP_TRY(launch_leastnorm(h->args(), h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_residual(lexls_lse_t h)
+    {
+        if (int rc = need_factor(h, "lexls_lse_residual")) return rc;
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(launch_residual(h->args(), h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_sensitivity(lexls_lse_t h, const int32_t *h_obj_index, int32_t obj_index_all, double tolW, double tolC)
+    {
+        if (int rc = need_factor(h, "lexls_lse_sensitivity")) return rc;
+        HIP_TRY(hipSetDevice(h->device));
+        const int32_t *d_obj = nullptr;
+        if (h_obj_index)
+        {
+            HIP_TRY(hipMemcpyAsync(h->d_objidx, h_obj_index, 4 * (size_t)h->batch, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            d_obj = h->d_objidx;
+        }
+        else if (obj_index_all < 0 || (uint32_t)obj_index_all >= h->nObj)
+        {
+            return fail(LEXLS_ERR_INVALID, "ObjIndex >= nObj");
+        }
+        HIP_TRY(launch_sensitivity(h->args(), d_obj, obj_index_all, tolW, tolC, h->stream));
+        return LEXLS_OK;
+    }
+
+    static int download(lexls_lse_t h, void *dst, const void *src, size_t bytes)
+    {
+        CHECK_HANDLE(h);
+        if (!dst) return fail(LEXLS_ERR_INVALID, "null output pointer");
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_get_x(lexls_lse_t h, double *h_x) { return h ? download(h, h_x, h->d_x, 8 * (size_t)h->batch * h->nVar) : fail(LEXLS_ERR_INVALID, "null handle"); }
+    int lexls_lse_get_factor(lexls_lse_t h, double *h_lod)
+    {
+        if (int rc = need_factor(h, "lexls_lse_get_factor")) return rc;
+        return download(h, h_lod, h->d_fac, 8 * (size_t)h->batch * h->problem_elems());
+    }
+    int lexls_lse_get_hh_scalars(lexls_lse_t h, double *h_hh) { return h ? download(h, h_hh, h->d_hh, 8 * (size_t)h->batch * h->cap) : fail(LEXLS_ERR_INVALID, "null handle"); }
+    int lexls_lse_get_permutation(lexls_lse_t h, uint32_t *h_perm)
+    {
+        return h ? download(h, h_perm, h->d_perm, 4 * (size_t)h->batch * h->nVar) : fail(LEXLS_ERR_INVALID, "null handle");
+    }
+    int lexls_lse_get_ranks(lexls_lse_t h, uint32_t *h_rank, uint32_t *h_first_col, uint32_t *h_total_rank)
+    {
+        CHECK_HANDLE(h);
+        int rc = LEXLS_OK;
+        if (h_rank) rc = download(h, h_rank, h->d_rank, 4 * (size_t)h->batch * h->nObj);
+        if (!rc && h_first_col) rc = download(h, h_first_col, h->d_fcol, 4 * (size_t)h->batch * h->nObj);
+        if (!rc && h_total_rank) rc = download(h, h_total_rank, h->d_totalrank, 4 * (size_t)h->batch);
+        return rc;
+    }
+    int lexls_lse_get_v(lexls_lse_t h, double *h_v) { return h ? download(h, h_v, h->d_v, 8 * (size_t)h->batch * h->cap) : fail(LEXLS_ERR_INVALID, "null handle"); }
+    int lexls_lse_get_lambda(lexls_lse_t h, double *h_lambda)
+    {
+        return h ? download(h, h_lambda, h->d_lambda, 8 * (size_t)h->batch * (h->nVar + h->cap)) : fail(LEXLS_ERR_INVALID, "null handle");
+    }
+    int lexls_lse_get_sensitivity(lexls_lse_t h, int32_t *h_found_ctr_obj, double *h_max_abs)
+    {
+        CHECK_HANDLE(h);
+        int rc = LEXLS_OK;
+        if (h_found_ctr_obj) rc = download(h, h_found_ctr_obj, h->d_sens, 4 * (size_t)h->batch * 3);
+        if (!rc && h_max_abs) rc = download(h, h_max_abs, h->d_maxabs, 8 * (size_t)h->batch);
+        return rc;
+    }
+    int lexls_lse_get_ctr_type(lexls_lse_t h, uint8_t *h_types) { return h ? download(h, h_types, h->d_ctr_type, (size_t)h->batch * h->cap) : fail(LEXLS_ERR_INVALID, "null handle"); }
+
+    int lexls_lse_device_ptr(lexls_lse_t h, int which, void **d_ptr)
+    {
+        CHECK_HANDLE(h);
+        if (!d_ptr) return fail(LEXLS_ERR_INVALID, "null output pointer");
+        switch (which)
+        {
+        case LEXLS_ARRAY_X: *d_ptr = h->d_x; break;
+        case LEXLS_ARRAY_FACTOR: *d_ptr = h->d_fac; break;
+        case LEXLS_ARRAY_HH: *d_ptr = h->d_hh; break;
+        case LEXLS_ARRAY_PERM: *d_ptr = h->d_perm; break;
+        case LEXLS_ARRAY_RANK: *d_ptr = h->d_rank; break;
+        case LEXLS_ARRAY_FIRST_COL: *d_ptr = h->d_fcol; break;
+        case LEXLS_ARRAY_TOTAL_RANK: *d_ptr = h->d_totalrank; break;
+        case LEXLS_ARRAY_V: *d_ptr = h->d_v; break;
+        case LEXLS_ARRAY_LAMBDA: *d_ptr = h->d_lambda; break;
+        case LEXLS_ARRAY_INPUT:
+            if (!h->d_in_owned)
+            {
+                HIP_TRY(hipSetDevice(h->device));
+                HIP_TRY(hipMalloc((void **)&h->d_in_owned, 8 * (size_t)h->batch * h->problem_elems()));
+            }
+            *d_ptr  = h->d_in_owned;
+            h->d_in = h->d_in_owned;
+            break;
+        default: return fail(LEXLS_ERR_INVALID, "unknown array id");
+        }
+        return LEXLS_OK;
+    }
+
+    const char *lexls_lse_last_kernel(lexls_lse_t h) { return h ? h->last_kernel : ""; }
+}

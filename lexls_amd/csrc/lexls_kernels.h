@@ -1,0 +1,44 @@
+// Device-side argument block shared by every kernel of liblexls_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lexls
+{
+    // ConstraintActivationType values (reference typedefs.h:69-76)
+    enum : uint8_t
+    {
+        CTR_INACTIVE           = 0,
+        CTR_ACTIVE_LB          = 1,
+        CTR_ACTIVE_UB          = 2,
+        CTR_ACTIVE_EQ          = 3,
+        CORRECT_SIGN_OF_LAMBDA = 4
+    };
+
+    /// One batch of equality problems resident in HBM.  All per-problem arrays are dense, problem-major.
+    struct LseArgs
+    {
+        uint32_t batch, nVar, nObj, cap; // cap = sum(maxObjDim) = leading dimension of one problem
+        uint32_t ldp;                    // padded (odd) leading dimension of the LDS image
+        double tol;                      // tol_linear_dependence (compared with a SQUARED norm, lexlse.h:214)
+        const double *in;                // batch x cap x (nVar+1)  problem data (read-only)
+        double *fac;                     // batch x cap x (nVar+1)  factor
+        double *x;                       // batch x nVar
+        double *hh;                      // batch x cap
+        uint32_t *perm;                  // batch x nVar
+        uint32_t *rank;                  // batch x nObj
+        uint32_t *fcol;                  // batch x nObj
+        uint32_t *totalrank;             // batch
+        const uint32_t *dims;            // batch x nObj
+        const uint32_t *nfixed;          // batch (NULL: no fixed variables anywhere)
+        const uint32_t *fixed_idx;       // batch x nVar
+        const double *fixed_val;         // batch x nVar
+        uint8_t *fixed_type;             // batch x nVar
+        uint8_t *ctr_type;               // batch x cap
+        double *v;                       // batch x cap
+        double *lambda;                  // batch x (nVar + cap)
+        int32_t *sens;                   // batch x 3
+        double *maxabs;                  // batch
+        double *scratch;                 // batch x nVar x (nVar+1) (least-norm only, may be NULL)
+    };
+} // namespace lexls

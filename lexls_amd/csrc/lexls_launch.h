@@ -1,0 +1,19 @@
+// Host-side launchers of the liblexls_hip kernels (one per translation unit that defines kernels).
+#pragma once
+#include "lexls_kernels.h"
+
+namespace lexls
+{
+    /// maximum dynamic LDS one workgroup may ask for on gfx950 (160 KiB per CU)
+    constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+    /// odd leading dimension >= rows for the LDS image (conflict-free column-per-lane access)
+    inline uint32_t odd_ld(uint32_t rows) { return rows | 1u; }
+
+    // lqr_generic.hip — any shape, one workgroup per problem
+    hipError_t launch_lqr_generic(LseArgs a, uint32_t max_rows, bool write_factor, bool do_solve, hipStream_t s, const char **variant);
+    hipError_t launch_solve_generic(const LseArgs &a, hipStream_t s);
+    hipError_t launch_residual(const LseArgs &a, hipStream_t s);
+    hipError_t launch_sensitivity(const LseArgs &a, const int32_t *d_obj_index, int32_t obj_all, double tolW, double tolC, hipStream_t s);
+    hipError_t launch_leastnorm(const LseArgs &a, hipStream_t s);
+} // namespace lexls

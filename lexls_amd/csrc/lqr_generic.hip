@@ -1,0 +1,905 @@
+// Generic lexicographic-QR kernels: ONE WORKGROUP PER PROBLEM, any shape.
+//
+// This is the shape-agnostic path of liblexls_hip: it factors and solves a problem of any size
+// (matrix staged in LDS when it fits in the CU's 160 KiB, otherwise worked on in HBM/L2) and is the
+// fallback behind the shape-specialised kernels.  It follows the reference algorithm statement by
+// statement — LexLSE::factorize() lexlse.h:117-506, solve() :1015-1045 — and evaluates every
+// reduction in the order fixed by the arithmetic contract in oracle/lexlse_oracle.h (ascending fma
+// chains, first-occurrence argmax, IEEE division/sqrt), so its results are bit-identical to the
+// CPU oracle's.  Parallelism inside a problem: columns across lanes for norms / Householder
+// application (each lane owns whole columns, so every dot product is a lane-local ordered chain,
+// no cross-lane reduction), rows across lanes for the column swap and the Gauss TRSM, elements
+// across lanes for the trailing update.
+//
+// LDS image: column-major with an ODD leading dimension ldp so that "lane j reads (i, j)" hits 32
+// distinct 8-byte bank pairs (ds_read_b64: bank = (addr/4) % 64, stride 2*ldp dwords).
+#include "lexls_kernels.h"
+#include "lexls_launch.h"
+
+#include <cfloat>
+
+namespace lexls
+{
+    namespace
+    {
+        __device__ __forceinline__ double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+        /// block-wide "first index of the maximum": every thread passes its best candidate
+        template <int NT>
+        __device__ __forceinline__ uint32_t block_argmax(double v, uint32_t idx, double *rv, uint32_t *ri, uint32_t tid)
+        {
+            rv[tid] = v;
+            ri[tid] = idx;
+            __syncthreads();
+#pragma unroll
+            for (int s = NT / 2; s > 0; s >>= 1)
+            {
+                if (tid < (uint32_t)s)
+                {
+                    const double v2   = rv[tid + s];
+                    const uint32_t i2 = ri[tid + s];
+                    if (v2 > rv[tid] || (v2 == rv[tid] && i2 < ri[tid]))
+                    {
+                        rv[tid] = v2;
+                        ri[tid] = i2;
+                    }
+                }
+                __syncthreads();
+            }
+            const uint32_t out = ri[0];
+            __syncthreads();
+            return out;
+        }
+
+        struct Shared
+        {
+            double tau, beta, den;
+            uint32_t piv;
+            int stop, degenerate;
+        };
+
+        /// v <- Q_k v (Householder sequence H_0 ... H_{r-1}, last reflector first; lexlse.h:1576-1578).
+        /// v points at the level's first entry (LDS); W is the factor.  Block-wide.
+        template <int NT>
+        __device__ void apply_q_block(const double *W, size_t ld, const double *hh, uint32_t F, uint32_t Fc, uint32_t dim, uint32_t rank, double *v,
+                                      double *bcast, uint32_t tid)
+        {
+            for (uint32_t j = rank; j--;)
+            {
+                const uint32_t rows = dim - j;
+                const double tau    = hh[F + j];
+                const double *ess   = W + (F + j + 1) + (size_t)(Fc + j) * ld;
+                if (rows == 1)
+                {
+                    if (tid == 0) v[j] *= (1.0 - tau);
+                    __syncthreads();
+                }
+                else if (tau != 0.0)
+                {
+                    if (tid == 0)
+                    {
+                        double t = 0.0;
+                        for (uint32_t i = 1; i < rows; i++) t = dfma(ess[i - 1], v[j + i], t);
+                        t += v[j];
+                        *bcast = t;
+                    }
+                    __syncthreads();
+                    const double t = *bcast;
+                    for (uint32_t i = tid; i < rows; i += NT)
+                    {
+                        if (i == 0)
+                            v[j] = dfma(-tau, t, v[j]);
+                        else
+                            v[j + i] = dfma(-(tau * ess[i - 1]), t, v[j + i]);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+
+        // -----------------------------------------------------------------------------------------
+        // factorize (+ solve)
+        // -----------------------------------------------------------------------------------------
+        template <int NT, bool LDSMAT>
+        __global__ __launch_bounds__(NT) void lqr_generic_kernel(LseArgs a, int write_factor, int do_solve)
+        {
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.x, tid = threadIdx.x;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const size_t pstride = (size_t)cap * (n + 1);
+
+            // ---- LDS carve-up (doubles first) ----
+            double *W;
+            size_t ld;
+            double *p = smem;
+            if (LDSMAT)
+            {
+                W  = p;
+                ld = a.ldp;
+                p += (size_t)a.ldp * (n + 1);
+            }
+            else
+            {
+                W  = a.fac + b * pstride;
+                ld = cap;
+            }
+            double *norms  = p;
+            double *xs     = norms + n;
+            double *red_v  = xs + n;
+            Shared *sh     = reinterpret_cast<Shared *>(red_v + NT);
+            uint32_t *red_i  = reinterpret_cast<uint32_t *>(sh + 1);
+            uint32_t *perm_s = red_i + NT;
+            uint32_t *rk_s   = perm_s + n;
+            uint32_t *fc_s   = rk_s + nObj;
+            uint32_t *fr_s   = fc_s + nObj;
+
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            uint32_t M           = 0;
+            for (uint32_t k = 0; k < nObj; k++)
+            {
+                if (tid == 0)
+                {
+                    fr_s[k] = M;
+                    rk_s[k] = 0;
+                    fc_s[k] = 0;
+                }
+                M += dims[k];
+            }
+
+            // ---- stage the problem (coalesced down the columns) ----
+            const double *in = a.in + b * pstride;
+            if (LDSMAT || in != W)
+                for (uint32_t j = 0; j <= n; j++)
+                    for (uint32_t i = tid; i < M; i += NT) W[i + j * ld] = in[i + (size_t)j * cap];
+            double *hh = a.hh + (size_t)b * cap;
+            for (uint32_t i = tid; i < cap; i += NT) hh[i] = 0.0; // initialize(), lexlse.h:1683
+            for (uint32_t i = tid; i < n; i += NT) perm_s[i] = i;
+            const uint32_t nf = a.nfixed ? a.nfixed[b] : 0;
+            for (uint32_t i = tid; i < n; i += NT) xs[i] = (i < nf) ? a.fixed_val[(size_t)b * n + i] : 0.0;
+            __syncthreads();
+
+            // ---- fixed variables: their columns go first, their contribution goes to the RHS (lexlse.h:132-156) ----
+            if (nf > 0)
+            {
+                if (tid == 0)
+                {
+                    uint32_t *fi = red_i; // scratch copy of fixed_var_index (nf <= n; red_i has NT entries, so spill to norms when larger)
+                    uint32_t *fidx = (nf <= (uint32_t)NT) ? fi : reinterpret_cast<uint32_t *>(norms);
+                    for (uint32_t k = 0; k < nf; k++) fidx[k] = a.fixed_idx[(size_t)b * n + k];
+                    for (uint32_t k = 0; k < nf; k++)
+                    {
+                        const uint32_t coeff = fidx[k];
+                        perm_s[k]            = coeff;
+                        for (uint32_t i = k + 1; i < nf; i++)
+                        {
+                            if (fidx[i] == k)
+                            {
+                                fidx[i] = coeff;
+                                break;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                for (uint32_t k = 0; k < nf; k++)
+                {
+                    const uint32_t coeff = perm_s[k];
+                    if (coeff != k)
+                        for (uint32_t i = tid; i < M; i += NT)
+                        {
+                            const double t    = W[i + k * ld];
+                            W[i + k * ld]     = W[i + coeff * ld];
+                            W[i + coeff * ld] = t;
+                        }
+                    __syncthreads();
+                }
+                for (uint32_t i = tid; i < M; i += NT)
+                {
+                    double s = 0.0;
+                    for (uint32_t k = 0; k < nf; k++) s = dfma(W[i + k * ld], xs[k], s);
+                    W[i + n * ld] -= s;
+                }
+                __syncthreads();
+            }
+
+            uint32_t ColIndex  = nf;
+            uint32_t TotalRank = nf;
+
+            if (ColIndex < n)
+            {
+                for (uint32_t ObjIndex = 0; ObjIndex < nObj; ObjIndex++)
+                {
+                    const uint32_t F = fr_s[ObjIndex], Fc = ColIndex, dim = dims[ObjIndex];
+                    if (tid == 0) fc_s[ObjIndex] = Fc;
+
+                    // initial squared column norms of the level (lexlse.h:193-196): one ordered chain per column
+                    for (uint32_t k = ColIndex + tid; k < n; k += NT)
+                    {
+                        double s = 0.0;
+                        for (uint32_t i = 0; i < dim; i++) s = dfma(W[F + i + k * ld], W[F + i + k * ld], s);
+                        norms[k] = s;
+                    }
+                    __syncthreads();
+
+                    for (uint32_t counter = 0; counter < dim; counter++)
+                    {
+                        const uint32_t row = F + counter, R = dim - counter;
+
+                        // pivot = first maximum of the down-dated norms (lexlse.h:205-206)
+                        double bv   = -INFINITY;
+                        uint32_t bi = 0xffffffffu;
+                        for (uint32_t k = ColIndex + tid; k < n; k += NT)
+                            if (norms[k] > bv)
+                            {
+                                bv = norms[k];
+                                bi = k;
+                            }
+                        const uint32_t piv = block_argmax<NT>(bv, bi, red_v, red_i, tid);
+
+                        // fresh norm, rank test, Householder scalars (lexlse.h:210-217, :241)
+                        if (tid == 0)
+                        {
+                            const double *col = W + row + piv * ld;
+                            double fresh      = 0.0;
+                            for (uint32_t i = 0; i < R; i++) fresh = dfma(col[i], col[i], fresh);
+                            norms[piv]     = fresh;
+                            sh->stop       = fresh < a.tol;
+                            sh->degenerate = 0;
+                            sh->tau        = 0.0;
+                            if (!sh->stop)
+                            {
+                                perm_s[ColIndex]       = piv;
+                                const double t         = norms[ColIndex];
+                                norms[ColIndex]        = norms[piv];
+                                norms[piv]             = t;
+                                if (R > 1)
+                                {
+                                    double tailSq = 0.0;
+                                    for (uint32_t i = 1; i < R; i++) tailSq = dfma(col[i], col[i], tailSq);
+                                    const double c0 = col[0];
+                                    if (tailSq <= DBL_MIN)
+                                    {
+                                        sh->degenerate = 1;
+                                        sh->beta       = c0;
+                                    }
+                                    else
+                                    {
+                                        double beta = sqrt(dfma(c0, c0, tailSq));
+                                        if (c0 >= 0.0) beta = -beta;
+                                        sh->beta = beta;
+                                        sh->den  = c0 - beta;
+                                        sh->tau  = (beta - c0) / beta;
+                                    }
+                                }
+                            }
+                        }
+                        __syncthreads();
+                        if (sh->stop) break; // uniform
+
+                        // column swap over ALL nCtr rows (lexlse.h:222-232) fused with writing beta / the essential part
+                        {
+                            const double den = sh->den, beta = sh->beta;
+                            const int degenerate = sh->degenerate;
+                            for (uint32_t i = tid; i < M; i += NT)
+                            {
+                                const double a1 = W[i + ColIndex * ld];
+                                const double a2 = W[i + piv * ld];
+                                double newc     = a2;
+                                if (R > 1)
+                                {
+                                    if (i == row)
+                                        newc = beta;
+                                    else if (i > row && i < row + R)
+                                        newc = degenerate ? 0.0 : a2 / den;
+                                }
+                                W[i + ColIndex * ld] = newc;
+                                if (piv != ColIndex) W[i + piv * ld] = a1;
+                            }
+                        }
+                        __syncthreads();
+
+                        // apply H to the trailing columns incl. the RHS (lexlse.h:243-246), then down-date (:262-266)
+                        {
+                            const double tau  = sh->tau;
+                            const double *ess = W + row + 1 + ColIndex * ld;
+                            for (uint32_t j = ColIndex + 1 + tid; j <= n; j += NT)
+                            {
+                                double *col = W + row + j * ld;
+                                if (R > 1 && tau != 0.0)
+                                {
+                                    double tmp = 0.0;
+                                    for (uint32_t i = 1; i < R; i++) tmp = dfma(ess[i - 1], col[i], tmp);
+                                    tmp += col[0];
+                                    col[0] = dfma(-tau, tmp, col[0]);
+                                    for (uint32_t i = 1; i < R; i++) col[i] = dfma(-(tau * ess[i - 1]), tmp, col[i]);
+                                }
+                                if (j < n) norms[j] = dfma(-col[0], col[0], norms[j]);
+                            }
+                            if (tid == 0 && R > 1) hh[row] = tau;
+                        }
+                        ColIndex++;
+                        __syncthreads();
+                        if (ColIndex == n) break;
+                    }
+
+                    const uint32_t rank = ColIndex - Fc;
+                    if (tid == 0) rk_s[ObjIndex] = rank;
+                    TotalRank += rank;
+
+                    // Gauss step (lexlse.h:431-471)
+                    if (ObjIndex + 1 < nObj && rank > 0)
+                    {
+                        const uint32_t Fn = F + dim;
+                        for (uint32_t i = Fn + tid; i < M; i += NT) // L <- L R^-1, one row per lane
+                        {
+                            for (uint32_t p2 = 0; p2 < rank; p2++)
+                            {
+                                double s = W[i + (Fc + p2) * ld];
+                                for (uint32_t q = 0; q < p2; q++) s = dfma(-W[i + (Fc + q) * ld], W[F + q + (Fc + p2) * ld], s);
+                                W[i + (Fc + p2) * ld] = s / W[F + p2 + (Fc + p2) * ld];
+                            }
+                        }
+                        __syncthreads();
+                        const uint32_t nrows = M - Fn, ncols = n - ColIndex + 1;
+                        if (nrows > 0)
+                            for (uint32_t e = tid; e < nrows * ncols; e += NT) // Trailing -= L * Up, one element per lane
+                            {
+                                const uint32_t i = Fn + e % nrows, j = ColIndex + e / nrows;
+                                double t         = W[i + j * ld];
+                                for (uint32_t p2 = 0; p2 < rank; p2++) t = dfma(-W[i + (Fc + p2) * ld], W[F + p2 + j * ld], t);
+                                W[i + j * ld] = t;
+                            }
+                        __syncthreads();
+                    }
+
+                    if (ColIndex == n) // lexlse.h:475-490
+                    {
+                        if (tid == 0)
+                            for (uint32_t k = ObjIndex + 1; k < nObj; k++) fc_s[k] = fc_s[k - 1] + rk_s[k - 1];
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- results of factorize() ----
+            for (uint32_t k = tid; k < nObj; k += NT)
+            {
+                a.rank[(size_t)b * nObj + k] = rk_s[k];
+                a.fcol[(size_t)b * nObj + k] = fc_s[k];
+            }
+            for (uint32_t i = tid; i < n; i += NT) a.perm[(size_t)b * n + i] = (i < TotalRank) ? perm_s[i] : i;
+            if (tid == 0) a.totalrank[b] = TotalRank;
+            if (LDSMAT && write_factor)
+            {
+                double *out = a.fac + b * pstride;
+                for (uint32_t j = 0; j <= n; j++)
+                    for (uint32_t i = tid; i < M; i += NT) out[i + (size_t)j * cap] = W[i + j * ld];
+            }
+
+            // ---- solve(): block back-substitution (lexlse.h:1015-1045) ----
+            if (do_solve)
+            {
+                uint32_t acc = 0;
+                for (uint32_t k = nObj; k--;)
+                {
+                    const uint32_t rank = rk_s[k];
+                    if (rank == 0) continue;
+                    const uint32_t F = fr_s[k], Fc = fc_s[k];
+                    const uint32_t c0 = (acc > 0) ? fc_s[k + 1] : 0;
+                    for (uint32_t i = tid; i < rank; i += NT)
+                    {
+                        double s = W[F + i + n * ld];
+                        for (uint32_t j = 0; j < acc; j++) s = dfma(-W[F + i + (c0 + j) * ld], xs[c0 + j], s);
+                        xs[Fc + i] = s;
+                    }
+                    __syncthreads();
+                    for (uint32_t j = rank; j--;)
+                    {
+                        if (tid == 0) xs[Fc + j] = xs[Fc + j] / W[F + j + (Fc + j) * ld];
+                        __syncthreads();
+                        const double xj = xs[Fc + j];
+                        for (uint32_t i = tid; i < j; i += NT) xs[Fc + i] = dfma(-W[F + i + (Fc + j) * ld], xj, xs[Fc + i]);
+                        __syncthreads();
+                    }
+                    acc += rank;
+                }
+                if (tid == 0) // x = P x (lexlse.h:1044)
+                    for (uint32_t k = TotalRank; k--;)
+                    {
+                        const uint32_t pk = perm_s[k];
+                        const double t    = xs[k];
+                        xs[k]             = xs[pk];
+                        xs[pk]            = t;
+                    }
+                __syncthreads();
+                for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
+            }
+        }
+
+        // -----------------------------------------------------------------------------------------
+        // solve() alone, from the factor in HBM
+        // -----------------------------------------------------------------------------------------
+        template <int NT>
+        __global__ __launch_bounds__(NT) void solve_generic_kernel(LseArgs a)
+        {
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.x, tid = threadIdx.x;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const double *W  = a.fac + (size_t)b * cap * (n + 1);
+            const size_t ld  = cap;
+            double *xs       = smem;
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            const uint32_t *rk = a.rank + (size_t)b * nObj, *fc = a.fcol + (size_t)b * nObj;
+            const uint32_t *perm = a.perm + (size_t)b * n;
+            const uint32_t nf    = a.nfixed ? a.nfixed[b] : 0;
+            for (uint32_t i = tid; i < n; i += NT) xs[i] = (i < nf) ? a.fixed_val[(size_t)b * n + i] : 0.0;
+            __syncthreads();
+            uint32_t M = 0;
+            for (uint32_t k = 0; k < nObj; k++) M += dims[k];
+            uint32_t acc = 0, Fend = M;
+            for (uint32_t k = nObj; k--;)
+            {
+                const uint32_t F = Fend - dims[k];
+                Fend             = F;
+                const uint32_t rank = rk[k];
+                if (rank == 0) continue;
+                const uint32_t Fc = fc[k];
+                const uint32_t c0 = (acc > 0) ? fc[k + 1] : 0;
+                for (uint32_t i = tid; i < rank; i += NT)
+                {
+                    double s = W[F + i + n * ld];
+                    for (uint32_t j = 0; j < acc; j++) s = dfma(-W[F + i + (c0 + j) * ld], xs[c0 + j], s);
+                    xs[Fc + i] = s;
+                }
+                __syncthreads();
+                for (uint32_t j = rank; j--;)
+                {
+                    if (tid == 0) xs[Fc + j] = xs[Fc + j] / W[F + j + (Fc + j) * ld];
+                    __syncthreads();
+                    const double xj = xs[Fc + j];
+                    for (uint32_t i = tid; i < j; i += NT) xs[Fc + i] = dfma(-W[F + i + (Fc + j) * ld], xj, xs[Fc + i]);
+                    __syncthreads();
+                }
+                acc += rank;
+            }
+            if (tid == 0)
+                for (uint32_t k = a.totalrank[b]; k--;)
+                {
+                    const uint32_t pk = perm[k];
+                    const double t    = xs[k];
+                    xs[k]             = xs[pk];
+                    xs[pk]            = t;
+                }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
+        }
+
+        // -----------------------------------------------------------------------------------------
+        // get_v(): residuals through Q (lexlse.h:1560-1582)
+        // -----------------------------------------------------------------------------------------
+        template <int NT>
+        __global__ __launch_bounds__(NT) void residual_kernel(LseArgs a)
+        {
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.x, tid = threadIdx.x;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const double *W  = a.fac + (size_t)b * cap * (n + 1);
+            const double *hh = a.hh + (size_t)b * cap;
+            double *v        = smem;       // cap
+            double *bcast    = smem + cap; // 1
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            for (uint32_t i = tid; i < cap; i += NT) v[i] = 0.0;
+            __syncthreads();
+            uint32_t F = 0;
+            for (uint32_t k = 0; k < nObj; k++)
+            {
+                const uint32_t dim = dims[k], rank = a.rank[(size_t)b * nObj + k], Fc = a.fcol[(size_t)b * nObj + k];
+                for (uint32_t i = rank + tid; i < dim; i += NT) v[F + i] = -W[F + i + (size_t)n * cap];
+                __syncthreads();
+                apply_q_block<NT>(W, cap, hh, F, Fc, dim, rank, v + F, bcast, tid);
+                F += dim;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < cap; i += NT) a.v[(size_t)b * cap + i] = v[i];
+        }
+
+        // -----------------------------------------------------------------------------------------
+        // ObjectiveSensitivity (lexlse.h:611-762) + findDescentDirection (:935-987)
+        // -----------------------------------------------------------------------------------------
+        struct SensState
+        {
+            double maxabs;
+            uint32_t ctr;
+            int obj, found;
+        };
+
+        /// scan one group of multipliers; sequential semantics of the reference (strict '<' keeps the first)
+        __device__ void find_descent(uint8_t *types, const double *lambda, uint32_t count, double tolW, double tolC, int objTag, SensState *st)
+        {
+            for (uint32_t k = 0; k < count; k++)
+            {
+                const uint8_t t = types[k];
+                if (t == CTR_ACTIVE_EQ || t == CORRECT_SIGN_OF_LAMBDA) continue;
+                double al = lambda[k];
+                if (t == CTR_ACTIVE_LB) al = -al;
+                if (al > tolC)
+                {
+                    types[k] = CORRECT_SIGN_OF_LAMBDA;
+                }
+                else if (al < -tolW && al < st->maxabs)
+                {
+                    st->maxabs = al;
+                    st->ctr    = k;
+                    st->obj    = objTag;
+                    st->found  = 1;
+                }
+            }
+        }
+
+        template <int NT>
+        __global__ __launch_bounds__(NT) void sensitivity_kernel(LseArgs a, const int32_t *obj_index, int32_t obj_all, double tolW, double tolC)
+        {
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.x, tid = threadIdx.x;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const int32_t oi = obj_index ? obj_index[b] : obj_all;
+            int32_t *sens    = a.sens + (size_t)b * 3;
+            if (oi < 0 || (uint32_t)oi >= nObj)
+            {
+                if (tid == 0)
+                {
+                    sens[0]     = 0;
+                    sens[1]     = -1;
+                    sens[2]     = -2;
+                    a.maxabs[b] = 0.0;
+                }
+                return;
+            }
+            const uint32_t ObjIndex = (uint32_t)oi;
+            const double *W  = a.fac + (size_t)b * cap * (n + 1);
+            const size_t ld  = cap;
+            const double *hh = a.hh + (size_t)b * cap;
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            const uint32_t *rk = a.rank + (size_t)b * nObj, *fc = a.fcol + (size_t)b * nObj;
+            const uint32_t nf  = a.nfixed ? a.nfixed[b] : 0;
+            uint8_t *ctr_type  = a.ctr_type + (size_t)b * cap;
+
+            // LDS: [LambdaFixed nVar | Lambda cap | rhs nVar | bcast | state]
+            double *LambdaFixed = smem;
+            double *Lambda      = smem + n;
+            double *rhs         = Lambda + cap;
+            double *bcast       = rhs + n;
+            SensState *st       = reinterpret_cast<SensState *>(bcast + 1);
+
+            uint32_t nLambda = 0, Fobj = 0;
+            for (uint32_t k = 0; k <= ObjIndex; k++)
+            {
+                if (k == ObjIndex) Fobj = nLambda;
+                nLambda += dims[k];
+            }
+            for (uint32_t i = tid; i < n + cap + n; i += NT) smem[i] = 0.0;
+            if (tid == 0)
+            {
+                st->maxabs = 0.0;
+                st->ctr    = 0;
+                st->obj    = -2;
+                st->found  = 0;
+            }
+            __syncthreads();
+
+            uint32_t F = Fobj, Fc = fc[ObjIndex], dim = dims[ObjIndex], rank = rk[ObjIndex];
+            for (uint32_t i = rank + tid; i < dim; i += NT) Lambda[F + i] = -W[F + i + n * ld];
+            __syncthreads();
+            apply_q_block<NT>(W, ld, hh, F, Fc, dim, rank, Lambda + F, bcast, tid);
+            if (tid == 0) find_descent(ctr_type + F, Lambda + F, dim, tolW, tolC, (int)ObjIndex, st);
+
+            if (ObjIndex > 0)
+            {
+                for (uint32_t c = tid; c < Fc; c += NT) // rhs.head(ColDim) -= L^T lambda (lexlse.h:706-707)
+                {
+                    double s = 0.0;
+                    for (uint32_t i = 0; i < dim; i++) s = dfma(W[F + i + c * ld], Lambda[F + i], s);
+                    rhs[c] -= s;
+                }
+                __syncthreads();
+                for (uint32_t k = ObjIndex; k--;)
+                {
+                    dim  = dims[k];
+                    F    = F - dim;
+                    Fc   = fc[k];
+                    rank = rk[k];
+                    for (uint32_t i = tid; i < rank; i += NT) Lambda[F + i] = rhs[Fc + i];
+                    __syncthreads();
+                    apply_q_block<NT>(W, ld, hh, F, Fc, dim, rank, Lambda + F, bcast, tid);
+                    for (uint32_t c = tid; c < Fc; c += NT)
+                    {
+                        double s = 0.0;
+                        for (uint32_t i = 0; i < dim; i++) s = dfma(W[F + i + c * ld], Lambda[F + i], s);
+                        rhs[c] -= s;
+                    }
+                    if (tid == 0) find_descent(ctr_type + F, Lambda + F, dim, tolW, tolC, (int)k, st);
+                    __syncthreads();
+                }
+            }
+
+            if (nf > 0) // lexlse.h:742-758
+            {
+                __syncthreads();
+                for (uint32_t c = tid; c < nf; c += NT)
+                {
+                    double s = 0.0;
+                    for (uint32_t i = 0; i < nLambda; i++) s = dfma(W[i + c * ld], Lambda[i], s);
+                    LambdaFixed[c] = -s;
+                }
+                __syncthreads();
+                if (tid == 0) find_descent(a.fixed_type + (size_t)b * n, LambdaFixed, nf, tolW, tolC, -1, st);
+            }
+            __syncthreads();
+
+            double *out = a.lambda + (size_t)b * (n + cap);
+            for (uint32_t i = tid; i < n + cap; i += NT)
+            {
+                double val = 0.0;
+                if (i < nf)
+                    val = LambdaFixed[i];
+                else if (i < nf + nLambda)
+                    val = Lambda[i - nf];
+                out[i] = val;
+            }
+            if (tid == 0)
+            {
+                sens[0]     = st->found;
+                sens[1]     = st->found ? (int32_t)st->ctr : -1;
+                sens[2]     = st->found ? st->obj : -2;
+                a.maxabs[b] = st->maxabs;
+            }
+        }
+
+        // -----------------------------------------------------------------------------------------
+        // solveLeastNorm_1(): Givens sweep (lexlse.h:1052-1131).  Per problem `scratch` holds
+        // RT (nVar x nVar, ld = nVar) followed by the rotation table (c,s pairs, <= nVar^2/2 doubles).
+        // -----------------------------------------------------------------------------------------
+        __device__ __forceinline__ void make_givens(double p2, double q, double &c, double &s)
+        {
+            if (q == 0.0)
+            {
+                c = p2 < 0.0 ? -1.0 : 1.0;
+                s = 0.0;
+            }
+            else if (p2 == 0.0)
+            {
+                c = 0.0;
+                s = q < 0.0 ? 1.0 : -1.0;
+            }
+            else if (fabs(p2) > fabs(q))
+            {
+                const double t = q / p2;
+                double u       = sqrt(dfma(t, t, 1.0));
+                if (p2 < 0.0) u = -u;
+                c = 1.0 / u;
+                s = -t * c;
+            }
+            else
+            {
+                const double t = p2 / q;
+                double u       = sqrt(dfma(t, t, 1.0));
+                if (q < 0.0) u = -u;
+                s = -1.0 / u;
+                c = -t * s;
+            }
+        }
+
+        template <int NT>
+        __global__ __launch_bounds__(NT) void leastnorm_kernel(LseArgs a)
+        {
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.x, tid = threadIdx.x;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const double *W  = a.fac + (size_t)b * cap * (n + 1);
+            const size_t ld  = cap;
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            const uint32_t *rk = a.rank + (size_t)b * nObj, *fc = a.fcol + (size_t)b * nObj;
+            const uint32_t *perm = a.perm + (size_t)b * n;
+            const uint32_t nf    = a.nfixed ? a.nfixed[b] : 0;
+
+            uint32_t nVarRank = 0;
+            for (uint32_t k = 0; k < nObj; k++) nVarRank += rk[k];
+            const uint32_t nVarFree = n - (nVarRank + nf);
+            const uint32_t ncol     = nVarRank + nVarFree;
+            double *RT              = a.scratch + (size_t)b * 2 * n * n; // nVarRank x ncol, ld = n
+            double *rot             = RT + (size_t)n * n;               // (c, s) pairs in sweep order
+            const size_t lr         = n;
+            double *rhs             = smem;         // n
+            double *xs              = smem + n;     // n
+            double *cs              = smem + 2 * n; // 2
+
+            for (uint32_t e = tid; e < n * n; e += NT) RT[e] = 0.0;
+            for (uint32_t i = tid; i < n; i += NT)
+            {
+                rhs[i] = 0.0;
+                xs[i]  = (i < nf) ? a.fixed_val[(size_t)b * n + i] : 0.0;
+            }
+            __syncthreads();
+            {
+                uint32_t counter = 0, col_dim = ncol, F = 0;
+                for (uint32_t k = 0; k < nObj; k++) // compact [R T | rhs] copy (lexlse.h:1081-1094)
+                {
+                    const uint32_t rank = rk[k], Fc = fc[k];
+                    for (uint32_t e = tid; e < rank * col_dim; e += NT)
+                    {
+                        const uint32_t i = e % rank, j = e / rank;
+                        if (j >= i) RT[counter + i + (counter + j) * lr] = W[F + i + (Fc + j) * ld];
+                    }
+                    for (uint32_t i = tid; i < rank; i += NT) rhs[counter + i] = W[F + i + n * ld];
+                    counter += rank;
+                    col_dim -= rank;
+                    F += dims[k];
+                }
+            }
+            __syncthreads();
+
+            uint32_t nrot = 0;
+            for (uint32_t i = 0; i < nVarFree; i++) // zero T against R from the right (lexlse.h:1099-1110)
+            {
+                for (uint32_t j = nVarRank; j--;)
+                {
+                    if (tid == 0)
+                    {
+                        double c, s;
+                        make_givens(RT[j + j * lr], RT[j + (nVarRank + i) * lr], c, s);
+                        cs[0]             = c;
+                        cs[1]             = s;
+                        rot[2 * nrot]     = c;
+                        rot[2 * nrot + 1] = s;
+                    }
+                    __syncthreads();
+                    const double c = cs[0], s = cs[1];
+                    for (uint32_t r = tid; r <= j; r += NT) // applyOnTheRight on RT.topRows(j+1)
+                    {
+                        const double x1 = RT[r + j * lr], y1 = RT[r + (nVarRank + i) * lr];
+                        RT[r + j * lr]              = dfma(c, x1, -(s * y1));
+                        RT[r + (nVarRank + i) * lr] = dfma(c, y1, s * x1);
+                    }
+                    nrot++;
+                    __syncthreads();
+                }
+            }
+
+            for (uint32_t j = nVarRank; j--;) // R^-1 rhs, column-oriented (lexlse.h:1115)
+            {
+                if (tid == 0) rhs[j] = rhs[j] / RT[j + j * lr];
+                __syncthreads();
+                const double xj = rhs[j];
+                for (uint32_t i = tid; i < j; i += NT) rhs[i] = dfma(-RT[i + j * lr], xj, rhs[i]);
+                __syncthreads();
+            }
+
+            if (tid == 0)
+            {
+                for (uint32_t k = nrot; k--;) // replay on the RHS in reverse (lexlse.h:1121-1124)
+                {
+                    const uint32_t fi = k / nVarRank, jj = nVarRank - 1 - (k % nVarRank);
+                    const uint32_t gi = jj, gj = nVarRank + fi;
+                    const double c = rot[2 * k], s = rot[2 * k + 1];
+                    const double x1 = rhs[gi], y1 = rhs[gj];
+                    rhs[gi] = dfma(c, x1, s * y1);
+                    rhs[gj] = dfma(c, y1, -(s * x1));
+                }
+                for (uint32_t i = 0; i < ncol; i++) xs[nf + i] = rhs[i]; // lexlse.h:1129
+                for (uint32_t k = a.totalrank[b]; k--;)
+                {
+                    const uint32_t pk = perm[k];
+                    const double t    = xs[k];
+                    xs[k]             = xs[pk];
+                    xs[pk]            = t;
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
+        }
+    } // namespace
+
+    // ---------------------------------------------------------------------------------------------
+    // launchers
+    // ---------------------------------------------------------------------------------------------
+    namespace
+    {
+        template <typename K>
+        hipError_t set_lds(K kernel, size_t bytes)
+        {
+            if (bytes <= 64 * 1024) return hipSuccess;
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        }
+
+        size_t lqr_lds_bytes(const LseArgs &a, int NT, bool ldsmat)
+        {
+            size_t b = 8 * ((ldsmat ? (size_t)a.ldp * (a.nVar + 1) : 0) + 2 * (size_t)a.nVar + NT);
+            b += sizeof(Shared) + 4 * ((size_t)NT + a.nVar + 3 * (size_t)a.nObj) + 16;
+            return b;
+        }
+
+        template <int NT, bool LDSMAT>
+        hipError_t launch_lqr_t(const LseArgs &a, bool write_factor, bool do_solve, hipStream_t s)
+        {
+            const size_t lds = lqr_lds_bytes(a, NT, LDSMAT);
+            hipError_t e     = set_lds(lqr_generic_kernel<NT, LDSMAT>, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((lqr_generic_kernel<NT, LDSMAT>), dim3(a.batch), dim3(NT), lds, s, a, write_factor ? 1 : 0, do_solve ? 1 : 0);
+            return hipGetLastError();
+        }
+    } // namespace
+
+    hipError_t launch_lqr_generic(LseArgs a, uint32_t max_rows, bool write_factor, bool do_solve, hipStream_t s, const char **variant)
+    {
+        a.ldp             = odd_ld(max_rows);
+        const uint32_t w  = (a.nVar + 1 > max_rows) ? a.nVar + 1 : max_rows;
+        const bool fits64 = lqr_lds_bytes(a, 64, true) <= kMaxLdsBytes;
+        if (w <= 64 && fits64)
+        {
+            *variant = "lqr_generic<64,lds>";
+            return launch_lqr_t<64, true>(a, write_factor, do_solve, s);
+        }
+        if (w <= 512 && lqr_lds_bytes(a, 256, true) <= kMaxLdsBytes)
+        {
+            *variant = "lqr_generic<256,lds>";
+            return launch_lqr_t<256, true>(a, write_factor, do_solve, s);
+        }
+        if (lqr_lds_bytes(a, 1024, true) <= kMaxLdsBytes)
+        {
+            *variant = "lqr_generic<1024,lds>";
+            return launch_lqr_t<1024, true>(a, write_factor, do_solve, s);
+        }
+        if (lqr_lds_bytes(a, 1024, false) > kMaxLdsBytes) return hipErrorInvalidValue; // nVar too large for the norm table
+        *variant = "lqr_generic<1024,hbm>";
+        return launch_lqr_t<1024, false>(a, true, do_solve, s);
+    }
+
+    hipError_t launch_solve_generic(const LseArgs &a, hipStream_t s)
+    {
+        const size_t lds = 8 * (size_t)a.nVar + 16;
+        if (a.nVar + 1 <= 64)
+        {
+            hipError_t e = set_lds(solve_generic_kernel<64>, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((solve_generic_kernel<64>), dim3(a.batch), dim3(64), lds, s, a);
+        }
+        else
+        {
+            hipError_t e = set_lds(solve_generic_kernel<256>, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((solve_generic_kernel<256>), dim3(a.batch), dim3(256), lds, s, a);
+        }
+        return hipGetLastError();
+    }
+
+    hipError_t launch_residual(const LseArgs &a, hipStream_t s)
+    {
+        const size_t lds = 8 * ((size_t)a.cap + 2);
+        if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
+        hipError_t e = set_lds(residual_kernel<64>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((residual_kernel<64>), dim3(a.batch), dim3(64), lds, s, a);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_sensitivity(const LseArgs &a, const int32_t *d_obj_index, int32_t obj_all, double tolW, double tolC, hipStream_t s)
+    {
+        const size_t lds = 8 * (2 * (size_t)a.nVar + a.cap + 2) + sizeof(SensState) + 16;
+        if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
+        hipError_t e = set_lds(sensitivity_kernel<64>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((sensitivity_kernel<64>), dim3(a.batch), dim3(64), lds, s, a, d_obj_index, obj_all, tolW, tolC);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_leastnorm(const LseArgs &a, hipStream_t s)
+    {
+        const size_t lds = 8 * (2 * (size_t)a.nVar + 4);
+        if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
+        hipError_t e = set_lds(leastnorm_kernel<64>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((leastnorm_kernel<64>), dim3(a.batch), dim3(64), lds, s, a);
+        return hipGetLastError();
+    }
+} // namespace lexls

@@ -1,0 +1,172 @@
+"""Host-side mirror of the reference's equality solver for a BATCH of problems, over the C ABI.
+
+``BatchedLexLSE`` keeps the reference's method names and call order
+(LexLS::internal::LexLSE, include/lexls/lexlse.h: resize :67, setObjDim :1426, setParameters :1467,
+fixVariables :1398, setCtrType :1548, setProblem :1511, factorize :117, solve :1015,
+solveLeastNorm_1 :1052, ObjectiveSensitivity :611, get_v :1560, get_x :1587, get_lexqr :1626,
+getRank :1603, getTotalRank :1503) — one object is `batch` independent problems of one capacity.
+
+Array conventions: a problem is the reference's column-major ``cap x (nVar+1)`` LOD, passed as a
+C-ordered numpy array of shape ``(batch, nVar+1, cap)``.  Every compute call goes to the HIP
+library; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def _ptr(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+class BatchedLexLSE:
+    def __init__(self, batch: int, nVar: int, maxObjDim, device: int = 0):
+        self._h = C.c_void_p()
+        self.batch, self.nVar = int(batch), int(nVar)
+        self.maxObjDim = np.ascontiguousarray(maxObjDim, dtype=np.uint32)
+        self.nObj = int(self.maxObjDim.size)
+        self.cap = int(self.maxObjDim.sum())
+        capi.check(capi.lib().lexls_lse_create(C.byref(self._h), C.c_int(device), C.c_uint32(self.batch), C.c_uint32(self.nVar),
+                                               C.c_uint32(self.nObj), _ptr(self.maxObjDim, C.c_uint32)))
+
+    # ---- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            capi.lib().lexls_lse_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: int):
+        capi.check(capi.lib().lexls_lse_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        capi.check(capi.lib().lexls_lse_synchronize(self._h))
+
+    # ---- problem definition ---------------------------------------------------------------------
+    def setParameters(self, tol_linear_dependence: float = 1e-12):
+        capi.check(capi.lib().lexls_lse_set_tolerance(self._h, C.c_double(tol_linear_dependence)))
+
+    def setObjDim(self, dims):
+        dims = np.ascontiguousarray(dims, dtype=np.uint32)
+        per = 1 if dims.ndim == 2 else 0
+        if per and dims.shape != (self.batch, self.nObj):
+            raise ValueError("dims must be (nObj,) or (batch, nObj)")
+        capi.check(capi.lib().lexls_lse_set_obj_dim(self._h, _ptr(dims, C.c_uint32), C.c_int(per)))
+
+    def fixVariables(self, nfixed, index, value, ctr_type=None):
+        if nfixed is None:
+            capi.check(capi.lib().lexls_lse_set_fixed(self._h, None, None, None, None))
+            return
+        nfixed = np.ascontiguousarray(nfixed, np.uint32)
+        index = np.ascontiguousarray(index, np.uint32)
+        value = np.ascontiguousarray(value, np.float64)
+        assert index.shape == (self.batch, self.nVar) and value.shape == (self.batch, self.nVar)
+        ctr_type = None if ctr_type is None else np.ascontiguousarray(ctr_type, np.uint8)
+        capi.check(capi.lib().lexls_lse_set_fixed(self._h, _ptr(nfixed, C.c_uint32), _ptr(index, C.c_uint32), _ptr(value, C.c_double),
+                                                  _ptr(ctr_type, C.c_uint8)))
+
+    def setCtrType(self, types):
+        types = np.ascontiguousarray(types, np.uint8)
+        assert types.shape == (self.batch, self.cap)
+        capi.check(capi.lib().lexls_lse_set_ctr_type(self._h, _ptr(types, C.c_uint8)))
+
+    def setProblem(self, lod):
+        """lod: host array (batch, nVar+1, cap); copied to the device."""
+        lod = np.ascontiguousarray(lod, np.float64)
+        if lod.shape != (self.batch, self.nVar + 1, self.cap):
+            raise ValueError(f"lod must have shape {(self.batch, self.nVar + 1, self.cap)}, got {lod.shape}")
+        capi.check(capi.lib().lexls_lse_set_problem_host(self._h, _ptr(lod, C.c_double)))
+
+    def setProblemDevice(self, device_ptr: int):
+        """Bind a device buffer (e.g. torch_tensor.data_ptr()) holding batch x cap x (nVar+1) doubles as the input."""
+        capi.check(capi.lib().lexls_lse_set_problem_device(self._h, C.c_void_p(device_ptr)))
+
+    # ---- hot path -------------------------------------------------------------------------------
+    def factorize(self):
+        capi.check(capi.lib().lexls_lse_factorize(self._h))
+
+    def solve(self):
+        capi.check(capi.lib().lexls_lse_solve(self._h))
+
+    def factorize_solve(self, keep_factor: bool = True):
+        capi.check(capi.lib().lexls_lse_factorize_solve(self._h, C.c_int(1 if keep_factor else 0)))
+
+    def solveLeastNorm_1(self):
+        capi.check(capi.lib().lexls_lse_solve_least_norm(self._h))
+
+    def ObjectiveSensitivity(self, ObjIndex, tol_wrong_sign_lambda=1e-8, tol_correct_sign_lambda=1e-12):
+        """ObjIndex: int (all problems) or per-problem int32 array (negative = skip). Returns (found, ctr, obj, maxAbs)."""
+        if np.isscalar(ObjIndex):
+            capi.check(capi.lib().lexls_lse_sensitivity(self._h, None, C.c_int32(int(ObjIndex)), C.c_double(tol_wrong_sign_lambda),
+                                                        C.c_double(tol_correct_sign_lambda)))
+        else:
+            oi = np.ascontiguousarray(ObjIndex, np.int32)
+            assert oi.shape == (self.batch,)
+            capi.check(capi.lib().lexls_lse_sensitivity(self._h, _ptr(oi, C.c_int32), C.c_int32(0), C.c_double(tol_wrong_sign_lambda),
+                                                        C.c_double(tol_correct_sign_lambda)))
+        sens = np.zeros((self.batch, 3), np.int32)
+        maxabs = np.zeros(self.batch)
+        capi.check(capi.lib().lexls_lse_get_sensitivity(self._h, _ptr(sens, C.c_int32), _ptr(maxabs, C.c_double)))
+        return sens[:, 0].astype(bool), sens[:, 1], sens[:, 2], maxabs
+
+    # ---- results --------------------------------------------------------------------------------
+    def get_x(self):
+        x = np.zeros((self.batch, self.nVar))
+        capi.check(capi.lib().lexls_lse_get_x(self._h, _ptr(x, C.c_double)))
+        return x
+
+    def get_lexqr(self):
+        f = np.zeros((self.batch, self.nVar + 1, self.cap))
+        capi.check(capi.lib().lexls_lse_get_factor(self._h, _ptr(f, C.c_double)))
+        return f
+
+    def get_hh_scalars(self):
+        h = np.zeros((self.batch, self.cap))
+        capi.check(capi.lib().lexls_lse_get_hh_scalars(self._h, _ptr(h, C.c_double)))
+        return h
+
+    def get_column_permutations(self):
+        p = np.zeros((self.batch, self.nVar), np.uint32)
+        capi.check(capi.lib().lexls_lse_get_permutation(self._h, _ptr(p, C.c_uint32)))
+        return p
+
+    def getRanks(self):
+        r = np.zeros((self.batch, self.nObj), np.uint32)
+        fc = np.zeros((self.batch, self.nObj), np.uint32)
+        tr = np.zeros(self.batch, np.uint32)
+        capi.check(capi.lib().lexls_lse_get_ranks(self._h, _ptr(r, C.c_uint32), _ptr(fc, C.c_uint32), _ptr(tr, C.c_uint32)))
+        return r, fc, tr
+
+    def get_v(self):
+        capi.check(capi.lib().lexls_lse_residual(self._h))
+        v = np.zeros((self.batch, self.cap))
+        capi.check(capi.lib().lexls_lse_get_v(self._h, _ptr(v, C.c_double)))
+        return v
+
+    def getWorkspace(self):
+        """[lambda_fixed; lambda] of the last ObjectiveSensitivity call, shape (batch, nVar+cap)."""
+        lam = np.zeros((self.batch, self.nVar + self.cap))
+        capi.check(capi.lib().lexls_lse_get_lambda(self._h, _ptr(lam, C.c_double)))
+        return lam
+
+    def getCtrType(self):
+        t = np.zeros((self.batch, self.cap), np.uint8)
+        capi.check(capi.lib().lexls_lse_get_ctr_type(self._h, _ptr(t, C.c_uint8)))
+        return t
+
+    def device_ptr(self, name: str) -> int:
+        p = C.c_void_p()
+        capi.check(capi.lib().lexls_lse_device_ptr(self._h, C.c_int(capi.ARRAY[name]), C.byref(p)))
+        return int(p.value)
+
+    def last_kernel(self) -> str:
+        return capi.lib().lexls_lse_last_kernel(self._h).decode()

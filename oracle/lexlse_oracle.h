@@ -20,6 +20,7 @@
 // ARITHMETIC CONTRACT (what the HIP kernels reproduce bit-for-bit; compile with -ffp-contract=off):
 //   dot / squaredNorm : s = 0; s = fma(a_i, b_i, s) for i ascending
 //   "c -= a*b"        : c = fma(-a, b, c), inner index ascending, accumulating INTO c
+//   triangular solve  : column-oriented, x_j /= R_jj then x_i = fma(-R_ij, x_j, x_i) for i < j, j descending
 //   division, sqrt    : IEEE correctly rounded
 //   argmax            : first occurrence of the maximum (Eigen maxCoeff, eigen_like_syntax/maxCoeff.m:11)
 #pragma once
@@ -415,11 +416,10 @@ namespace lexls_oracle
                 }
             }
 
-            for (Index i = nVarRank; i--;) // :1115 R^-1 rhs
+            for (Index j = nVarRank; j--;) // :1115 R^-1 rhs, column-oriented like back_substitute()
             {
-                double s = rhs[i];
-                for (Index j = i + 1; j < nVarRank; j++) s = std::fma(-RT(i, j), rhs[j], s);
-                rhs[i] = s / RT(i, i);
+                rhs[j] = rhs[j] / RT(j, j);
+                for (Index i = 0; i < j; i++) rhs[i] = std::fma(-RT(i, j), rhs[j], rhs[i]);
             }
 
             for (size_t k = gs.size(); k--;) // :1121-1124 applyOnTheLeft in reverse
@@ -569,11 +569,12 @@ namespace lexls_oracle
         /// x[0..rank) <- R^-1 x, R = LOD(F.., Fc..) upper triangular
         void back_substitute(Index F, Index Fc, Index rank, double *xk) const
         {
-            for (Index i = rank; i--;)
+            // column-oriented (as Eigen's column-major triangular solver): x_j is final once every
+            // column to its right has been eliminated; contributions reach x_i in order j = rank-1 .. i+1
+            for (Index j = rank; j--;)
             {
-                double s = xk[i];
-                for (Index j = i + 1; j < rank; j++) s = std::fma(-LOD(F + i, Fc + j), xk[j], s);
-                xk[i] = s / LOD(F + i, Fc + i);
+                xk[j] = xk[j] / LOD(F + j, Fc + j);
+                for (Index i = 0; i < j; i++) xk[i] = std::fma(-LOD(F + i, Fc + j), xk[j], xk[i]);
             }
         }
 

@@ -1,0 +1,235 @@
+"""HIP path vs the CPU oracle on identical inputs, through the C ABI (bit-exact: the kernels follow the
+oracle's arithmetic contract, oracle/lexlse_oracle.h).  Tolerance north_star asks for: pivots/ranks
+exact, x within 1e-10; what is asserted here is stronger (bitwise equality) wherever noted."""
+import numpy as np
+import pytest
+
+from lexls_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(hip, oracle, lod, dims, nvar, maxdim=None, keep_factor=True, **fixed):
+    batch = lod.shape[0]
+    dims_a = np.asarray(dims, np.uint32)
+    if maxdim is None:
+        maxdim = dims_a if dims_a.ndim == 1 else dims_a.max(axis=0)
+        maxdim = np.array(maxdim, np.uint32)
+        maxdim[-1] += lod.shape[2] - int(maxdim.sum())
+    ref = oracle.lse_run(lod, dims, nvar, maxdim=maxdim, **fixed)
+    s = hip.BatchedLexLSE(batch, nvar, maxdim)
+    s.setObjDim(dims_a)
+    if "nfixed" in fixed:
+        s.fixVariables(fixed["nfixed"], fixed["fixed_idx"], fixed["fixed_val"], fixed.get("fixed_type"))
+    s.setProblem(lod)
+    s.factorize_solve(keep_factor=keep_factor)
+    return s, ref
+
+
+def assert_factor_equal(s, ref, dims, nvar):
+    r, fc, tr = s.getRanks()
+    np.testing.assert_array_equal(r, ref["rank"])
+    np.testing.assert_array_equal(fc, ref["fcol"])
+    np.testing.assert_array_equal(tr, ref["totalrank"])
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    np.testing.assert_array_equal(s.get_hh_scalars(), ref["hh"])
+    f = s.get_lexqr()
+    dims_a = np.asarray(dims)
+    m = dims_a.sum(axis=-1) if dims_a.ndim == 2 else np.full(f.shape[0], dims_a.sum())
+    for b in range(f.shape[0]):
+        np.testing.assert_array_equal(f[b, :, :m[b]], ref["factor"][b, :, :m[b]])
+
+
+def test_ik_batch_bit_exact(hip, oracle):
+    dims, n = [12] * 5, 40
+    lod = P.lse_batch(20260100, 64, n, dims)
+    s, ref = run_both(hip, oracle, lod, dims, n)
+    assert (ref["rank"] == [12, 12, 12, 4, 0]).all()
+    assert_factor_equal(s, ref, dims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    assert "lds" in s.last_kernel()
+
+
+def test_x_only_variant_matches(hip, oracle):
+    dims, n = [12] * 5, 40
+    lod = P.lse_batch(7, 32, n, dims)
+    s, ref = run_both(hip, oracle, lod, dims, n, keep_factor=False)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
+    with pytest.raises(Exception):
+        s.get_lexqr()  # factor was not kept: the library must refuse, not return stale data
+
+
+def test_factorize_then_solve_separately(hip, oracle):
+    dims, n = [6] * 5, 40
+    lod = P.lse_batch(11, 16, n, dims)
+    ref = oracle.lse_run(lod, dims, n)
+    s = hip.BatchedLexLSE(16, n, dims)
+    s.setProblem(lod)
+    s.factorize()
+    s.solve()
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    assert (ref["rank"] == 6).all()
+
+
+def test_rank_deficient_levels(hip, oracle):
+    n, dims, ranks = 15, [5, 5, 5, 5], [3, 3, 3, 3]
+    lod = np.stack([P.rank_deficient_problem(100 + b, n, dims, ranks) for b in range(24)])
+    s, ref = run_both(hip, oracle, lod, dims, n)
+    assert (ref["rank"] == ranks).all()
+    assert_factor_equal(s, ref, dims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+
+
+def test_ragged_batch(hip, oracle):
+    n, cap_dims = 20, [8, 8, 8]
+    rng_dims = np.array([[8, 8, 8], [3, 0, 5], [1, 8, 2], [0, 0, 4], [8, 1, 0], [5, 5, 5], [2, 2, 2], [7, 3, 8]], np.uint32)
+    full = np.zeros((8, n + 1, 24))
+    for b in range(8):
+        m = int(rng_dims[b].sum())
+        full[b, :, :m] = P.lse_problem(900 + b, n, rng_dims[b])
+    s, ref = run_both(hip, oracle, full, rng_dims, n, maxdim=np.array(cap_dims, np.uint32))
+    assert_factor_equal(s, ref, rng_dims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+
+
+
+
+def test_fixed_variables(hip, oracle):
+    n, dims, batch = 12, [4, 4, 6], 10
+    lod = P.lse_batch(31, batch, n, dims)
+    nfixed = np.array([0, 1, 2, 3, 4, 5, 12, 2, 1, 3], np.uint32)
+    idx = np.zeros((batch, n), np.uint32)
+    val = np.zeros((batch, n))
+    typ = np.full((batch, n), 2, np.uint8)
+    for b in range(batch):
+        perm = np.argsort(P.uniform(500 + b, n))
+        idx[b, :nfixed[b]] = perm[:nfixed[b]]
+        val[b, :nfixed[b]] = P.normal(600 + b, n)[:nfixed[b]]
+    s, ref = run_both(hip, oracle, lod, dims, n, nfixed=nfixed, fixed_idx=idx, fixed_val=val, fixed_type=typ)
+    assert_factor_equal(s, ref, dims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+
+
+def test_medium_problem_256_thread_variant(hip, oracle):
+    n, dims = 100, [30, 30, 30, 30]
+    lod = P.lse_batch(41, 3, n, dims)
+    s, ref = run_both(hip, oracle, lod, dims, n)
+    assert_factor_equal(s, ref, dims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    assert s.last_kernel() == "lqr_generic<256,lds>"
+
+
+def test_hbm_resident_variant(hip, oracle):
+    n, dims = 200, [100, 100, 100, 100]
+    lod = P.lse_batch(43, 2, n, dims)
+    s, ref = run_both(hip, oracle, lod, dims, n)
+    assert s.last_kernel() == "lqr_generic<1024,hbm>"
+    assert_factor_equal(s, ref, dims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+
+
+def test_config2_single_large(hip, oracle):
+    """BASELINE.json configs[1]: n=512, 4 levels x 256 rows."""
+    n, dims = 512, [256] * 4
+    lod = P.lse_batch(20260001, 1, n, dims)
+    s, ref = run_both(hip, oracle, lod, dims, n)
+    assert (ref["rank"] == [256, 256, 0, 0]).all()
+    np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+
+
+def test_residuals(hip, oracle):
+    n, dims = 15, [5, 5, 5, 5]
+    lod = np.stack([P.rank_deficient_problem(200 + b, n, dims, [3, 3, 3, 3]) for b in range(8)])
+    s, ref = run_both(hip, oracle, lod, dims, n)
+    np.testing.assert_array_equal(s.get_v(), ref["v"])
+    # and they are the true residuals A x - b
+    x = s.get_x()
+    for b in range(8):
+        A = lod[b, :-1, :].T
+        np.testing.assert_allclose(A @ x[b] - lod[b, -1, :], ref["v"][b], atol=1e-10)
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
+def test_objective_sensitivity(hip, oracle, level):
+    n, dims, batch = 15, [5, 5, 5, 5], 12
+    lod = np.stack([P.rank_deficient_problem(300 + b, n, dims, [3, 4, 3, 2]) for b in range(batch)])
+    types = np.zeros((batch, 20), np.uint8)
+    for b in range(batch):
+        types[b] = 1 + (P.uniform(700 + b, 20) * 3).astype(np.uint8)  # LB / UB / EQ
+    ref = oracle.lse_run(lod, dims, n, ctr_type=types, sens_obj=level)
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.setProblem(lod)
+    s.setCtrType(types)
+    s.factorize_solve()
+    found, ctr, obj, maxabs = s.ObjectiveSensitivity(level)
+    np.testing.assert_array_equal(found.astype(np.int32), ref["sens"][:, 0])
+    np.testing.assert_array_equal(ctr, ref["sens"][:, 1])
+    np.testing.assert_array_equal(obj, ref["sens"][:, 2])
+    np.testing.assert_array_equal(maxabs, ref["maxabs"])
+    np.testing.assert_array_equal(s.getWorkspace(), ref["lam"])
+    np.testing.assert_array_equal(s.getCtrType(), ref["ctr_type_out"])
+
+
+def test_sensitivity_with_fixed_variables(hip, oracle):
+    n, dims, batch = 12, [4, 4, 6], 6
+    lod = P.lse_batch(51, batch, n, dims)
+    nfixed = np.array([1, 2, 3, 0, 4, 2], np.uint32)
+    idx = np.zeros((batch, n), np.uint32)
+    val = np.zeros((batch, n))
+    typ = np.zeros((batch, n), np.uint8)
+    for b in range(batch):
+        perm = np.argsort(P.uniform(800 + b, n))
+        idx[b, :nfixed[b]] = perm[:nfixed[b]]
+        val[b, :nfixed[b]] = P.normal(810 + b, n)[:nfixed[b]]
+        typ[b, :nfixed[b]] = 1 + (P.uniform(820 + b, n)[:nfixed[b]] * 2).astype(np.uint8)
+    types = np.full((batch, 14), 2, np.uint8)
+    ref = oracle.lse_run(lod, dims, n, nfixed=nfixed, fixed_idx=idx, fixed_val=val, fixed_type=typ, ctr_type=types, sens_obj=2)
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.fixVariables(nfixed, idx, val, typ)
+    s.setProblem(lod)
+    s.setCtrType(types)
+    s.factorize_solve()
+    found, ctr, obj, maxabs = s.ObjectiveSensitivity(2)
+    np.testing.assert_array_equal(np.stack([found.astype(np.int32), ctr, obj], 1), ref["sens"])
+    np.testing.assert_array_equal(s.getWorkspace(), ref["lam"])
+
+
+def test_least_norm_givens(hip, oracle):
+    n, dims, batch = 40, [6] * 5, 8
+    lod = P.lse_batch(61, batch, n, dims)
+    ref = oracle.lse_run(lod, dims, n, solve_option=1)
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.setProblem(lod)
+    s.factorize()
+    s.solveLeastNorm_1()
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    # least-norm property: x is orthogonal to the null space of the stacked constraints
+    for b in range(batch):
+        A = lod[b, :-1, :].T
+        _, _, Vt = np.linalg.svd(A)
+        assert np.abs(Vt[30:] @ s.get_x()[b]).max() < 1e-10
+
+
+def test_full_size_batch_4096(hip, oracle):
+    """BASELINE.json configs[2]: batch 4096 x (n=40, 5x12) against the oracle on all problems."""
+    n, dims, batch = 40, [12] * 5, 4096
+    lod = P.lse_batch_fast(20260100, batch, n, dims)
+    ref = oracle.lse_run(lod, dims, n, nthreads=8)
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.setProblem(lod)
+    s.factorize_solve(keep_factor=False)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+
+
+def test_error_behaviour(hip):
+    s = hip.BatchedLexLSE(2, 4, [2, 2])
+    with pytest.raises(Exception):
+        s.factorize()  # no problem data
+    with pytest.raises(Exception):
+        s.setObjDim([3, 2])  # exceeds capacity
+    with pytest.raises(Exception):
+        s.solve()  # no factorization

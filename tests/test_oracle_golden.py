@@ -1,0 +1,158 @@
+"""The CPU oracle against everything that pins it:
+  * the reference's own fixture tests/test_01.dat `#Solution` (copied to tests/golden/test_01.dat),
+  * known-answer tests restated from the reference's MATLAB suites,
+  * an independent numpy solver that does not use the l-QR algorithm,
+  * committed golden vectors (tests/golden/lse_golden.npz, made by tests/golden/make_golden.py).
+No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+from lexls_amd import problems as P
+from oracle import oracle_np
+
+from conftest import GOLDEN
+
+DAT = os.path.join(GOLDEN, "test_01.dat")
+
+
+@pytest.mark.parametrize("use_as,use_x", [(0, 0), (1, 0), (1, 1), (0, 1)])
+def test_reference_fixture_test_01_solution(oracle, use_as, use_x):
+    """reference tests/test_01.dat:328-416 stores x* with 15 significant digits; every warm-start mode must reach it."""
+    d = oracle.lsi_run_dat(DAT, one_based=True, use_active_guess=bool(use_as), use_x_guess=bool(use_x))
+    assert d["header"].tolist() == [88, 5, 210, 1]
+    assert d["info"]["status"] == 0  # PROBLEM_SOLVED
+    assert np.abs(d["x"] - d["solution"]).max() < 1e-9
+    if use_as:  # the stored active set is optimal: one factorization, nothing added or removed
+        assert d["info"]["factorizations"] == 1 and d["info"]["activations"] == 0 and d["info"]["deactivations"] == 0
+
+
+def test_lambda_closed_form(oracle):
+    """interfaces/matlab-octave/tests/lexlsi/lambda_test.m:8-47: (x_1=1) > (2x_2=1) > ... > (n x_n=1) > (sum x = 1)."""
+    n = 5
+    w = sum(1.0 / k for k in range(2, n + 1))
+    objs = []
+    for k in range(1, n + 1):
+        A = np.zeros((1, n))
+        A[0, k - 1] = k
+        objs.append(dict(A=A, lb=[1.0], ub=[1.0]))
+    objs.append(dict(A=np.ones((1, n)), lb=[1.0], ub=[1.0]))
+    x, lam = oracle.lsi_lambda(n, objs)
+    expect = np.zeros((n + 1, n + 1))
+    expect[n, n] = w
+    for k in range(1, n + 1):
+        expect[k - 1, n] = -w / k
+    np.testing.assert_allclose(x, [1.0 / k for k in range(1, n + 1)], atol=1e-14)
+    np.testing.assert_allclose(lam, expect, atol=1e-13)
+
+
+def test_pinv_identity(oracle):
+    """examples/example_lexlse.m:17-29: with a terminal level x = 0, x equals pinv(A1) b1."""
+    n, m = 10, 6
+    A1 = P.normal(1, m * n).reshape(m, n)
+    b1 = P.normal(2, m)
+    lod = np.zeros((1, n + 1, m + n))
+    lod[0, :n, :m] = A1.T
+    lod[0, n, :m] = b1
+    lod[0, :n, m:] = np.eye(n)
+    r = oracle.lse_run(lod, [m, n], n)
+    np.testing.assert_allclose(r["x"][0], np.linalg.pinv(A1) @ b1, atol=1e-12)
+    assert r["rank"][0].tolist() == [m, n - m]
+
+
+def test_least_norm_equals_terminal_identity_level(oracle):
+    """append_terminal_objective.m / test_lexlse_main.m:16-20 (tol 1e-10): Givens least-norm == extra level I x = 0."""
+    n, dims = 30, [9, 8, 10]
+    lod = np.stack([P.rank_deficient_problem(40 + b, n, dims, [7, 6, 8]) for b in range(4)])
+    ln = oracle.lse_run(lod, dims, n, solve_option=1)
+    ext = np.zeros((4, n + 1, sum(dims) + n))
+    ext[:, :, :sum(dims)] = lod
+    ext[:, :n, sum(dims):] = np.eye(n)
+    basic = oracle.lse_run(ext, dims + [n], n)
+    np.testing.assert_allclose(ln["x"], basic["x"], atol=1e-10)
+
+
+def test_fixed_variables_equal_unit_row_equalities(oracle):
+    """fixed2general.m: fixing variables == a first level of unit rows (tol 1e-10, test_lexlse_main.m:20)."""
+    n, dims, batch = 12, [4, 5], 5
+    lod = P.lse_batch(77, batch, n, dims)
+    nfixed = np.full(batch, 3, np.uint32)
+    idx = np.zeros((batch, n), np.uint32)
+    val = np.zeros((batch, n))
+    gen = np.zeros((batch, n + 1, 3 + sum(dims)))
+    for b in range(batch):
+        perm = np.argsort(P.uniform(90 + b, n))[:3]
+        idx[b, :3] = perm
+        val[b, :3] = P.normal(95 + b, 3)
+        for k in range(3):
+            gen[b, perm[k], k] = 1.0
+            gen[b, n, k] = val[b, k]
+        gen[b, :, 3:] = lod[b]
+    fx = oracle.lse_run(lod, dims, n, nfixed=nfixed, fixed_idx=idx, fixed_val=val)
+    ge = oracle.lse_run(gen, [3] + dims, n)
+    np.testing.assert_allclose(fx["x"], ge["x"], atol=1e-10)
+    np.testing.assert_allclose(fx["v"][:, :sum(dims)], ge["v"][:, 3:], atol=1e-10)
+
+
+@pytest.mark.parametrize("n,dims,ranks", [(15, [5, 5, 5, 5], [3, 3, 3, 3]), (40, [12] * 5, None), (30, [9, 8, 10, 6], [7, 6, 8, 5]), (8, [3, 3, 3, 3], None)])
+def test_against_independent_numpy_solver(oracle, n, dims, ranks):
+    """per-level optimal residual norms are unique: compare with sequential null-space projection (oracle_np)."""
+    for seed in range(6):
+        lod = (P.rank_deficient_problem(seed, n, dims, ranks) if ranks else P.lse_problem(seed, n, dims))[None]
+        r = oracle.lse_run(lod, dims, n)
+        levels = P.levels_of(lod[0], dims)
+        xn, resn, rk = oracle_np.lex_solve(levels)
+        res = oracle_np.residual_norms(levels, r["x"][0])
+        np.testing.assert_allclose(res, resn, atol=1e-9)
+        assert r["rank"][0].tolist() == rk
+        # get_v reproduces the residuals A x - b
+        A = lod[0, :-1, :].T
+        np.testing.assert_allclose(r["v"][0], A @ r["x"][0] - lod[0, -1, :], atol=1e-9)
+        if sum(rk) == n:
+            np.testing.assert_allclose(r["x"][0], xn, atol=1e-9)
+
+
+def test_factor_structure(oracle):
+    """R_k upper triangular with |diag| decreasing-ish pivots, Q_k orthogonal: Q^T [A P] = [R T] on level 1."""
+    n, dims = 10, [6, 6]
+    lod = P.lse_problem(5, n, dims)[None]
+    r = oracle.lse_run(lod, dims, n)
+    F = r["factor"][0].T  # (M, n+1)
+    perm = r["perm"][0]
+    A = lod[0].T.copy()
+    # replay the column swaps on the data of level 1
+    for k in range(int(r["totalrank"][0])):
+        A[:, [k, perm[k]]] = A[:, [perm[k], k]]
+    # rebuild Q_1 from the stored essentials / scalars
+    m = dims[0]
+    Q = np.eye(m)
+    for j in range(int(r["rank"][0][0])):
+        v = np.zeros(m)
+        v[j] = 1.0
+        v[j + 1:] = F[j + 1:m, j]
+        Q = Q @ (np.eye(m) - r["hh"][0][j] * np.outer(v, v))
+    RT = Q.T @ A[:m, :]
+    R = np.triu(F[:m, :n][:, :m])
+    np.testing.assert_allclose(np.triu(RT[:, :m]), R, atol=1e-12)
+    np.testing.assert_allclose(np.tril(RT[:, :m], -1), 0, atol=1e-12)
+    np.testing.assert_allclose(RT[:, m:], F[:m, m:], atol=1e-12)
+
+
+def test_golden_vectors_regression(oracle):
+    """committed vectors (made by tests/golden/make_golden.py from this oracle) must be reproduced bit for bit."""
+    g = np.load(os.path.join(GOLDEN, "lse_golden.npz"))
+    for name in ("ik", "rankdef"):
+        lod, dims, n = g[f"{name}_lod"], g[f"{name}_dims"].tolist(), int(g[f"{name}_nvar"])
+        r = oracle.lse_run(lod, dims, n, sens_obj=len(dims) - 1, ctr_type=g[f"{name}_types"])
+        for key in ("x", "factor", "hh", "perm", "rank", "v", "lam", "sens"):
+            np.testing.assert_array_equal(r[key], g[f"{name}_{key}"], err_msg=f"{name}:{key}")
+
+
+def test_flop_and_byte_model():
+    """SURVEY.md section 8(d) totals."""
+    assert P.flop_model(40, [12] * 5)["total"] == 97402
+    assert abs(P.flop_model(512, [256] * 4)["total"] - 2.653e8) < 1e5
+    assert P.algorithmic_bytes(40, [12] * 5) == 20000
+    assert P.algorithmic_bytes(512, [256] * 4) == 4206592
+    assert P.algorithmic_bytes(40, [12] * 5, write_factor=True) == 40360
