@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched fp64 l-QR factorizations/s (one factorization = factorize()+solve() of one problem).
+
+Workload (BASELINE.json configs[2] per GPU, configs[3] at 8 GPUs): 4096 IK-sized problems per GPU
+(n=40 variables, 5 levels x 12 rows, iid N(0,1), seed 20260100 + global problem id), resident in HBM
+before the timed region.  One "step" = one pass of the hot path (lexls_lse_factorize_solve, x-only
+traffic variant) over the rank's batch.  Multi-GPU: problems are independent, so the batch is sharded
+by contiguous index blocks, one process per GPU, no data-path collective (weak scaling); the process
+group (RCCL) is used for the barriers around the timed region, the max-over-ranks of the elapsed time
+and a final all-gather of per-shard solution checksums.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NVAR, DIMS, PER_GPU_BATCH, SEED0 = 40, [12] * 5, 4096, 20260100
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="problems per GPU")
+    ap.add_argument("--keep-factor", action="store_true", help="also write the factor to HBM (40,360 B/problem variant)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import lexls_amd
+    from lexls_amd import problems as P
+
+    batch = args.batch
+    # this rank's shard of the global batch (contiguous block of problem ids) -> HBM
+    first_id = rank * batch
+    lod_host = P.lse_batch(SEED0 + first_id, batch, NVAR, DIMS)  # problem id -> seed 20260100 + id
+    lod_dev = torch.from_numpy(lod_host).cuda()
+
+    stream = torch.cuda.Stream()
+    solver = lexls_amd.BatchedLexLSE(batch, NVAR, DIMS, device=local_rank)
+    solver.set_stream(stream.cuda_stream)
+    solver.setProblemDevice(lod_dev.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            solver.factorize_solve(keep_factor=args.keep_factor)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            solver.factorize_solve(keep_factor=args.keep_factor)
+        ev1.record(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream: average launch duration
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness guard outside the timed region: solution checksum per shard, gathered on every rank
+    x = solver.get_x()
+    ranks_ok = bool((solver.getRanks()[0] == np.array([12, 12, 12, 4, 0])).all())
+    checksum = torch.tensor([float(np.abs(x).sum()), float(ranks_ok)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        gathered = [torch.zeros_like(checksum) for _ in range(world)]
+        dist.all_gather(gathered, checksum)
+        all_ok = all(bool(g[1].item()) and np.isfinite(g[0].item()) for g in gathered)
+    else:
+        all_ok = ranks_ok and np.isfinite(checksum[0].item())
+    if not all_ok:
+        raise SystemExit("bench: wrong ranks / non-finite solution — refusing to report a number")
+
+    if rank == 0:
+        total = batch * world * args.steps
+        value = total / elapsed
+        bytes_per = P.algorithmic_bytes(NVAR, DIMS, write_factor=args.keep_factor)
+        flops_per = P.flop_model(NVAR, DIMS)["total"]
+        achieved = bytes_per * batch / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "batched fp64 l-QR factorizations/s (factorize+solve)",
+            "value": value,
+            "unit": "factorizations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"IK batch: {batch} problems/GPU x (n={NVAR}, 5 levels x 12 rows), BASELINE configs[2] (x{world} GPUs -> configs[3] at 8)",
+                       "per_gpu_batch": batch, "global_batch": batch * world, "parallelism": f"batch-sharded x{world}",
+                       "variant": "factor kept in HBM" if args.keep_factor else "x-only", "kernel": solver.last_kernel()},
+            "gflops_fp64": value * flops_per / 1e9,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": _committed_traffic(args.keep_factor), "algorithmic_bytes_per_launch": bytes_per * batch,
+                         "kernel_ms": kernel_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(lod_host, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _committed_traffic(keep_factor):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command (profiles/), if present."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get("factor" if keep_factor else "x_only", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(lod_host, target_seconds):
+    """The CPU restatement of the reference algorithm (oracle/, kind 'port'; the Eigen-backed reference cannot be built:
+    Eigen is absent) on this host's cores, on a bounded sample of the same workload."""
+    from oracle import oracle_ctypes as oc
+    threads = max(1, oc.hardware_threads())
+    sample = lod_host[:min(len(lod_host), 4096)]
+    t1, _ = oc.lse_time(sample, DIMS, NVAR, threads, 1)
+    repeats = int(max(1, min(2000, target_seconds / max(t1, 1e-6))))
+    t, _ = oc.lse_time(sample, DIMS, NVAR, threads, repeats)
+    return {"value": len(sample) * repeats / t, "unit": "factorizations/s", "cores": threads, "kind": "port",
+            "sample": f"{repeats} passes over {len(sample)} problems of the bench batch ({t:.1f} s, g++ -O3 scalar restatement, {threads} std::threads)"}
+
+
+if __name__ == "__main__":
+    main()
