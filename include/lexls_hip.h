@@ -119,6 +119,8 @@ int lexls_lse_device_ptr(lexls_lse_t h, int which, void **d_ptr);
 
 /* name of the kernel variant the last factorize/factorize_solve call dispatched to (diagnostics) */
 const char *lexls_lse_last_kernel(lexls_lse_t h);
+/* diagnostics: force_generic != 0 disables the shape-specialised kernels (parity tests run both paths) */
+int lexls_lse_set_kernel_policy(lexls_lse_t h, int force_generic);
 
 #ifdef __cplusplus
 }

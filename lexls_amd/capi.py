@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblexls_hip.so")
+LIB_PATH = os.environ.get("LEXLS_HIP_LIB", os.path.join(_HERE, "csrc", "liblexls_hip.so"))  # env override: kernel-tuning A/B builds
 
 # every symbol include/lexls_hip.h declares (tests/test_capi_symbols.py checks the export table against the header)
 SYMBOLS = [
@@ -21,7 +21,7 @@ SYMBOLS = [
     "lexls_lse_residual", "lexls_lse_sensitivity",
     "lexls_lse_get_x", "lexls_lse_get_factor", "lexls_lse_get_hh_scalars", "lexls_lse_get_permutation", "lexls_lse_get_ranks",
     "lexls_lse_get_v", "lexls_lse_get_lambda", "lexls_lse_get_sensitivity", "lexls_lse_get_ctr_type",
-    "lexls_lse_device_ptr", "lexls_lse_last_kernel",
+    "lexls_lse_device_ptr", "lexls_lse_last_kernel", "lexls_lse_set_kernel_policy",
 ]
 
 ARRAY = dict(x=0, factor=1, hh=2, perm=3, rank=4, first_col=5, total_rank=6, v=7, lam=8, input=9)

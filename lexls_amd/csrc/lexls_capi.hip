@@ -38,7 +38,8 @@ struct lexls_lse_s
 {
     int device;
     hipStream_t stream;
-    uint32_t batch, nVar, nObj, cap, max_rows;
+    uint32_t batch, nVar, nObj, cap, max_rows, max_level_dim;
+    int force_generic;
     std::vector<uint32_t> maxdim;
     double tol;
     bool dims_set, has_fixed, factor_valid, factor_in_hbm;
@@ -122,6 +123,8 @@ extern "C"
             return fail(LEXLS_ERR_INVALID, "lexls_lse_create: zero capacity");
         }
         h->max_rows    = h->cap;
+        h->max_level_dim = 0;
+        h->force_generic = 0;
         h->tol         = 1e-12; // typedefs.h:120
         h->dims_set    = false;
         h->has_fixed   = false;
@@ -207,7 +210,7 @@ extern "C"
         CHECK_HANDLE(h);
         if (!h_dims) return fail(LEXLS_ERR_INVALID, "set_obj_dim: null dims");
         std::vector<uint32_t> d((size_t)h->batch * h->nObj);
-        uint32_t max_rows = 0;
+        uint32_t max_rows = 0, max_level = 0;
         for (uint32_t b = 0; b < h->batch; b++)
         {
             uint32_t m = 0;
@@ -217,13 +220,15 @@ extern "C"
                 if (v > h->maxdim[k]) return fail(LEXLS_ERR_INVALID, "set_obj_dim: dimension exceeds the capacity given at creation");
                 d[(size_t)b * h->nObj + k] = v;
                 m += v;
+                if (v > max_level) max_level = v;
             }
             if (m > max_rows) max_rows = m;
         }
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipMemcpyAsync(h->d_dims, d.data(), 4 * d.size(), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream)); // d is a temporary
-        h->max_rows     = max_rows ? max_rows : 1;
+        h->max_rows      = max_rows ? max_rows : 1;
+        h->max_level_dim = max_level;
         h->dims_set     = true;
         h->factor_valid = false;
         return LEXLS_OK;
@@ -300,7 +305,11 @@ extern "C"
         if (!h->d_in) return fail(LEXLS_ERR_INVALID, "no problem data: call lexls_lse_set_problem_host/device first");
         HIP_TRY(hipSetDevice(h->device));
         const char *variant = "";
-        HIP_TRY(launch_lqr_generic(h->args(), h->max_rows, write_factor, do_solve, h->stream, &variant));
+        const LseArgs a     = h->args();
+        if (!h->force_generic && wave_kernel_supports(a, h->max_rows, h->max_level_dim, h->has_fixed))
+            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->stream, &variant)); // always solves as well
+        else
+            HIP_TRY(launch_lqr_generic(a, h->max_rows, write_factor, do_solve, h->stream, &variant));
         h->last_kernel   = variant;
         h->factor_valid  = true;
         h->factor_in_hbm = write_factor || std::strstr(variant, "hbm") != nullptr;
@@ -436,4 +445,11 @@ extern "C"
     }
 
     const char *lexls_lse_last_kernel(lexls_lse_t h) { return h ? h->last_kernel : ""; }
+
+    int lexls_lse_set_kernel_policy(lexls_lse_t h, int force_generic)
+    {
+        CHECK_HANDLE(h);
+        h->force_generic = force_generic;
+        return LEXLS_OK;
+    }
 }

@@ -330,13 +330,13 @@ namespace lexls
                     if (ObjIndex + 1 < nObj && rank > 0)
                     {
                         const uint32_t Fn = F + dim;
-                        for (uint32_t i = Fn + tid; i < M; i += NT) // L <- L R^-1, one row per lane
+                        for (uint32_t i = Fn + tid; i < M; i += NT) // L <- L R^-1, one row per lane (reciprocal of the diagonal, see oracle)
                         {
                             for (uint32_t p2 = 0; p2 < rank; p2++)
                             {
                                 double s = W[i + (Fc + p2) * ld];
                                 for (uint32_t q = 0; q < p2; q++) s = dfma(-W[i + (Fc + q) * ld], W[F + q + (Fc + p2) * ld], s);
-                                W[i + (Fc + p2) * ld] = s / W[F + p2 + (Fc + p2) * ld];
+                                W[i + (Fc + p2) * ld] = s * (1.0 / W[F + p2 + (Fc + p2) * ld]);
                             }
                         }
                         __syncthreads();

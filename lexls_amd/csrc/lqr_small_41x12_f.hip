@@ -1,0 +1,2 @@
+#include "lqr_small_impl.h"
+LEXLS_WAVE_INSTANCE(launch_wave_41x12_f, 41, 12, false, true)

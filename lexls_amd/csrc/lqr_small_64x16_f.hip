@@ -1,0 +1,2 @@
+#include "lqr_small_impl.h"
+LEXLS_WAVE_INSTANCE(launch_wave_64x16_f, 64, 16, false, true)

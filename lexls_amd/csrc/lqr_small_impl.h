@@ -1,0 +1,585 @@
+// Shape-specialised lexicographic-QR kernel for IK-sized problems: ONE WAVEFRONT PER PROBLEM,
+// the whole problem in VGPRs.
+//
+// Applies when n+1 <= 64 columns, nCtr <= 64 rows and every level has <= MD rows (BASELINE
+// configs[2]/[3]: n = 40, 5 levels x 12 rows).  It computes exactly what lqr_generic.hip computes
+// (same arithmetic contract, oracle/lexlse_oracle.h, hence bit-identical results) but is organised
+// around the CDNA4 register file instead of LDS:
+//
+//   T[j]   (NC doubles / lane)  ROW-PER-LANE image of [A|b]: lane i holds row i, register j holds
+//          physical column j.  Rows of lower-priority levels stay here for the whole kernel; the
+//          Gauss step updates them with lane-local fma chains (the multipliers L[i,:] never leave
+//          the lane that computes them, the level's U rows are LDS broadcast reads).
+//   hh[r]  (MD doubles / lane)  COLUMN-PER-LANE image of the level being factorised: lane j holds
+//          column j of the level's <= MD rows, so column norms and the Householder dot products
+//          are lane-local ordered chains — no cross-lane floating-point reduction anywhere.
+//   pos    position of physical column j in the reference's permuted ordering.  Columns are never
+//          moved: the reference's column swaps (lexlse.h:222-232) become an update of this map.
+//
+// Cross-lane traffic per pivot: one DPP max-reduction (row_shr-free butterfly + row_bcast), a few
+// v_readlane for the pivot column's scalars, and one LDS exchange that spreads the pivot column
+// over the lanes so that the R-1 divisions of makeHouseholderInPlace (plus tau and 1/R_jj) cost ONE
+// division sequence.  LDS per wave: the transposition scratch and the compact [R_k T_k | rhs_k]
+// images the back-substitution needs (~10 KB), so ~12 waves fit a CU.
+#pragma once
+#include "lexls_kernels.h"
+#include "lexls_launch.h"
+
+#include <cfloat>
+#include <type_traits>
+
+namespace lexls
+{
+    namespace
+    {
+        __device__ __forceinline__ double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+        __device__ __forceinline__ double rdlane(double v, int lane)
+        {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+            return __hiloint2double(hi, lo);
+        }
+
+        template <int CTRL, int ROWMASK>
+        __device__ __forceinline__ double dpp_max(double v)
+        {
+            const int lo  = __double2loint(v), hi = __double2hiint(v);
+            const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
+            const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+            return __builtin_fmax(v, __hiloint2double(hi2, lo2));
+        }
+
+        /// maximum over the 64 lanes, returned as a wave-uniform value
+        __device__ __forceinline__ double wave_max(double v)
+        {
+            v = dpp_max<0xB1, 0xF>(v);  // quad_perm [1,0,3,2]
+            v = dpp_max<0x4E, 0xF>(v);  // quad_perm [2,3,0,1]
+            v = dpp_max<0x141, 0xF>(v); // row_half_mirror
+            v = dpp_max<0x140, 0xF>(v); // row_mirror
+            v = dpp_max<0x142, 0xA>(v); // row_bcast:15 -> rows 1,3
+            v = dpp_max<0x143, 0xC>(v); // row_bcast:31 -> rows 2,3
+            return rdlane(v, 63);
+        }
+
+        /// T[idx] for a wave-uniform idx: a scalar branch tree instead of dynamic register indexing
+        template <int NC>
+        __device__ __forceinline__ double select_reg(const double (&T)[NC], int idx)
+        {
+            double v = 0.0;
+            switch (idx)
+            {
+#define LEXLS_CASE(J)            \
+    case J:                      \
+        if (J < NC) v = T[J < NC ? J : 0]; \
+        break;
+                LEXLS_CASE(0) LEXLS_CASE(1) LEXLS_CASE(2) LEXLS_CASE(3) LEXLS_CASE(4) LEXLS_CASE(5) LEXLS_CASE(6) LEXLS_CASE(7)
+                LEXLS_CASE(8) LEXLS_CASE(9) LEXLS_CASE(10) LEXLS_CASE(11) LEXLS_CASE(12) LEXLS_CASE(13) LEXLS_CASE(14) LEXLS_CASE(15)
+                LEXLS_CASE(16) LEXLS_CASE(17) LEXLS_CASE(18) LEXLS_CASE(19) LEXLS_CASE(20) LEXLS_CASE(21) LEXLS_CASE(22) LEXLS_CASE(23)
+                LEXLS_CASE(24) LEXLS_CASE(25) LEXLS_CASE(26) LEXLS_CASE(27) LEXLS_CASE(28) LEXLS_CASE(29) LEXLS_CASE(30) LEXLS_CASE(31)
+                LEXLS_CASE(32) LEXLS_CASE(33) LEXLS_CASE(34) LEXLS_CASE(35) LEXLS_CASE(36) LEXLS_CASE(37) LEXLS_CASE(38) LEXLS_CASE(39)
+                LEXLS_CASE(40) LEXLS_CASE(41) LEXLS_CASE(42) LEXLS_CASE(43) LEXLS_CASE(44) LEXLS_CASE(45) LEXLS_CASE(46) LEXLS_CASE(47)
+                LEXLS_CASE(48) LEXLS_CASE(49) LEXLS_CASE(50) LEXLS_CASE(51) LEXLS_CASE(52) LEXLS_CASE(53) LEXLS_CASE(54) LEXLS_CASE(55)
+                LEXLS_CASE(56) LEXLS_CASE(57) LEXLS_CASE(58) LEXLS_CASE(59) LEXLS_CASE(60) LEXLS_CASE(61) LEXLS_CASE(62) LEXLS_CASE(63)
+#undef LEXLS_CASE
+            default: break;
+            }
+            return v;
+        }
+
+        template <int NC>
+        __device__ __forceinline__ void store_reg(double (&T)[NC], int idx, double val, bool pred)
+        {
+            switch (idx)
+            {
+#define LEXLS_CASE(J)                                   \
+    case J:                                             \
+        if (J < NC && pred) T[J < NC ? J : 0] = val;    \
+        break;
+                LEXLS_CASE(0) LEXLS_CASE(1) LEXLS_CASE(2) LEXLS_CASE(3) LEXLS_CASE(4) LEXLS_CASE(5) LEXLS_CASE(6) LEXLS_CASE(7)
+                LEXLS_CASE(8) LEXLS_CASE(9) LEXLS_CASE(10) LEXLS_CASE(11) LEXLS_CASE(12) LEXLS_CASE(13) LEXLS_CASE(14) LEXLS_CASE(15)
+                LEXLS_CASE(16) LEXLS_CASE(17) LEXLS_CASE(18) LEXLS_CASE(19) LEXLS_CASE(20) LEXLS_CASE(21) LEXLS_CASE(22) LEXLS_CASE(23)
+                LEXLS_CASE(24) LEXLS_CASE(25) LEXLS_CASE(26) LEXLS_CASE(27) LEXLS_CASE(28) LEXLS_CASE(29) LEXLS_CASE(30) LEXLS_CASE(31)
+                LEXLS_CASE(32) LEXLS_CASE(33) LEXLS_CASE(34) LEXLS_CASE(35) LEXLS_CASE(36) LEXLS_CASE(37) LEXLS_CASE(38) LEXLS_CASE(39)
+                LEXLS_CASE(40) LEXLS_CASE(41) LEXLS_CASE(42) LEXLS_CASE(43) LEXLS_CASE(44) LEXLS_CASE(45) LEXLS_CASE(46) LEXLS_CASE(47)
+                LEXLS_CASE(48) LEXLS_CASE(49) LEXLS_CASE(50) LEXLS_CASE(51) LEXLS_CASE(52) LEXLS_CASE(53) LEXLS_CASE(54) LEXLS_CASE(55)
+                LEXLS_CASE(56) LEXLS_CASE(57) LEXLS_CASE(58) LEXLS_CASE(59) LEXLS_CASE(60) LEXLS_CASE(61) LEXLS_CASE(62) LEXLS_CASE(63)
+#undef LEXLS_CASE
+            default: break;
+            }
+        }
+
+        __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Diagnostic build only (-DLEXLS_WAVE_STAMPS): per-phase shader-clock totals of every wave go to the (otherwise unused)
+// lambda buffer; the product build contains no stamp.  Phases: 0 load, 1 transpose, 2 pivot search, 3 norms+rank test,
+// 4 householder scalars (exchange, sqrt, division), 5 apply+downdate, 6 image store, 7 trsm, 8 gemm, 9 solve, 10 output.
+#ifdef LEXLS_WAVE_STAMPS
+#define STAMP_DECL                   \
+    unsigned long long st_acc[11];   \
+    for (int i_ = 0; i_ < 11; i_++) st_acc[i_] = 0; \
+    unsigned long long st_t0 = clock64();
+#define STAMP(i)                                   \
+    {                                              \
+        const unsigned long long t_ = clock64();   \
+        st_acc[i] += t_ - st_t0;                   \
+        st_t0 = t_;                                \
+    }
+#define STAMP_WRITE                                                                              \
+    if (lane == 0)                                                                               \
+        for (int i_ = 0; i_ < 11; i_++) a.lambda[(size_t)b * (n + cap) + i_] = (double)st_acc[i_];
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_WRITE
+#endif
+
+        // NC: register columns (n+1 <= NC <= 64).  MD: max rows of one level (even).  EXACT: n+1 == NC (n is then a
+        // compile-time constant and every column guard folds away).
+        //
+        // Control flow is kept coarse on purpose: a level whose dim == MD (and, in the Gauss step, whose rank == MD) runs a
+        // fully static, branch-free instruction stream (FULL = true); ragged levels take the same code with run-time
+        // guards.  Per-element scalar branches around single fma's cost more than the arithmetic they skip.
+#ifndef LEXLS_WAVE_OCC
+#define LEXLS_WAVE_OCC 2
+#endif
+        template <int NC, int MD, bool EXACT, bool WF>
+        __global__ __launch_bounds__(64, LEXLS_WAVE_OCC) void lqr_wave_kernel(LseArgs a, uint32_t img_doubles)
+        {
+            constexpr bool write_factor = WF; // factor kept in HBM (get_lexqr / dual solve) or x-only traffic
+            extern __shared__ double smem[];
+            const int lane       = threadIdx.x;
+            const uint32_t b     = blockIdx.x;
+            const int n          = EXACT ? NC - 1 : (int)a.nVar;
+            const int cap        = (int)a.cap;
+            const int nObj       = (int)a.nObj;
+            const size_t pstride = (size_t)cap * (n + 1);
+
+            // ---- LDS carve-up ----
+            double *X        = smem;                  // NC*MD : level transposition scratch
+            double *EX       = X + NC * MD;           // 128   : [0,64) pivot-column exchange, [64,64+MD) 1/R_qq, [96,..) pivot lanes
+            double *idg_s    = EX + 64;               // MD: reciprocal diagonal of the level being factorised
+            int *pivl_s      = reinterpret_cast<int *>(EX + 96); // MD: lane of the q-th pivot column
+            double *IMG      = EX + 128;              // img_doubles : compact [R T | rhs] images of the levels
+            double *xs       = IMG + img_doubles;     // 64    : solution by position
+            uint32_t *perm_s = reinterpret_cast<uint32_t *>(xs + 64); // 64
+            uint32_t *meta   = perm_s + 64;           // 4*nObj: fc, rank, base, stride
+            uint8_t *phys_s  = reinterpret_cast<uint8_t *>(meta + 4 * nObj); // 64: physical column at each final position
+            uint8_t *slotmap = phys_s + 64;           // nObj*64: position of each physical column when level k was stored
+            uint16_t *offs   = reinterpret_cast<uint16_t *>(slotmap + 64 * nObj); // 64: image offsets of the solved columns
+            STAMP_DECL
+
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            int M                = 0;
+            for (int k = 0; k < nObj; k++) M += (int)dims[k];
+
+            // ---- load: row-per-lane, coalesced down each column ----
+            const double *in = a.in + b * pstride;
+            double T[NC];
+#pragma unroll
+            for (int j = 0; j < NC; j++) T[j] = (j <= n && lane < M) ? in[lane + (size_t)j * cap] : 0.0;
+
+            double *hhs = a.hh + (size_t)b * cap;
+            for (int i = lane; i < cap; i += 64) hhs[i] = 0.0; // initialize(), lexlse.h:1683
+            perm_s[lane] = lane;
+
+            int pos        = (lane < n) ? lane : (lane == n ? n : 0x3fffffff);
+            int ColIndex   = 0;
+            int TotalRank  = 0;
+            uint32_t imgp  = 0; // bump pointer into IMG
+            bool exhausted = false;
+            int F          = 0;
+            STAMP(0)
+
+            for (int k = 0; k < nObj; k++)
+            {
+                const int dim_rt = (int)dims[k];
+                const int Fc     = ColIndex;
+                int rank         = 0;
+
+                double hh[MD];
+#pragma unroll
+                for (int r = 0; r < MD; r++) hh[r] = 0.0;
+
+                // =====================================================================================
+                // Householder QR with column pivoting of the level (lexlse.h:182-268)
+                // =====================================================================================
+                auto factor_level = [&](auto full_c) {
+                    constexpr bool FULL = decltype(full_c)::value;
+                    const int dim       = FULL ? MD : dim_rt;
+
+                    // transpose the level's rows: row-per-lane T -> column-per-lane hh (through LDS)
+                    __syncthreads();
+                    if (lane >= F && lane < F + dim)
+                    {
+#pragma unroll
+                        for (int j = 0; j < NC; j++)
+                            if (j <= n) X[j * MD + (lane - F)] = T[j];
+                    }
+                    __syncthreads();
+                    if (lane <= n)
+                    {
+#pragma unroll
+                        for (int r = 0; r < MD; r++)
+                            if (r < dim) hh[r] = X[lane * MD + r];
+                    }
+
+                    // initial squared norms of the level's columns (lexlse.h:193-196); rows >= dim are zero: fma(0,0,s) == s
+                    double nrm = 0.0;
+#pragma unroll
+                    for (int r = 0; r < MD; r++) nrm = dfma(hh[r], hh[r], nrm);
+                    STAMP(1)
+
+                    bool go = !exhausted; // wave-uniform: false once the level hit its rank / the columns ran out
+#pragma unroll
+                    for (int counter = 0; counter < MD; counter++)
+                    {
+                        if (!(go && counter < dim)) continue;
+                        const int R   = dim - counter; // compile-time when FULL
+                        const int row = F + counter;
+
+                        // -- pivot: first maximum (by position) of the down-dated norms (lexlse.h:205-206) --
+                        const bool cand      = (lane < n) && (pos >= ColIndex);
+                        const double key     = cand ? nrm : -INFINITY;
+                        const double maxv    = wave_max(key);
+                        unsigned long long m = __ballot(cand && key == maxv);
+                        int pl               = (int)__builtin_ctzll(m);
+                        if (__builtin_popcountll(m) > 1)
+                        {
+                            int bestpos = 0x7fffffff;
+                            while (m)
+                            {
+                                const int l = (int)__builtin_ctzll(m);
+                                m &= m - 1;
+                                const int p2 = __builtin_amdgcn_readlane(pos, l);
+                                if (p2 < bestpos)
+                                {
+                                    bestpos = p2;
+                                    pl      = l;
+                                }
+                            }
+                        }
+                        pl = uni(pl);
+                        STAMP(2)
+
+                        // -- fresh norm of the pivot column and the Householder tail norm (lexlse.h:210-211, :241) --
+                        double fr = 0.0, tl = 0.0;
+#pragma unroll
+                        for (int r = 0; r < MD; r++)
+                        {
+                            if (r >= counter) fr = dfma(hh[r], hh[r], fr);
+                            if (r > counter) tl = dfma(hh[r], hh[r], tl);
+                        }
+                        const double fresh = rdlane(fr, pl);
+                        if (lane == pl) nrm = fresh;
+                        if (fresh < a.tol) // rank test on the squared norm (lexlse.h:214)
+                        {
+                            go = false;
+                            continue;
+                        }
+                        STAMP(3)
+
+                        // -- column "swap": update the position map (lexlse.h:222-232) --
+                        const int ppos = __builtin_amdgcn_readlane(pos, pl);
+                        if (lane == 0) perm_s[ColIndex] = (uint32_t)ppos;
+                        {
+                            const unsigned long long mc = __ballot(lane < n && pos == ColIndex);
+                            const int lc                = (int)__builtin_ctzll(mc);
+                            if (lane == lc) pos = ppos;
+                            if (lane == pl) pos = ColIndex;
+                        }
+
+                        const double c0 = rdlane(hh[counter], pl);
+                        if (R > 1)
+                        {
+                            const double tailSq   = rdlane(tl, pl);
+                            const bool degenerate = tailSq <= DBL_MIN;
+                            double beta           = sqrt(dfma(c0, c0, tailSq));
+                            if (c0 >= 0.0) beta = -beta;
+                            const double diag = degenerate ? c0 : beta;
+                            const double den  = c0 - beta;
+
+                            // spread the pivot column over the lanes: lane t gets v_{counter+t}
+                            __syncthreads();
+                            if (lane == pl)
+                            {
+#pragma unroll
+                                for (int r = 0; r < MD; r++)
+                                    if (r > counter) EX[r - counter] = hh[r];
+                            }
+                            __syncthreads();
+                            double num = (lane > 0 && lane < R) ? EX[lane] : 1.0;
+                            double dnm = den;
+                            if (lane == 0)
+                            {
+                                num = beta - c0;
+                                dnm = beta;
+                            }
+                            if (lane >= R)
+                            {
+                                num = 1.0;
+                                dnm = diag;
+                            }
+                            const double quo = num / dnm; // ONE division sequence: tau | essential part | 1/R_jj
+                            if (lane == 63) idg_s[counter] = quo;
+                            STAMP(4)
+                            // wave-uniform tau and essentials (SGPR pairs); zero beyond the level's rows and when H is the identity
+                            const double quo_e = (degenerate || lane >= R) ? 0.0 : quo;
+                            const double tau   = rdlane(quo_e, 0);
+                            double e[MD];
+#pragma unroll
+                            for (int t = 0; t < MD; t++) e[t] = 0.0;
+#pragma unroll
+                            for (int t = 1; t < MD; t++)
+                                if (t < MD - counter) e[t] = rdlane(quo_e, t);
+
+                            // the pivot column now holds beta and the essential part (zeros if degenerate)
+                            if (lane == pl)
+                            {
+                                hh[counter] = diag;
+#pragma unroll
+                                for (int r = 0; r < MD; r++)
+                                    if (r > counter) hh[r] = e[r - counter];
+                            }
+                            // apply H to the trailing columns and the RHS (lexlse.h:243-246); branch-free: zero essentials are no-ops
+                            const bool trailing = ((lane < n) && (pos > ColIndex)) || (lane == n);
+                            if (tau != 0.0 && trailing)
+                            {
+                                double tmp = 0.0;
+#pragma unroll
+                                for (int r = 0; r < MD; r++)
+                                    if (r > counter) tmp = dfma(e[r - counter], hh[r], tmp);
+                                tmp += hh[counter];
+                                hh[counter] = dfma(-tau, tmp, hh[counter]);
+#pragma unroll
+                                for (int r = 0; r < MD; r++)
+                                    if (r > counter) hh[r] = dfma(-(tau * e[r - counter]), tmp, hh[r]);
+                            }
+                            if (lane == 0) hhs[row] = tau;
+                        }
+                        else
+                        {
+                            if (lane == 63) idg_s[counter] = 1.0 / c0;
+                        }
+                        if (lane == 0) pivl_s[counter] = pl;
+
+                        ColIndex++;
+                        rank++;
+                        if (ColIndex == n)
+                        {
+                            exhausted = true;
+                            go        = false;
+                        }
+                        else if ((lane < n) && (pos >= ColIndex))
+                        {
+                            nrm = dfma(-hh[counter], hh[counter], nrm); // lexlse.h:262-266
+                        }
+                        STAMP(5)
+                    }
+                };
+
+                if (dim_rt > 0 && (!exhausted || write_factor))
+                {
+                    if (dim_rt == MD)
+                        factor_level(std::true_type{});
+                    else
+                        factor_level(std::false_type{});
+                }
+                const int dim = dim_rt;
+
+                const int stride = (rank + 1) & ~1;
+                if (lane == 0)
+                {
+                    meta[4 * k + 0] = (uint32_t)Fc;
+                    meta[4 * k + 1] = (uint32_t)rank;
+                    meta[4 * k + 2] = imgp;
+                    meta[4 * k + 3] = (uint32_t)stride;
+                }
+                TotalRank += rank;
+
+                // ---- the level's final rows: compact image for the Gauss step / back-substitution ----
+                double *img = IMG + imgp;
+                if (rank > 0)
+                {
+                    const int slot = (lane < n) ? pos : n;
+                    if (lane <= n && slot >= Fc)
+                    {
+#pragma unroll
+                        for (int r = 0; r < MD; r++)
+                            if (r < stride) img[(slot - Fc) * stride + r] = (r < rank) ? hh[r] : 0.0; // padding row zeroed
+                    }
+                    imgp += (uint32_t)((n + 1 - Fc) * stride);
+                }
+                slotmap[k * 64 + lane] = (uint8_t)((lane < n) ? pos : n);
+                if (write_factor && dim > 0) // the level's final rows go back into the row-per-lane image (factor output)
+                {
+                    __syncthreads();
+                    if (lane <= n)
+                    {
+#pragma unroll
+                        for (int r = 0; r < MD; r++)
+                            if (r < dim) X[lane * MD + r] = hh[r];
+                    }
+                    __syncthreads();
+                    if (lane >= F && lane < F + dim)
+                    {
+#pragma unroll
+                        for (int j = 0; j < NC; j++)
+                            if (j <= n) T[j] = X[j * MD + (lane - F)];
+                    }
+                }
+                __syncthreads();
+                STAMP(6)
+
+                // =====================================================================================
+                // Gauss step on the rows below (lexlse.h:431-471): lane i = row i
+                // =====================================================================================
+                auto gauss = [&](auto full_c) {
+                    constexpr bool FULL = decltype(full_c)::value;
+                    const int rk        = FULL ? MD : rank;
+                    const int Fn        = F + dim;
+                    const bool below    = lane >= Fn && lane < M;
+                    double Lv[MD];
+#pragma unroll
+                    for (int q = 0; q < MD; q++) Lv[q] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < MD; q++)
+                    {
+                        if (q < rk) // one uniform guard per pivot (folds away when FULL)
+                        {
+                            const int pq = uni(pivl_s[q]);
+                            double s     = select_reg<NC>(T, pq);
+#pragma unroll
+                            for (int p2 = 0; p2 < MD; p2++)
+                                if (p2 < q) s = dfma(-Lv[p2], img[q * stride + p2], s);
+                            Lv[q] = s * idg_s[q];
+                            if (write_factor) store_reg<NC>(T, pq, Lv[q], below);
+#ifdef LEXLS_WAVE_SCHED_FENCE
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
+                        }
+                    }
+                    STAMP(7)
+                    // Trailing -= L * Up for every column that is still free, and the RHS.  Lv[p] == 0 for p >= rank and the
+                    // image's padding row is zero, so the chain runs over the (even) stride without per-element guards.
+                    const unsigned long long tmask = __ballot(((lane < n) && (pos >= ColIndex)) || (lane == n));
+#pragma unroll
+                    for (int j = 0; j < NC; j++)
+                    {
+                        if (j <= n && ((tmask >> j) & 1ull))
+                        {
+                            const int slot  = (j < n) ? __builtin_amdgcn_readlane(pos, j) : n;
+                            const double *u = static_cast<const double *>(__builtin_assume_aligned(img + (slot - Fc) * stride, 16));
+                            double t        = T[j];
+#pragma unroll
+                            for (int p2 = 0; p2 < MD; p2++)
+                                if (FULL || p2 < stride) t = dfma(-Lv[p2], u[p2], t);
+                            if (below) T[j] = t;
+#ifdef LEXLS_WAVE_SCHED_FENCE
+                            if ((j % LEXLS_WAVE_SCHED_FENCE) == LEXLS_WAVE_SCHED_FENCE - 1) __builtin_amdgcn_sched_barrier(0); // bound the live ranges of hoisted LDS loads
+#endif
+                        }
+                    }
+                    STAMP(8)
+                };
+                if (k + 1 < nObj && rank > 0)
+                {
+                    if (rank == MD)
+                        gauss(std::true_type{});
+                    else
+                        gauss(std::false_type{});
+                }
+                F += dim;
+            }
+
+            // ---- solve(): block back-substitution on the compact images (lexlse.h:1015-1045) ----
+            __syncthreads();
+            xs[lane] = 0.0;
+            if (lane <= n) phys_s[(lane < n) ? pos : n] = (uint8_t)lane;
+            __syncthreads();
+            {
+                int acc = 0;
+                for (int k = nObj; k--;)
+                {
+                    const int rank = uni((int)meta[4 * k + 1]);
+                    if (rank == 0) continue;
+                    const int Fc       = uni((int)meta[4 * k + 0]);
+                    const double *img  = IMG + uni((int)meta[4 * k + 2]);
+                    const int stride   = uni((int)meta[4 * k + 3]);
+                    const int c0       = Fc + rank; // == first_col_index of the next level with rank > 0
+                    // later column swaps also permuted this level's T block: final position -> physical column -> slot at store time
+                    // (lane j resolves the offset of position c0 + j once; the ordered fma chain below then only streams)
+                    if (lane < acc) offs[lane] = (uint16_t)(((int)slotmap[k * 64 + phys_s[c0 + lane]] - Fc) * stride);
+                    __syncthreads();
+                    double s = 0.0;
+                    if (lane < rank)
+                    {
+                        s = img[(n - Fc) * stride + lane];
+#pragma unroll 4
+                        for (int j = 0; j < acc; j++) s = dfma(-img[offs[j] + lane], xs[c0 + j], s);
+                    }
+                    for (int j = rank; j--;)
+                    {
+                        const double rjj = img[j * stride + j]; // uniform address
+                        const double sj  = rdlane(s, j);
+                        const double xj  = sj / rjj;
+                        if (lane == j) s = xj;
+                        if (lane < j) s = dfma(-img[j * stride + lane], xj, s);
+                    }
+                    if (lane < rank) xs[Fc + lane] = s;
+                    __syncthreads();
+                    acc += rank;
+                }
+            }
+            STAMP(9)
+
+            // ---- results ----
+            if (write_factor) // get_lexqr layout: column = FINAL position of the physical column
+            {
+                double *out = a.fac + b * pstride;
+#pragma unroll
+                for (int j = 0; j < NC; j++)
+                    if (j <= n)
+                    {
+                        const int slot = (j < n) ? __builtin_amdgcn_readlane(pos, j) : n;
+                        if (lane < M) out[lane + (size_t)slot * cap] = T[j];
+                    }
+            }
+            if (lane < n) a.x[(size_t)b * n + lane] = xs[pos]; // x = P x: variable j sits at position pos[j]
+            if (lane < n) a.perm[(size_t)b * n + lane] = (lane < TotalRank) ? perm_s[lane] : (uint32_t)lane;
+            if (lane < nObj)
+            {
+                a.fcol[(size_t)b * nObj + lane] = meta[4 * lane + 0];
+                a.rank[(size_t)b * nObj + lane] = meta[4 * lane + 1];
+            }
+            if (lane == 0) a.totalrank[b] = (uint32_t)TotalRank;
+            STAMP(10)
+            STAMP_WRITE
+        }
+    } // namespace
+
+    namespace
+    {
+        template <int NC, int MD, bool EXACT, bool WF>
+        hipError_t launch_wave_t2(const LseArgs &a, hipStream_t s)
+        {
+            // worst case of sum_k (n+1-Fc_k) * even(rank_k) over rank distributions with rank_k <= MD
+            const uint32_t n   = a.nVar;
+            const uint32_t img = (n * n) / 2 + n + (n * MD) / 2 + a.nObj * (n + 1) + 64;
+            const size_t lds   = 8 * ((size_t)NC * MD + 128 + img + 64) + 4 * (64 + 4 * (size_t)a.nObj) + 64 + 64 * (size_t)a.nObj + 128 + 16;
+            if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
+            if (lds > 64 * 1024)
+            {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_wave_kernel<NC, MD, EXACT, WF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL((lqr_wave_kernel<NC, MD, EXACT, WF>), dim3(a.batch), dim3(64), lds, s, a, img);
+            return hipGetLastError();
+        }
+
+    } // namespace
+} // namespace lexls
+
+// One translation unit per instantiation (parallel builds): LEXLS_WAVE_INSTANCE(name, NC, MD, EXACT, WF)
+#define LEXLS_WAVE_INSTANCE(NAME, NC, MD, EXACT, WF) \
+    namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_wave_t2<NC, MD, EXACT, WF>(a, s); } }

@@ -168,5 +168,9 @@ class BatchedLexLSE:
         capi.check(capi.lib().lexls_lse_device_ptr(self._h, C.c_int(capi.ARRAY[name]), C.byref(p)))
         return int(p.value)
 
+    def set_kernel_policy(self, force_generic: bool):
+        """diagnostics: route every factorization through the generic kernels"""
+        capi.check(capi.lib().lexls_lse_set_kernel_policy(self._h, C.c_int(1 if force_generic else 0)))
+
     def last_kernel(self) -> str:
         return capi.lib().lexls_lse_last_kernel(self._h).decode()

@@ -20,6 +20,7 @@
 // ARITHMETIC CONTRACT (what the HIP kernels reproduce bit-for-bit; compile with -ffp-contract=off):
 //   dot / squaredNorm : s = 0; s = fma(a_i, b_i, s) for i ascending
 //   "c -= a*b"        : c = fma(-a, b, c), inner index ascending, accumulating INTO c
+//   Gauss TRSM        : L_ip = (A_ip - sum_{q<p} L_iq R_qp) * (1 / R_pp), q ascending, reciprocal computed once per pivot
 //   triangular solve  : column-oriented, x_j /= R_jj then x_i = fma(-R_ij, x_j, x_i) for i < j, j descending
 //   division, sqrt    : IEEE correctly rounded
 //   argmax            : first occurrence of the maximum (Eigen maxCoeff, eigen_like_syntax/maxCoeff.m:11)
@@ -315,13 +316,17 @@ namespace lexls_oracle
                 if (ObjIndex < nObj - 1 && rank > 0)
                 {
                     const Index Fn = F + dim;
+                    // Eigen's right-side triangular solve scales by the RECIPROCAL of the diagonal
+                    // (TriangularSolverMatrix.h, OnTheRight kernel: "inv_rjj = 1/rhs(j,j); r[i] *= inv_rjj")
+                    double *inv_diag = dWorkspace.data() + nVar;
+                    for (Index p = 0; p < rank; p++) inv_diag[p] = 1.0 / LOD(F + p, Fc + p);
                     for (Index i = Fn; i < M; i++)
                     {
                         for (Index p = 0; p < rank; p++)
                         {
                             double s = LOD(i, Fc + p);
                             for (Index q = 0; q < p; q++) s = std::fma(-LOD(i, Fc + q), LOD(F + q, Fc + p), s);
-                            LOD(i, Fc + p) = s / LOD(F + p, Fc + p);
+                            LOD(i, Fc + p) = s * inv_diag[p];
                         }
                         for (Index j = ColIndex; j <= n; j++)
                         {

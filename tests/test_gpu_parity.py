@@ -9,7 +9,7 @@ from lexls_amd import problems as P
 pytestmark = pytest.mark.gpu
 
 
-def run_both(hip, oracle, lod, dims, nvar, maxdim=None, keep_factor=True, **fixed):
+def run_both(hip, oracle, lod, dims, nvar, maxdim=None, keep_factor=True, force_generic=False, **fixed):
     batch = lod.shape[0]
     dims_a = np.asarray(dims, np.uint32)
     if maxdim is None:
@@ -18,6 +18,7 @@ def run_both(hip, oracle, lod, dims, nvar, maxdim=None, keep_factor=True, **fixe
         maxdim[-1] += lod.shape[2] - int(maxdim.sum())
     ref = oracle.lse_run(lod, dims, nvar, maxdim=maxdim, **fixed)
     s = hip.BatchedLexLSE(batch, nvar, maxdim)
+    s.set_kernel_policy(force_generic)
     s.setObjDim(dims_a)
     if "nfixed" in fixed:
         s.fixVariables(fixed["nfixed"], fixed["fixed_idx"], fixed["fixed_val"], fixed.get("fixed_type"))
@@ -40,20 +41,25 @@ def assert_factor_equal(s, ref, dims, nvar):
         np.testing.assert_array_equal(f[b, :, :m[b]], ref["factor"][b, :, :m[b]])
 
 
-def test_ik_batch_bit_exact(hip, oracle):
+BOTH_PATHS = pytest.mark.parametrize("force_generic", [False, True], ids=["specialised", "generic"])
+
+
+@BOTH_PATHS
+def test_ik_batch_bit_exact(hip, oracle, force_generic):
     dims, n = [12] * 5, 40
     lod = P.lse_batch(20260100, 64, n, dims)
-    s, ref = run_both(hip, oracle, lod, dims, n)
+    s, ref = run_both(hip, oracle, lod, dims, n, force_generic=force_generic)
     assert (ref["rank"] == [12, 12, 12, 4, 0]).all()
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
-    assert "lds" in s.last_kernel()
+    assert s.last_kernel() == ("lqr_generic<64,lds>" if force_generic else "lqr_wave<41,12,exact>")
 
 
-def test_x_only_variant_matches(hip, oracle):
+@BOTH_PATHS
+def test_x_only_variant_matches(hip, oracle, force_generic):
     dims, n = [12] * 5, 40
     lod = P.lse_batch(7, 32, n, dims)
-    s, ref = run_both(hip, oracle, lod, dims, n, keep_factor=False)
+    s, ref = run_both(hip, oracle, lod, dims, n, keep_factor=False, force_generic=force_generic)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
     np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
     with pytest.raises(Exception):
@@ -72,27 +78,50 @@ def test_factorize_then_solve_separately(hip, oracle):
     assert (ref["rank"] == 6).all()
 
 
-def test_rank_deficient_levels(hip, oracle):
+@BOTH_PATHS
+def test_rank_deficient_levels(hip, oracle, force_generic):
     n, dims, ranks = 15, [5, 5, 5, 5], [3, 3, 3, 3]
     lod = np.stack([P.rank_deficient_problem(100 + b, n, dims, ranks) for b in range(24)])
-    s, ref = run_both(hip, oracle, lod, dims, n)
+    s, ref = run_both(hip, oracle, lod, dims, n, force_generic=force_generic)
     assert (ref["rank"] == ranks).all()
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
-def test_ragged_batch(hip, oracle):
+@BOTH_PATHS
+def test_ragged_batch(hip, oracle, force_generic):
     n, cap_dims = 20, [8, 8, 8]
     rng_dims = np.array([[8, 8, 8], [3, 0, 5], [1, 8, 2], [0, 0, 4], [8, 1, 0], [5, 5, 5], [2, 2, 2], [7, 3, 8]], np.uint32)
     full = np.zeros((8, n + 1, 24))
     for b in range(8):
         m = int(rng_dims[b].sum())
         full[b, :, :m] = P.lse_problem(900 + b, n, rng_dims[b])
-    s, ref = run_both(hip, oracle, full, rng_dims, n, maxdim=np.array(cap_dims, np.uint32))
+    s, ref = run_both(hip, oracle, full, rng_dims, n, maxdim=np.array(cap_dims, np.uint32), force_generic=force_generic)
     assert_factor_equal(s, ref, rng_dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
+
+
+@pytest.mark.parametrize("n,dims", [(63, [16, 16, 16, 16]), (30, [14, 9, 16]), (40, [6] * 5), (5, [12, 12]), (40, [12, 0, 12, 12, 12]), (12, [1, 1, 1, 1, 1, 1, 1, 1])])
+def test_wave_kernel_shapes(hip, oracle, n, dims):
+    lod = P.lse_batch(1000 + n, 9, n, dims)
+    s, ref = run_both(hip, oracle, lod, dims, n)
+    assert s.last_kernel().startswith("lqr_wave")
+    assert_factor_equal(s, ref, dims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+
+
+def test_wave_kernel_tied_norms(hip, oracle):
+    """duplicated columns: exact ties in the pivot search must resolve to the first position (maxCoeff semantics)."""
+    n, dims = 10, [4, 4, 4]
+    lod = P.lse_batch(77, 4, n, dims)
+    lod[:, 3, :] = lod[:, 1, :]
+    lod[:, 7, :] = lod[:, 1, :]
+    lod[:, 5, :] = -lod[:, 2, :]
+    s, ref = run_both(hip, oracle, lod, dims, n)
+    assert_factor_equal(s, ref, dims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
 def test_fixed_variables(hip, oracle):
