@@ -1,0 +1,284 @@
+// LexLS::internal::LexLSE — drop-in for the reference's equality solver, backed by liblexls_hip.
+//
+// Same public member functions, argument meaning and error behaviour as the reference class
+// (/root/reference/include/lexls/lexlse.h:33-2886; signatures listed in SURVEY.md section 8(b)),
+// but every arithmetic member function is a call through the C ABI (include/lexls_hip.h) into the
+// hand-written HIP kernels; the object keeps host copies of the problem (inputs are copied, like the
+// reference's setData/setCtr) and of the last results.  One object = a batch of ONE problem; the
+// batched drivers use the C ABI directly.  Link with -llexls_hip.  There is no CPU fallback: without a
+// GPU the constructor throws LexLS::Exception.
+//
+// Differences a caller can observe: Eigen types are replaced by the containers of typedefs.h
+// (dMatrixConstRef is a (ptr, rows, cols, ld) view); setCtr takes a pointer to nVar doubles;
+// regularization types other than REGULARIZATION_NONE and solveLeastNorm_2/_3/solveGeneralNorm throw.
+#pragma once
+
+#include <lexls/typedefs.h>
+#include <lexls_hip.h>
+
+namespace LexLS
+{
+    namespace internal
+    {
+        class LexLSE
+        {
+        public:
+            LexLSE() : h(NULL), nVar(0), nObj(0), nCtr(0), cap(0), nVarFixed(0), nVarFixedInit(0), TotalRank(0), device(0) {}
+            LexLSE(Index nVar_, Index nObj_, Index *ObjDim_) : h(NULL), nVarFixed(0), nVarFixedInit(0), device(0)
+            {
+                resize(nVar_, nObj_, ObjDim_);
+                setObjDim(ObjDim_);
+            }
+            ~LexLSE()
+            {
+                if (h) lexls_lse_destroy(h);
+            }
+            LexLSE(const LexLSE &)            = delete;
+            LexLSE &operator=(const LexLSE &) = delete;
+
+            /// which GPU later resize() calls allocate on (default 0)
+            void setDevice(int device_) { device = device_; }
+
+            /// lexlse.h:67-103
+            void resize(Index nVar_, Index nObj_, Index *maxObjDim)
+            {
+                if (h) lexls_lse_destroy(h);
+                h    = NULL;
+                nVar = nVar_;
+                nObj = nObj_;
+                check(lexls_lse_create(&h, device, 1, nVar, nObj, maxObjDim));
+                cap = 0;
+                for (Index k = 0; k < nObj; k++) cap += maxObjDim[k];
+                dims.assign(nObj, 0);
+                first_row.assign(nObj, 0);
+                rank.assign(nObj, 0);
+                first_col.assign(nObj, 0);
+                x.resize(nVar);
+                LOD.resize(cap, nVar + 1);
+                PROBLEM_DATA.resize(cap, nVar + 1);
+                FACTOR.resize(cap, nVar + 1);
+                dWorkspace.resize(2 * std::max(cap, nVar) + nVar + 1);
+                ctr_type.assign(cap, static_cast<uint8_t>(CTR_INACTIVE));
+                fixed_idx.assign(nVar, 0);
+                fixed_val.assign(nVar, 0.0);
+                fixed_type.assign(nVar, static_cast<uint8_t>(CTR_ACTIVE_UB));
+                nCtr = TotalRank = 0;
+                check(lexls_lse_set_tolerance(h, parameters.tol_linear_dependence));
+            }
+
+            /// lexlse.h:1426-1442 (incl. initialize(), :1672-1693)
+            void setObjDim(Index *ObjDim_)
+            {
+                nCtr = 0;
+                for (Index k = 0; k < nObj; k++)
+                {
+                    dims[k]      = ObjDim_[k];
+                    first_row[k] = nCtr;
+                    nCtr += ObjDim_[k];
+                    rank[k] = first_col[k] = 0;
+                }
+                check(lexls_lse_set_obj_dim(h, dims.data(), 0));
+                nVarFixedInit = 0;
+                TotalRank     = 0;
+                for (Index i = nVarFixed; i < nVar; i++) x(i) = 0.0;
+            }
+
+            /// lexlse.h:1467 — only REGULARIZATION_NONE has a device path
+            void setParameters(const ParametersLexLSE &p)
+            {
+                if (p.regularization_type != REGULARIZATION_NONE) throw Exception("lexls_hip: only REGULARIZATION_NONE is implemented on the device path");
+                parameters = p;
+                if (h) check(lexls_lse_set_tolerance(h, p.tol_linear_dependence));
+            }
+            void setRegularizationFactor(Index, RealScalar) {} // lexlse.h:1477 (unused without regularization)
+
+            /// lexlse.h:1449-1462
+            void setFixedVariablesCount(Index nVarFixed_)
+            {
+                if (nVarFixed_ > nVar) throw Exception("Cannot fix more than nVar variables");
+                nVarFixed = nVarFixed_;
+            }
+            /// lexlse.h:1381-1388
+            void fixVariable(Index VarIndex, RealScalar VarValue, ConstraintActivationType type = CTR_ACTIVE_UB)
+            {
+                fixed_idx[nVarFixedInit]  = VarIndex;
+                fixed_val[nVarFixedInit]  = VarValue;
+                fixed_type[nVarFixedInit] = static_cast<uint8_t>(type);
+                x(nVarFixedInit)          = VarValue;
+                nVarFixedInit++;
+            }
+            /// lexlse.h:1398-1419
+            void fixVariables(Index nVarFixed_, Index *VarIndex, RealScalar *VarValue, ConstraintActivationType *type)
+            {
+                setFixedVariablesCount(nVarFixed_);
+                nVarFixedInit = 0;
+                for (Index k = 0; k < nVarFixed; k++) fixVariable(VarIndex[k], VarValue[k], type[k]);
+            }
+
+            /// lexlse.h:1511-1514
+            void setProblem(const dMatrixConstRef &data)
+            {
+                for (Index j = 0; j < data.cols(); j++)
+                    for (Index i = 0; i < data.rows(); i++) LOD(i, j) = data(i, j);
+            }
+            /// lexlse.h:1522-1530
+            void setData(Index ObjIndex, const dMatrixConstRef &data)
+            {
+                if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");
+                for (Index j = 0; j <= nVar; j++)
+                    for (Index i = 0; i < dims[ObjIndex]; i++) LOD(first_row[ObjIndex] + i, j) = data(i, j);
+            }
+            /// lexlse.h:1539-1543
+            void setCtrStrided(Index CtrIndex, const RealScalar *row, Index stride, RealScalar rhs)
+            {
+                for (Index j = 0; j < nVar; j++) LOD(CtrIndex, j) = row[static_cast<size_t>(j) * stride];
+                LOD(CtrIndex, nVar) = rhs;
+            }
+            void setCtr(Index CtrIndex, const RealScalar *row, RealScalar rhs) { setCtrStrided(CtrIndex, row, 1, rhs); }
+            /// lexlse.h:1548-1552
+            void setCtrType(Index ObjIndex, Index CtrIndex, ConstraintActivationType type) { ctr_type[first_row[ObjIndex] + CtrIndex] = static_cast<uint8_t>(type); }
+
+            /// lexlse.h:117-506
+            void factorize()
+            {
+                PROBLEM_DATA = LOD; // :119
+                upload();
+                check(lexls_lse_factorize(h));
+                check(lexls_lse_get_ranks(h, rank.data(), first_col.data(), &TotalRank));
+                factor_on_host = false;
+            }
+            /// lexlse.h:1015-1045
+            void solve()
+            {
+                check(lexls_lse_solve(h));
+                check(lexls_lse_get_x(h, x.data()));
+            }
+            /// lexlse.h:1052-1131
+            void solveLeastNorm_1()
+            {
+                check(lexls_lse_solve_least_norm(h));
+                check(lexls_lse_get_x(h, x.data()));
+            }
+            void solveLeastNorm_2() { throw Exception("lexls_hip: solveLeastNorm_2 has no device path (use solveLeastNorm_1)"); }
+            void solveLeastNorm_3() { throw Exception("lexls_hip: solveLeastNorm_3 has no device path (use solveLeastNorm_1)"); }
+
+            /// lexlse.h:611-762; on return getWorkspace().head(nVarFixed + nLambda) = [lambda_fixed; lambda]
+            bool ObjectiveSensitivity(Index ObjIndex, Index &CtrIndex2Remove, int &ObjIndex2Remove, RealScalar tol_wrong_sign_lambda,
+                                      RealScalar tol_correct_sign_lambda, RealScalar &maxAbsValue)
+            {
+                if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");
+                check(lexls_lse_sensitivity(h, NULL, static_cast<int32_t>(ObjIndex), tol_wrong_sign_lambda, tol_correct_sign_lambda));
+                int32_t s3[3];
+                check(lexls_lse_get_sensitivity(h, s3, &maxAbsValue));
+                std::vector<double> lam(nVar + cap);
+                check(lexls_lse_get_lambda(h, lam.data()));
+                for (Index i = 0; i < nVar + cap && i < dWorkspace.size(); i++) dWorkspace(i) = lam[i];
+                if (s3[0])
+                {
+                    CtrIndex2Remove = static_cast<Index>(s3[1]);
+                    ObjIndex2Remove = s3[2];
+                }
+                return s3[0] != 0;
+            }
+            /// lexlse.h:511-602 (deactivate_first_wrong_sign): not on the device path
+            void ObjectiveSensitivity(Index, RealScalar, RealScalar, std::vector<ConstraintInfo> &)
+            {
+                throw Exception("lexls_hip: the 'collect all wrong-sign multipliers' overload has no device path (deactivate_first_wrong_sign)");
+            }
+
+            /// lexlse.h:1560-1582
+            dVectorType &get_v()
+            {
+                check(lexls_lse_residual(h));
+                std::vector<double> v(cap);
+                check(lexls_lse_get_v(h, v.data()));
+                for (Index i = 0; i < nCtr; i++) dWorkspace(i) = v[i];
+                return dWorkspace;
+            }
+
+            const dVectorType &get_x() const { return x; }
+            Index getDim(Index k) const { return dims[k]; }
+            Index getRank(Index k) const { return rank[k]; }
+            Index get_nObj() const { return nObj; }
+            Index get_nVar() const { return nVar; }
+            Index getTotalRank() const { return TotalRank; }
+            Index getFixedVariablesCount() const { return nVarFixed; }
+            const dVectorType &getWorkspace() const { return dWorkspace; }
+            const dMatrixType &get_data() const { return PROBLEM_DATA; }
+            const dMatrixType &get_lexqr()
+            {
+                if (!factor_on_host)
+                {
+                    check(lexls_lse_get_factor(h, FACTOR.data()));
+                    factor_on_host = true;
+                }
+                return FACTOR;
+            }
+            const char *last_kernel() const { return lexls_lse_last_kernel(h); }
+
+            /// lexlse.h:1654-1658
+            void reset()
+            {
+                nVarFixedInit = 0;
+                TotalRank     = 0;
+                x.setZero();
+            }
+
+        private:
+            static void check(int rc)
+            {
+                if (rc != LEXLS_OK) throw Exception(std::string("liblexls_hip: ") + lexls_last_error());
+            }
+            void upload()
+            {
+                const uint32_t nf = nVarFixed;
+                check(lexls_lse_set_fixed(h, nf ? &nf : NULL, fixed_idx.data(), fixed_val.data(), fixed_type.data()));
+                check(lexls_lse_set_ctr_type(h, ctr_type.data()));
+                check(lexls_lse_set_problem_host(h, LOD.data()));
+            }
+
+            lexls_lse_t h;
+            Index nVar, nObj, nCtr, cap, nVarFixed, nVarFixedInit, TotalRank;
+            int device;
+            bool factor_on_host = false;
+            ParametersLexLSE parameters;
+            std::vector<Index> dims, first_row, rank, first_col, fixed_idx;
+            std::vector<double> fixed_val;
+            std::vector<uint8_t> fixed_type, ctr_type;
+            dMatrixType LOD, PROBLEM_DATA, FACTOR;
+            dVectorType x, dWorkspace;
+        };
+    } // namespace internal
+
+    /// public wrapper of the reference (include/lexls/lexls.h:16-68)
+    class LexLSE
+    {
+    public:
+        LexLSE() {}
+        LexLSE(Index nVar_, Index nObj_, Index *ObjDim_)
+        {
+            resize(nVar_, nObj_, ObjDim_);
+            setObjDim(ObjDim_);
+        }
+        void resize(Index nVar_, Index nObj_, Index *ObjDim_) { lexlse.resize(nVar_, nObj_, ObjDim_); }
+        void setObjDim(Index *ObjDim_) { lexlse.setObjDim(ObjDim_); }
+        /// the reference's wrapper exposes no data setter (lexls.h:16-68); this one forwards setData
+        void setData(Index ObjIndex, const dMatrixConstRef &data) { lexlse.setData(ObjIndex, data); }
+        const dVectorType &solve(Index solve_option = 0)
+        {
+            lexlse.factorize();
+            switch (solve_option)
+            {
+            case 0: lexlse.solve(); break;
+            case 1: lexlse.solveLeastNorm_1(); break;
+            case 2: lexlse.solveLeastNorm_2(); break;
+            case 3: lexlse.solveLeastNorm_3(); break;
+            default: break;
+            }
+            return lexlse.get_x();
+        }
+
+    private:
+        internal::LexLSE lexlse;
+    };
+} // namespace LexLS

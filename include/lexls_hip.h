@@ -122,6 +122,27 @@ const char *lexls_lse_last_kernel(lexls_lse_t h);
 /* diagnostics: force_generic != 0 disables the shape-specialised kernels (parity tests run both paths) */
 int lexls_lse_set_kernel_policy(lexls_lse_t h, int force_generic);
 
+/* ---- inequality problems: the reference's LexLSI active-set driver (lexlsi.h), kept on the host -------------
+ * The driver is host C++ (include/lexls/lexlsi.h, same logic as the reference's lexlsi.h/objective.h/workingset.h);
+ * every factorize / solve / ObjectiveSensitivity it issues goes to the HIP kernels above.  Call sequence = the
+ * reference's MEX front end (interfaces/matlab-octave/lexlsi.cpp:527-625).
+ *   h_dims[nObj]; h_types[nObj]: 0 general, 1 simple bounds (objective 0 only, typedefs.h:60-64);
+ *   h_data: objectives back to back, column-major: general dim x (nVar+2) = [A lb ub], simple dim x 2 = [lb ub];
+ *   h_var_index[dims[0]]: 0-based variable indices of a simple-bounds objective (else NULL);
+ *   h_active_guess: sum(dims) ConstraintActivationType bytes or NULL; h_x0: nVar or NULL;
+ *   h_params9: {max_number_of_factorizations, tol_linear_dependence, tol_wrong_sign_lambda, tol_correct_sign_lambda,
+ *               tol_feasibility, cycling_handling_enabled, cycling_max_counter, cycling_relax_step,
+ *               deactivate_first_wrong_sign} or NULL for the defaults of typedefs.h:268-294;
+ *   outputs: h_x[nVar]; h_info6 = {status, iterations, activations, deactivations, factorizations, total_rank};
+ *            h_active[sum(dims)] final working set; h_v[sum(dims)] constraint violations (either may be NULL). */
+int lexls_lsi_solve(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types, const double *h_data,
+                    const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_params9, double *h_x,
+                    int32_t *h_info6, uint8_t *h_active, double *h_v);
+/* the same on a hierarchy file in the reference's .dat format (tools.h:261-453); h_solution receives the file's
+ * `#Solution` block when present (may be NULL).  one_based: simple-bound indices in the file are 1-based. */
+int lexls_lsi_solve_dat(int device, const char *path, int one_based, int use_active_guess, int use_x_guess, double *h_x, int32_t *h_info6,
+                        double *h_solution);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ SYMBOLS = [
     "lexls_lse_get_x", "lexls_lse_get_factor", "lexls_lse_get_hh_scalars", "lexls_lse_get_permutation", "lexls_lse_get_ranks",
     "lexls_lse_get_v", "lexls_lse_get_lambda", "lexls_lse_get_sensitivity", "lexls_lse_get_ctr_type",
     "lexls_lse_device_ptr", "lexls_lse_last_kernel", "lexls_lse_set_kernel_policy",
+    "lexls_lsi_solve", "lexls_lsi_solve_dat",
 ]
 
 ARRAY = dict(x=0, factor=1, hh=2, perm=3, rank=4, first_col=5, total_rank=6, v=7, lam=8, input=9)

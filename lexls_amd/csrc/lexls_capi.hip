@@ -88,6 +88,8 @@ struct lexls_lse_s
 extern "C"
 {
     const char *lexls_last_error(void) { return g_err.c_str(); }
+    /* internal: lets the other translation units of the library report through lexls_last_error() */
+    void lexls_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
     int lexls_version(void) { return 100; }
 
     int lexls_device_count(int *count)

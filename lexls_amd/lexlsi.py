@@ -1,0 +1,71 @@
+"""Inequality problems through the C ABI: the reference's LexLSI active-set driver (kept on the host, C++) over the
+HIP equality solver.  Problem description = list of objectives, highest priority first:
+  general objective        {"A": (m x n), "lb": (m,), "ub": (m,)}          lb <= A x - v <= ub
+  simple bounds (first)    {"var": (m,) 0-based indices, "lb": ..., "ub": ...}
+(the reference's MATLAB front end takes the same fields, interfaces/matlab-octave/lexlsi.cpp:380-445)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+PARAM_KEYS = ["max_number_of_factorizations", "tol_linear_dependence", "tol_wrong_sign_lambda", "tol_correct_sign_lambda",
+              "tol_feasibility", "cycling_handling_enabled", "cycling_max_counter", "cycling_relax_step", "deactivate_first_wrong_sign"]
+PARAM_DEFAULTS = [200, 1e-12, 1e-8, 1e-12, 1e-13, 0, 50, 1e-8, 0]  # typedefs.h:268-294
+INFO_KEYS = ["status", "iterations", "activations", "deactivations", "factorizations", "total_rank"]
+
+
+def pack_params(**kw) -> np.ndarray:
+    vals = list(PARAM_DEFAULTS)
+    for k, v in kw.items():
+        vals[PARAM_KEYS.index(k)] = float(v)
+    return np.array(vals, dtype=np.float64)
+
+
+def flatten(nvar: int, objectives):
+    """-> dims (uint32), types (int32), data (float64, objectives back to back, column-major), var_index (uint32)"""
+    dims, types, chunks, var_index = [], [], [], np.zeros(0, np.uint32)
+    for k, o in enumerate(objectives):
+        lb, ub = np.asarray(o["lb"], float), np.asarray(o["ub"], float)
+        dims.append(lb.size)
+        if "var" in o:
+            if k != 0:
+                raise ValueError("simple bounds are supported only in the first objective")
+            types.append(1)
+            var_index = np.asarray(o["var"], np.uint32)
+            m = np.stack([lb, ub], axis=1)
+        else:
+            types.append(0)
+            m = np.hstack([np.asarray(o["A"], float).reshape(lb.size, nvar), lb[:, None], ub[:, None]])
+        chunks.append(np.asfortranarray(m).ravel(order="F"))
+    data = np.concatenate(chunks) if chunks else np.zeros(0)
+    return np.array(dims, np.uint32), np.array(types, np.int32), np.ascontiguousarray(data), np.ascontiguousarray(var_index)
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def lsi_solve(nvar: int, objectives, active_guess=None, x0=None, device: int = 0, **params):
+    dims, types, data, var_index = flatten(nvar, objectives)
+    total = int(dims.sum())
+    x, info = np.zeros(nvar), np.zeros(6, np.int32)
+    active, v = np.zeros(total, np.uint8), np.zeros(total)
+    guess = None if active_guess is None else np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint8) for g in active_guess]))
+    x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
+    par = pack_params(**params)
+    capi.check(capi.lib().lexls_lsi_solve(
+        C.c_int(device), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32), _p(data, C.c_double),
+        _p(var_index if var_index.size else None, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(par, C.c_double),
+        _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8), _p(v, C.c_double)))
+    cuts = np.cumsum(dims)[:-1]
+    return dict(x=x, info=dict(zip(INFO_KEYS, info.tolist())), active=np.split(active, cuts), v=np.split(v, cuts))
+
+
+def lsi_solve_dat(path: str, nvar: int, one_based=True, use_active_guess=False, use_x_guess=False, device: int = 0):
+    x, sol, info = np.zeros(nvar), np.zeros(nvar), np.zeros(6, np.int32)
+    capi.check(capi.lib().lexls_lsi_solve_dat(C.c_int(device), path.encode(), C.c_int(one_based), C.c_int(use_active_guess), C.c_int(use_x_guess),
+                                              _p(x, C.c_double), _p(info, C.c_int32), _p(sol, C.c_double)))
+    return dict(x=x, solution=sol, info=dict(zip(INFO_KEYS, info.tolist())))

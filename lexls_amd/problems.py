@@ -152,3 +152,29 @@ def algorithmic_bytes(nvar: int, dims, write_factor: bool = False) -> int:
     if write_factor:
         b += 8 * M * (nvar + 1) + 8 * M + 4 * nvar + 8 * len(list(dims))
     return b
+
+
+# --- inequality (LexLSI) problems: BASELINE.md C5 -------------------------------------------------
+
+def lsi_problem(seed: int, nvar: int = 40, dims=(12, 12, 12, 12, 12), simple_bounds: bool = True, perturb: float = 0.0, perturb_seed: int = 0):
+    """Objectives of one LexLSI problem: level 0 = simple bounds -1 <= x_i <= 1 on dims[0] variables, middle levels
+    b - w <= A x <= b + w with w ~ U(0,1), last level equalities A x = b.  `perturb` adds perturb * N(0,1) to every b
+    (the warm-start neighbour of BASELINE.md C5)."""
+    dims = list(dims)
+    objs, stream = [], 0
+    for k, m in enumerate(dims):
+        if k == 0 and simple_bounds:
+            var = np.argsort(uniform(seed, nvar, 1000))[:m].astype(np.uint32)
+            objs.append(dict(var=var, lb=-np.ones(m), ub=np.ones(m)))
+            continue
+        A = normal(seed, m * nvar, stream).reshape(m, nvar)
+        b = normal(seed, m, stream + 1)
+        w = uniform(seed, m, 2000 + k)
+        stream += 2
+        if perturb:
+            b = b + perturb * normal(seed + 7919 * (perturb_seed + 1), m, 3000 + k)
+        if k == len(dims) - 1:
+            objs.append(dict(A=A, lb=b.copy(), ub=b.copy()))
+        else:
+            objs.append(dict(A=A, lb=b - w, ub=b + w))
+    return objs

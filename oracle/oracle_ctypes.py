@@ -96,35 +96,7 @@ def hardware_threads():
     return int(lib().oracle_hardware_threads())
 
 
-_PARAM_KEYS = ["max_number_of_factorizations", "tol_linear_dependence", "tol_wrong_sign_lambda", "tol_correct_sign_lambda",
-               "tol_feasibility", "cycling_handling_enabled", "cycling_max_counter", "cycling_relax_step", "deactivate_first_wrong_sign"]
-_PARAM_DEFAULTS = [200, 1e-12, 1e-8, 1e-12, 1e-13, 0, 50, 1e-8, 0]
-
-
-def pack_params(**kw):
-    vals = list(_PARAM_DEFAULTS)
-    for k, v in kw.items():
-        vals[_PARAM_KEYS.index(k)] = float(v)
-    return np.array(vals, dtype=np.float64)
-
-
-def flatten_lsi(nvar, objectives):
-    """objectives: list of dicts {A (m x n) | var (m,) 0-based, lb, ub}. -> dims, types, data, var_index"""
-    dims, types, chunks, var_index = [], [], [], np.zeros(0, np.uint32)
-    for k, o in enumerate(objectives):
-        lb, ub = np.asarray(o["lb"], float), np.asarray(o["ub"], float)
-        dims.append(lb.size)
-        if "var" in o:
-            assert k == 0
-            types.append(1)
-            var_index = np.asarray(o["var"], np.uint32)
-            m = np.stack([lb, ub], axis=1)
-        else:
-            types.append(0)
-            m = np.hstack([np.asarray(o["A"], float).reshape(lb.size, nvar), lb[:, None], ub[:, None]])
-        chunks.append(np.asfortranarray(m).ravel(order="F"))
-    data = np.concatenate(chunks) if chunks else np.zeros(0)
-    return (np.array(dims, np.uint32), np.array(types, np.int32), np.ascontiguousarray(data), np.ascontiguousarray(var_index))
+from lexls_amd.lexlsi import flatten as flatten_lsi, pack_params  # noqa: E402  (flat problem layout shared with the product binding)
 
 
 def lsi_run(nvar, objectives, active_guess=None, x0=None, **params):

@@ -1,0 +1,71 @@
+"""Inequality problems on the HIP path: the kept-on-host active-set driver (include/lexls/lexlsi.h) over the HIP
+equality solver, through the C ABI (lexls_lsi_solve*), against (a) the reference's own fixture and (b) the same
+driver over the CPU oracle.  Because the equality solver is bit-identical, the whole active-set trajectory must be:
+same working set, same counters, same x (north_star: active-set indices exact, x within 1e-10)."""
+import os
+
+import numpy as np
+import pytest
+
+from lexls_amd import lexlsi, problems as P
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DAT = os.path.join(GOLDEN, "test_01.dat")
+
+
+@pytest.mark.parametrize("use_as,use_x", [(0, 0), (1, 0), (1, 1)])
+def test_reference_fixture_test_01(hip, oracle, use_as, use_x):
+    """BASELINE.json configs[0] (its label is wrong: the file is a 5-level inequality hierarchy with simple bounds)."""
+    d = lexlsi.lsi_solve_dat(DAT, 88, one_based=True, use_active_guess=bool(use_as), use_x_guess=bool(use_x))
+    o = oracle.lsi_run_dat(DAT, True, bool(use_as), bool(use_x))
+    assert d["info"]["status"] == 0
+    assert np.abs(d["x"] - d["solution"]).max() < 1e-9          # the reference's stored answer
+    assert d["info"] == o["info"]                                # same trajectory as the oracle-backed driver
+    np.testing.assert_array_equal(d["x"], o["x"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_lsi_matches_oracle_driver(hip, oracle, seed):
+    n, dims = 20, [6, 5, 5, 6]
+    objs = P.lsi_problem(100 + seed, n, dims)
+    d = lexlsi.lsi_solve(n, objs)
+    o = oracle.lsi_run(n, objs)
+    assert d["info"] == o["info"] and d["info"]["status"] == 0
+    for a, b in zip(d["active"], o["active"]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(d["x"], o["x"])
+    for a, b in zip(d["v"], o["v"]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_warm_start_from_neighbour(hip, oracle):
+    """BASELINE.md C5 pattern: solve, perturb b, re-solve warm-started from the neighbour's active set and x."""
+    n, dims = 40, [12] * 5
+    base = lexlsi.lsi_solve(n, P.lsi_problem(7, n, dims))
+    objs = P.lsi_problem(7, n, dims, perturb=0.05)
+    guess = [np.where(a == 3, 0, a) for a in base["active"]]  # equalities are detected internally
+    cold = lexlsi.lsi_solve(n, objs)
+    warm = lexlsi.lsi_solve(n, objs, active_guess=guess, x0=base["x"])
+    owarm = oracle.lsi_run(n, objs, active_guess=guess, x0=base["x"])
+    assert warm["info"] == owarm["info"]
+    np.testing.assert_array_equal(warm["x"], owarm["x"])
+    assert warm["info"]["status"] == 0 and cold["info"]["status"] == 0
+    assert warm["info"]["factorizations"] <= cold["info"]["factorizations"]
+    np.testing.assert_allclose(warm["x"], cold["x"], atol=1e-8)
+
+
+def test_no_simple_bounds_all_general(hip, oracle):
+    n, dims = 10, [4, 4, 4]
+    objs = P.lsi_problem(55, n, dims, simple_bounds=False)
+    d, o = lexlsi.lsi_solve(n, objs), oracle.lsi_run(n, objs)
+    assert d["info"] == o["info"]
+    np.testing.assert_array_equal(d["x"], o["x"])
+
+
+def test_lsi_error_behaviour(hip):
+    n = 4
+    bad = [dict(A=np.eye(2, n), lb=[1.0, 0.0], ub=[0.0, 1.0])]  # lb > ub -> the reference throws (lexlsi.h:430)
+    with pytest.raises(Exception, match="Lower bound is greater than upper bound"):
+        lexlsi.lsi_solve(n, bad)
