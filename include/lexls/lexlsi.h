@@ -433,7 +433,240 @@ namespace LexLS
                 return operation;
             }
 
+            // -------------------------------------------------------------------------------------
+            // Resumable form of solve() for LOCK-STEP BATCHES (config 5: many LexLSI instances whose equality
+            // solves are served by ONE batched device call per round).  Same statements as phase1() +
+            // verifyWorkingSet() above, cut at the points where the equality solver is used:
+            //     begin();  while (!finished()) { <serve need()> ; advance(); }
+            // advance() itself calls lexlse.factorize()/solve()/ObjectiveSensitivity(); an LSE whose results
+            // were pre-computed by a batch call implements them as look-ups (lexls_amd/csrc/lexls_lsi_capi.hip),
+            // a stand-alone LSE computes on the spot, so solve_resumable() == solve() for any LSE.
+            // -------------------------------------------------------------------------------------
+            enum DeviceNeed
+            {
+                NEED_NOTHING = 0,
+                NEED_FACTORIZE_SOLVE,
+                NEED_SENSITIVITY
+            };
+
+            /// what the next advance() will ask the equality solver for (and, for sensitivity, at which LexLSE level)
+            DeviceNeed need() const { return pending; }
+            Index needLevel() const { return sens_level; }
+            bool finished() const { return pc == PC_DONE; }
+
+            void begin()
+            {
+                if (parameters.use_phase1_v0)
+                {
+                    phase1_v0();
+                    iteration_prepare();
+                    return;
+                }
+                hot_start_related_tests();
+                if (!x_guess_is_specified)
+                {
+                    formLexLSE();
+                    pc      = PC_P1_SOLVED_NO_GUESS;
+                    pending = NEED_FACTORIZE_SOLVE;
+                }
+                else
+                {
+                    phase1_objectives_then_maybe_solve();
+                }
+            }
+
+            void advance()
+            {
+                switch (pc)
+                {
+                case PC_P1_SOLVED_NO_GUESS:
+                    lexlse.factorize();
+                    lexlse.solve();
+                    lexlse_rank = getTotalRank();
+                    x           = lexlse.get_x();
+                    phase1_objectives_then_maybe_solve();
+                    break;
+                case PC_P1_SOLVED_WITH_GUESS:
+                {
+                    lexlse.factorize();
+                    lexlse.solve();
+                    lexlse_rank           = getTotalRank();
+                    const dVectorType &xs = lexlse.get_x();
+                    for (Index i = 0; i < nVar; i++) dx(i) = xs(i) - x(i);
+                    phase1_finish();
+                    break;
+                }
+                case PC_IT_SOLVED:
+                    lexlse.factorize();
+                    lexlse.solve();
+                    lexlse_rank = getTotalRank();
+                    formStep();
+                    nFactorizations++;
+                    iteration_blocking();
+                    break;
+                case PC_IT_SENSITIVITY:
+                {
+                    Index CtrIndex2Remove = 0;
+                    int ObjIndex2Remove   = 0;
+                    RealScalar lambda_wrong_sign;
+                    const bool found = lexlse.ObjectiveSensitivity(sens_level, CtrIndex2Remove, ObjIndex2Remove, parameters.tol_wrong_sign_lambda,
+                                                                   parameters.tol_correct_sign_lambda, lambda_wrong_sign);
+                    if (found)
+                    {
+                        const Index o = static_cast<Index>(ObjIndex2Remove + static_cast<int>(nObjOffset));
+                        if (parameters.log_working_set_enabled)
+                            working_set_log.push_back(WorkingSetLogEntry(o, objectives[o].getActiveCtrIndex(CtrIndex2Remove), CTR_INACTIVE, lambda_wrong_sign, lexlse_rank));
+                        it_constraint.set(o, objectives[o].getActiveCtrIndex(CtrIndex2Remove), objectives[o].getActiveCtrType(CtrIndex2Remove));
+                        it_operation = OPERATION_REMOVE;
+                        deactivate(o, CtrIndex2Remove);
+                        iteration_finish();
+                    }
+                    else if (sens_level + 1 < nObj - nObjOffset)
+                    {
+                        sens_level++;
+                        pending = NEED_SENSITIVITY;
+                    }
+                    else
+                    {
+                        status = PROBLEM_SOLVED;
+                        iteration_finish();
+                    }
+                    break;
+                }
+                default:
+                    throw Exception("LexLSI::advance() called in a state without pending work");
+                }
+            }
+
+            /// solve() expressed through the resumable form (used to check that both forms agree)
+            TerminationStatus solve_resumable()
+            {
+                if (parameters.deactivate_first_wrong_sign) throw Exception("solve_resumable: deactivate_first_wrong_sign is not supported");
+                begin();
+                while (!finished()) advance();
+                return status;
+            }
+
         private:
+            enum ProgramCounter
+            {
+                PC_IDLE = 0,
+                PC_P1_SOLVED_NO_GUESS,
+                PC_P1_SOLVED_WITH_GUESS,
+                PC_IT_SOLVED,
+                PC_IT_SENSITIVITY,
+                PC_DONE
+            };
+
+            void phase1_objectives_then_maybe_solve()
+            {
+                for (Index k = 0; k < nObj; k++)
+                    objectives[k].phase1(x, x_guess_is_specified, parameters.modify_type_active_enabled, parameters.modify_type_inactive_enabled,
+                                         parameters.modify_x_guess_enabled, parameters.set_min_init_ctr_violation, parameters.tol_feasibility);
+                if (x_guess_is_specified)
+                {
+                    formLexLSE();
+                    pc      = PC_P1_SOLVED_WITH_GUESS;
+                    pending = NEED_FACTORIZE_SOLVE;
+                }
+                else
+                {
+                    phase1_finish();
+                }
+            }
+
+            void phase1_finish()
+            {
+                for (Index k = 0; k < nObj; k++) objectives[k].formStep(dx);
+                nFactorizations++;
+                iteration_prepare();
+            }
+
+            /// head of verifyWorkingSet() (lexlsi.h:1161-1179)
+            void iteration_prepare()
+            {
+                it_operation = OPERATION_UNDEFINED;
+                it_constraint.set(0, 0, CTR_INACTIVE);
+                it_normal = true;
+                if (nIterations != 0)
+                {
+                    formLexLSE();
+                    pc      = PC_IT_SOLVED;
+                    pending = NEED_FACTORIZE_SOLVE;
+                }
+                else
+                {
+                    if (parameters.use_phase1_v0) it_normal = false;
+                    iteration_blocking();
+                }
+            }
+
+            /// lexlsi.h:1181-1232 up to the point where multipliers are needed
+            void iteration_blocking()
+            {
+                Index o = 0, c = 0;
+                ConstraintActivationType t = CTR_INACTIVE;
+                if (checkBlockingConstraints(o, c, t, it_alpha))
+                {
+                    it_constraint.set(o, c, t);
+                    if (parameters.log_working_set_enabled) working_set_log.push_back(WorkingSetLogEntry(o, c, t, it_alpha, lexlse_rank));
+                    it_operation = OPERATION_ADD;
+                    activate(o, c, t);
+                    iteration_finish();
+                }
+                else if (it_normal && nObj - nObjOffset > 0)
+                {
+                    sens_level = 0;
+                    pc         = PC_IT_SENSITIVITY;
+                    pending    = NEED_SENSITIVITY;
+                }
+                else
+                {
+                    if (it_normal) status = PROBLEM_SOLVED;
+                    iteration_finish();
+                }
+            }
+
+            /// tail of verifyWorkingSet() (lexlsi.h:1234-1264) + the termination test of solve() (:232-243)
+            void iteration_finish()
+            {
+                step_length = (it_operation == OPERATION_ADD) ? it_alpha : -1;
+                if (it_alpha > 0)
+                {
+                    for (Index i = 0; i < nVar; i++) x(i) += it_alpha * dx(i);
+                    for (Index k = 0; k < nObj; k++) objectives[k].step(it_alpha);
+                }
+                if (parameters.cycling_handling_enabled && it_operation != OPERATION_UNDEFINED)
+                {
+                    bool cycling_detected;
+                    status = cycling_handler.update(it_operation, it_constraint, objectives, cycling_detected);
+                    if (parameters.log_working_set_enabled) working_set_log.back().cycling_detected = cycling_detected;
+                }
+                nIterations++;
+                pending = NEED_NOTHING;
+                if (status == PROBLEM_SOLVED || status == PROBLEM_SOLVED_CYCLING_HANDLING)
+                {
+                    pc = PC_DONE;
+                }
+                else if (nFactorizations >= parameters.max_number_of_factorizations)
+                {
+                    status = MAX_NUMBER_OF_FACTORIZATIONS_EXCEEDED;
+                    pc     = PC_DONE;
+                }
+                else
+                {
+                    iteration_prepare();
+                }
+            }
+
+            ProgramCounter pc      = PC_IDLE;
+            DeviceNeed pending     = NEED_NOTHING;
+            Index sens_level       = 0;
+            OperationType it_operation = OPERATION_UNDEFINED;
+            ConstraintIdentifier it_constraint;
+            RealScalar it_alpha = 1;
+            bool it_normal      = true;
+
             /// lexlsi.h:758-793
             void hot_start_related_tests()
             {

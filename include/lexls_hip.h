@@ -79,6 +79,9 @@ int lexls_lse_set_obj_dim(lexls_lse_t h, const uint32_t *h_dims, int per_problem
 int lexls_lse_set_fixed(lexls_lse_t h, const uint32_t *h_nfixed, const uint32_t *h_index, const double *h_value, const uint8_t *h_type);
 /* replaces setCtrType (lexlse.h:1548): batch x cap ConstraintActivationType bytes, row order of LOD */
 int lexls_lse_set_ctr_type(lexls_lse_t h, const uint8_t *h_types);
+/* lock-step batches (batched LexLSI): problems whose flag is non-zero are left untouched by the next
+ * factorize / factorize_solve calls (their previous results stay valid).  NULL clears the mask. */
+int lexls_lse_set_skip(lexls_lse_t h, const uint8_t *h_skip);
 /* replaces setProblem / setData (lexlse.h:1511-1530): copies batch x cap x (nVar+1) doubles H2D */
 int lexls_lse_set_problem_host(lexls_lse_t h, const double *h_lod);
 /* zero-copy variant: the caller's device buffer becomes the (read-only) input of later factorizations */
@@ -138,6 +141,14 @@ int lexls_lse_set_kernel_policy(lexls_lse_t h, int force_generic);
 int lexls_lsi_solve(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types, const double *h_data,
                     const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_params9, double *h_x,
                     int32_t *h_info6, uint8_t *h_active, double *h_v);
+/* A batch of LexLSI problems of ONE structure (same nVar, dims, types; different data), advanced in LOCK STEP: every
+ * active-set round issues one batched factorize+solve and one batched ObjectiveSensitivity per LexLSE level for all the
+ * instances that need it (BASELINE configs[4]).  Arrays are the per-problem arrays of lexls_lsi_solve, back to back
+ * (h_var_index: batch x dims[0]; h_active_guess / h_x0 may be NULL); h_rounds2 (may be NULL) receives
+ * {factorize+solve rounds, sensitivity rounds} actually issued to the device. */
+int lexls_lsi_batch_solve(int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types,
+                          const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
+                          const double *h_params9, double *h_x, int32_t *h_info6, uint8_t *h_active, double *h_v, int32_t *h_rounds2);
 /* the same on a hierarchy file in the reference's .dat format (tools.h:261-453); h_solution receives the file's
  * `#Solution` block when present (may be NULL).  one_based: simple-bound indices in the file are 1-based. */
 int lexls_lsi_solve_dat(int device, const char *path, int one_based, int use_active_guess, int use_x_guess, double *h_x, int32_t *h_info6,

@@ -16,13 +16,13 @@ SYMBOLS = [
     "lexls_last_error", "lexls_version", "lexls_device_count",
     "lexls_lse_create", "lexls_lse_destroy", "lexls_lse_set_stream", "lexls_lse_synchronize",
     "lexls_lse_set_tolerance", "lexls_lse_set_obj_dim", "lexls_lse_set_fixed", "lexls_lse_set_ctr_type",
-    "lexls_lse_set_problem_host", "lexls_lse_set_problem_device",
+    "lexls_lse_set_problem_host", "lexls_lse_set_problem_device", "lexls_lse_set_skip",
     "lexls_lse_factorize", "lexls_lse_solve", "lexls_lse_factorize_solve", "lexls_lse_solve_least_norm",
     "lexls_lse_residual", "lexls_lse_sensitivity",
     "lexls_lse_get_x", "lexls_lse_get_factor", "lexls_lse_get_hh_scalars", "lexls_lse_get_permutation", "lexls_lse_get_ranks",
     "lexls_lse_get_v", "lexls_lse_get_lambda", "lexls_lse_get_sensitivity", "lexls_lse_get_ctr_type",
     "lexls_lse_device_ptr", "lexls_lse_last_kernel", "lexls_lse_set_kernel_policy",
-    "lexls_lsi_solve", "lexls_lsi_solve_dat",
+    "lexls_lsi_solve", "lexls_lsi_solve_dat", "lexls_lsi_batch_solve",
 ]
 
 ARRAY = dict(x=0, factor=1, hh=2, perm=3, rank=4, first_col=5, total_rank=6, v=7, lam=8, input=9)

@@ -49,7 +49,8 @@ struct lexls_lse_s
     const double *d_in;
     double *d_fac, *d_x, *d_hh, *d_v, *d_lambda, *d_maxabs, *d_scratch, *d_fixed_val;
     uint32_t *d_perm, *d_rank, *d_fcol, *d_totalrank, *d_dims, *d_nfixed, *d_fixed_idx;
-    uint8_t *d_fixed_type, *d_ctr_type;
+    uint8_t *d_fixed_type, *d_ctr_type, *d_skip;
+    bool has_skip;
     int32_t *d_sens, *d_objidx;
 
     LseArgs args() const
@@ -80,6 +81,7 @@ struct lexls_lse_s
         a.sens       = d_sens;
         a.maxabs     = d_maxabs;
         a.scratch    = d_scratch;
+        a.skip       = has_skip ? d_skip : nullptr;
         return a;
     }
     size_t problem_elems() const { return (size_t)cap * (nVar + 1); }
@@ -159,6 +161,7 @@ extern "C"
         alloc((void **)&h->d_ctr_type, B * cap);
         alloc((void **)&h->d_sens, 4 * B * 3);
         alloc((void **)&h->d_objidx, 4 * B);
+        alloc((void **)&h->d_skip, B);
         if (e == hipSuccess) e = hipMemset(h->d_ctr_type, 0, B * cap);
         if (e == hipSuccess) e = hipMemset(h->d_fixed_type, 0, B * n);
         if (e == hipSuccess) e = hipMemset(h->d_nfixed, 0, 4 * B);
@@ -178,7 +181,7 @@ extern "C"
         (void)hipSetDevice(h->device);
         void *ptrs[] = {h->d_in_owned, h->d_fac,     h->d_x,      h->d_hh,        h->d_v,        h->d_lambda,     h->d_maxabs,
                         h->d_scratch,  h->d_fixed_val, h->d_perm,   h->d_rank,      h->d_fcol,     h->d_totalrank,  h->d_dims,
-                        h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx};
+                        h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx,      h->d_skip};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         delete h;
@@ -275,6 +278,21 @@ extern "C"
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipMemcpyAsync(h->d_ctr_type, h_types, (size_t)h->batch * h->cap, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_skip(lexls_lse_t h, const uint8_t *h_skip)
+    {
+        CHECK_HANDLE(h);
+        if (!h_skip)
+        {
+            h->has_skip = false;
+            return LEXLS_OK;
+        }
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpyAsync(h->d_skip, h_skip, (size_t)h->batch, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->has_skip = true;
         return LEXLS_OK;
     }
 

@@ -39,6 +39,7 @@ namespace lexls
         double *lambda;                  // batch x (nVar + cap)
         int32_t *sens;                   // batch x 3
         double *maxabs;                  // batch
-        double *scratch;                 // batch x nVar x (nVar+1) (least-norm only, may be NULL)
+        double *scratch;                 // batch x 2 x nVar x nVar (least-norm only, may be NULL)
+        const uint8_t *skip;             // batch flags: non-zero = leave this problem untouched (NULL: none); lock-step LSI batches
     };
 } // namespace lexls

@@ -4,6 +4,8 @@
 #include <lexls/lexls.h>
 #include <lexls/lsi_runner.h>
 
+#include <memory>
+
 using namespace LexLS;
 
 namespace
@@ -28,9 +30,279 @@ namespace
     }
 } // namespace
 
+// ---------------------------------------------------------------------------------------------------
+// Lock-step batch: B driver instances share ONE batched device handle.  SlotLSE is the equality-solver
+// facade each instance sees: its setters stage the instance's problem in the batch's host arrays, its
+// factorize()/solve()/ObjectiveSensitivity() return what the batch call of this round already computed.
+// ---------------------------------------------------------------------------------------------------
+namespace
+{
+    void hip_check(int rc)
+    {
+        if (rc != LEXLS_OK) throw Exception(std::string("liblexls_hip: ") + lexls_last_error());
+    }
+
+    struct BatchCtx
+    {
+        lexls_lse_t h = NULL;
+        uint32_t B = 0, n = 0, nObjL = 0, cap = 0;
+        size_t pstride = 0;
+        std::vector<uint32_t> maxdim, dims, nfixed, fixed_idx, rank, totalrank;
+        std::vector<double> fixed_val, lod, x, maxabs;
+        std::vector<uint8_t> fixed_type, ctr_type, skip;
+        std::vector<int32_t> sens, objidx;
+        int rounds_fs = 0, rounds_sens = 0;
+
+        void create(int device, uint32_t B_, uint32_t n_, uint32_t nObjL_, const uint32_t *maxdim_)
+        {
+            B     = B_;
+            n     = n_;
+            nObjL = nObjL_;
+            maxdim.assign(maxdim_, maxdim_ + nObjL);
+            cap = 0;
+            for (uint32_t k = 0; k < nObjL; k++) cap += maxdim[k];
+            pstride = (size_t)cap * (n + 1);
+            hip_check(lexls_lse_create(&h, device, B, n, nObjL, maxdim.data()));
+            dims.assign((size_t)B * nObjL, 0);
+            nfixed.assign(B, 0);
+            fixed_idx.assign((size_t)B * n, 0);
+            fixed_val.assign((size_t)B * n, 0.0);
+            fixed_type.assign((size_t)B * n, CTR_ACTIVE_UB);
+            ctr_type.assign((size_t)B * cap, CTR_INACTIVE);
+            lod.assign((size_t)B * pstride, 0.0);
+            x.assign((size_t)B * n, 0.0);
+            rank.assign((size_t)B * nObjL, 0);
+            totalrank.assign(B, 0);
+            skip.assign(B, 0);
+            sens.assign((size_t)B * 3, 0);
+            objidx.assign(B, -1);
+            maxabs.assign(B, 0.0);
+        }
+        ~BatchCtx()
+        {
+            if (h) lexls_lse_destroy(h);
+        }
+
+        /// one batched factorize+solve for every instance with skip == 0
+        void factorize_solve()
+        {
+            hip_check(lexls_lse_set_obj_dim(h, dims.data(), 1));
+            hip_check(lexls_lse_set_fixed(h, nfixed.data(), fixed_idx.data(), fixed_val.data(), fixed_type.data()));
+            hip_check(lexls_lse_set_ctr_type(h, ctr_type.data()));
+            hip_check(lexls_lse_set_problem_host(h, lod.data()));
+            hip_check(lexls_lse_set_skip(h, skip.data()));
+            hip_check(lexls_lse_factorize_solve(h, 1));
+            std::vector<double> xn((size_t)B * n);
+            std::vector<uint32_t> tr(B), rk((size_t)B * nObjL);
+            hip_check(lexls_lse_get_x(h, xn.data()));
+            hip_check(lexls_lse_get_ranks(h, rk.data(), NULL, tr.data()));
+            for (uint32_t b = 0; b < B; b++)
+                if (!skip[b])
+                {
+                    std::copy(xn.begin() + (size_t)b * n, xn.begin() + (size_t)(b + 1) * n, x.begin() + (size_t)b * n);
+                    totalrank[b] = tr[b];
+                }
+            rounds_fs++;
+        }
+
+        /// one batched ObjectiveSensitivity: objidx[b] < 0 skips instance b
+        void sensitivity(double tolW, double tolC)
+        {
+            hip_check(lexls_lse_sensitivity(h, objidx.data(), 0, tolW, tolC));
+            hip_check(lexls_lse_get_sensitivity(h, sens.data(), maxabs.data()));
+            rounds_sens++;
+        }
+    };
+
+    class SlotLSE
+    {
+    public:
+        SlotLSE() : c(NULL), b(0), nVarFixed(0), nVarFixedInit(0) {}
+        void bind(BatchCtx *ctx, uint32_t slot)
+        {
+            c = ctx;
+            b = slot;
+            x.resize(c->n);
+            first_row.assign(c->nObjL, 0);
+        }
+        void resize(Index nVar_, Index nObj_, Index *maxObjDim)
+        {
+            if (!c) throw Exception("SlotLSE: not bound to a batch");
+            if (nVar_ != c->n || nObj_ != c->nObjL) throw Exception("SlotLSE: shape differs from the batch");
+            for (Index k = 0; k < nObj_; k++)
+                if (maxObjDim[k] != c->maxdim[k]) throw Exception("SlotLSE: capacity differs from the batch");
+        }
+        void setParameters(const ParametersLexLSE &p)
+        {
+            if (p.regularization_type != REGULARIZATION_NONE) throw Exception("lexls_hip: only REGULARIZATION_NONE is implemented on the device path");
+            tol = p.tol_linear_dependence;
+            if (c) hip_check(lexls_lse_set_tolerance(c->h, tol));
+        }
+        void setRegularizationFactor(Index, RealScalar) {}
+        void setObjDim(Index *ObjDim_)
+        {
+            Index r = 0;
+            for (Index k = 0; k < c->nObjL; k++)
+            {
+                c->dims[(size_t)b * c->nObjL + k] = ObjDim_[k];
+                first_row[k]                      = r;
+                r += ObjDim_[k];
+            }
+            nVarFixedInit = 0;
+        }
+        void setFixedVariablesCount(Index nf)
+        {
+            if (nf > c->n) throw Exception("Cannot fix more than nVar variables");
+            nVarFixed    = nf;
+            c->nfixed[b] = nf;
+        }
+        void fixVariable(Index VarIndex, RealScalar VarValue, ConstraintActivationType type = CTR_ACTIVE_UB)
+        {
+            const size_t o   = (size_t)b * c->n + nVarFixedInit++;
+            c->fixed_idx[o]  = VarIndex;
+            c->fixed_val[o]  = VarValue;
+            c->fixed_type[o] = static_cast<uint8_t>(type);
+        }
+        void setCtrType(Index ObjIndex, Index CtrIndex, ConstraintActivationType type) { c->ctr_type[(size_t)b * c->cap + first_row[ObjIndex] + CtrIndex] = static_cast<uint8_t>(type); }
+        void setCtrStrided(Index CtrIndex, const RealScalar *row, Index stride, RealScalar rhs)
+        {
+            double *L = c->lod.data() + (size_t)b * c->pstride;
+            for (Index j = 0; j < c->n; j++) L[CtrIndex + (size_t)j * c->cap] = row[(size_t)j * stride];
+            L[CtrIndex + (size_t)c->n * c->cap] = rhs;
+        }
+        // served by the batch call of this round
+        void factorize() {}
+        void solve()
+        {
+            for (Index i = 0; i < c->n; i++) x(i) = c->x[(size_t)b * c->n + i];
+        }
+        bool ObjectiveSensitivity(Index, Index &CtrIndex2Remove, int &ObjIndex2Remove, RealScalar, RealScalar, RealScalar &maxAbsValue)
+        {
+            const int32_t *s3 = &c->sens[(size_t)b * 3];
+            maxAbsValue       = c->maxabs[b];
+            if (s3[0])
+            {
+                CtrIndex2Remove = static_cast<Index>(s3[1]);
+                ObjIndex2Remove = s3[2];
+            }
+            return s3[0] != 0;
+        }
+        void ObjectiveSensitivity(Index, RealScalar, RealScalar, std::vector<ConstraintInfo> &) { throw Exception("not available in lock-step batches"); }
+        const dVectorType &get_x() const { return x; }
+        Index getTotalRank() const { return c->totalrank[b]; }
+        Index getDim(Index k) const { return c->dims[(size_t)b * c->nObjL + k]; }
+        Index getFixedVariablesCount() const { return nVarFixed; }
+        const dVectorType &getWorkspace() const { return x; }
+        const dMatrixType &get_lexqr() { throw Exception("not available in lock-step batches"); }
+        const dMatrixType &get_data() { throw Exception("not available in lock-step batches"); }
+
+    private:
+        BatchCtx *c;
+        uint32_t b;
+        Index nVarFixed, nVarFixedInit;
+        double tol = 1e-12;
+        std::vector<Index> first_row;
+        dVectorType x;
+    };
+
+    typedef internal::LexLSI_T<SlotLSE> SlotLSI;
+} // namespace
+
 extern "C"
 {
     void lexls_internal_set_error(const char *msg);
+
+    int lexls_lsi_batch_solve(int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types,
+                              const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
+                              const double *h_params9, double *h_x, int32_t *h_info6, uint8_t *h_active, double *h_v, int32_t *h_rounds2)
+    {
+        try
+        {
+            if (batch == 0 || nObj == 0) throw Exception("lexls_lsi_batch_solve: empty batch");
+            const ParametersLexLSI par = unpack(h_params9);
+            if (par.deactivate_first_wrong_sign) throw Exception("lexls_lsi_batch_solve: deactivate_first_wrong_sign has no device path");
+            const uint32_t off = (h_types[0] == 1) ? 1 : 0;
+            if (nObj - off == 0) throw Exception("Problems consisting of one level of simple bounds are not supported."); // lexlsi.cpp:417
+            size_t per_data = 0, total = 0;
+            for (uint32_t k = 0; k < nObj; k++)
+            {
+                per_data += (size_t)h_dims[k] * (h_types[k] == 1 ? 2 : nVar + 2);
+                total += h_dims[k];
+            }
+            BatchCtx ctx;
+            ctx.create(device, batch, nVar, nObj - off, h_dims + off);
+
+            std::vector<std::unique_ptr<SlotLSI>> lsi(batch);
+            std::vector<runner::LsiProblem> prob(batch);
+            for (uint32_t b = 0; b < batch; b++)
+            {
+                lsi[b].reset(new SlotLSI());
+                lsi[b]->getLexLSE().bind(&ctx, b);
+                prob[b] = {nVar,
+                           nObj,
+                           h_dims,
+                           h_types,
+                           h_data + (size_t)b * per_data,
+                           h_var_index ? h_var_index + (size_t)b * h_dims[0] : NULL,
+                           h_active_guess ? h_active_guess + (size_t)b * total : NULL,
+                           h_x0 ? h_x0 + (size_t)b * nVar : NULL};
+                runner::setup(*lsi[b], prob[b], par);
+                lsi[b]->begin();
+            }
+
+            // lock-step rounds: serve every pending factorize+solve in one call, every pending sensitivity in one call
+            while (true)
+            {
+                bool any_fs = false, any_sens = false, any_alive = false;
+                for (uint32_t b = 0; b < batch; b++)
+                {
+                    const bool fs   = !lsi[b]->finished() && lsi[b]->need() == SlotLSI::NEED_FACTORIZE_SOLVE;
+                    ctx.skip[b]     = fs ? 0 : 1;
+                    any_fs          = any_fs || fs;
+                    any_alive       = any_alive || !lsi[b]->finished();
+                }
+                if (!any_alive) break;
+                if (any_fs)
+                {
+                    ctx.factorize_solve();
+                    for (uint32_t b = 0; b < batch; b++)
+                        if (!ctx.skip[b]) lsi[b]->advance();
+                }
+                for (uint32_t b = 0; b < batch; b++)
+                {
+                    const bool se = !lsi[b]->finished() && lsi[b]->need() == SlotLSI::NEED_SENSITIVITY;
+                    ctx.objidx[b] = se ? static_cast<int32_t>(lsi[b]->needLevel()) : -1;
+                    any_sens      = any_sens || se;
+                }
+                if (any_sens)
+                {
+                    ctx.sensitivity(par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
+                    for (uint32_t b = 0; b < batch; b++)
+                        if (ctx.objidx[b] >= 0) lsi[b]->advance();
+                }
+                if (!any_fs && !any_sens) throw Exception("lexls_lsi_batch_solve: an instance is alive but requests nothing");
+            }
+
+            for (uint32_t b = 0; b < batch; b++)
+            {
+                runner::LsiInfo info;
+                runner::collect(*lsi[b], prob[b], h_x + (size_t)b * nVar, &info, h_active ? h_active + (size_t)b * total : NULL,
+                                h_v ? h_v + (size_t)b * total : NULL);
+                if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
+            }
+            if (h_rounds2)
+            {
+                h_rounds2[0] = ctx.rounds_fs;
+                h_rounds2[1] = ctx.rounds_sens;
+            }
+            return LEXLS_OK;
+        }
+        catch (const std::exception &e)
+        {
+            lexls_internal_set_error(e.what());
+            return LEXLS_ERR_INVALID;
+        }
+    }
 
     int lexls_lsi_solve(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types, const double *h_data,
                         const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_params9, double *h_x,

@@ -107,6 +107,7 @@ namespace lexls
             const uint32_t b = blockIdx.x, tid = threadIdx.x;
             const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
             const size_t pstride = (size_t)cap * (n + 1);
+            if (a.skip && a.skip[b]) return; // uniform per workgroup
 
             // ---- LDS carve-up (doubles first) ----
             double *W;

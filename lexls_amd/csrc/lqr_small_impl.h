@@ -154,6 +154,7 @@ namespace lexls
             const int cap        = (int)a.cap;
             const int nObj       = (int)a.nObj;
             const size_t pstride = (size_t)cap * (n + 1);
+            if (a.skip && a.skip[b]) return; // uniform per wave
 
             // ---- LDS carve-up ----
             double *X        = smem;                  // NC*MD : level transposition scratch

@@ -69,3 +69,29 @@ def lsi_solve_dat(path: str, nvar: int, one_based=True, use_active_guess=False, 
     capi.check(capi.lib().lexls_lsi_solve_dat(C.c_int(device), path.encode(), C.c_int(one_based), C.c_int(use_active_guess), C.c_int(use_x_guess),
                                               _p(x, C.c_double), _p(info, C.c_int32), _p(sol, C.c_double)))
     return dict(x=x, solution=sol, info=dict(zip(INFO_KEYS, info.tolist())))
+
+
+def lsi_batch_solve(nvar: int, problems, active_guess=None, x0=None, device: int = 0, **params):
+    """Lock-step batch of LexLSI problems of one structure (BASELINE configs[4]).  `problems`: list of objective lists
+    (same dims / types); `active_guess`: per problem list of per-objective flag arrays, or None; `x0`: (batch, nvar) or None."""
+    flat = [flatten(nvar, objs) for objs in problems]
+    dims, types = flat[0][0], flat[0][1]
+    for f in flat:
+        if not (np.array_equal(f[0], dims) and np.array_equal(f[1], types)):
+            raise ValueError("all problems of a batch must share dims and objective types")
+    batch, total = len(problems), int(dims.sum())
+    data = np.ascontiguousarray(np.stack([f[2] for f in flat]))
+    var_index = np.ascontiguousarray(np.stack([f[3] for f in flat])) if flat[0][3].size else None
+    guess = None
+    if active_guess is not None:
+        guess = np.ascontiguousarray(np.stack([np.concatenate([np.asarray(g, np.uint8) for g in ag]) for ag in active_guess]))
+    x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
+    x, info = np.zeros((batch, nvar)), np.zeros((batch, 6), np.int32)
+    active, v, rounds = np.zeros((batch, total), np.uint8), np.zeros((batch, total)), np.zeros(2, np.int32)
+    par = pack_params(**params)
+    capi.check(capi.lib().lexls_lsi_batch_solve(
+        C.c_int(device), C.c_uint32(batch), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32), _p(data, C.c_double),
+        _p(var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(par, C.c_double), _p(x, C.c_double), _p(info, C.c_int32),
+        _p(active, C.c_uint8), _p(v, C.c_double), _p(rounds, C.c_int32)))
+    return dict(x=x, info=[dict(zip(INFO_KEYS, row.tolist())) for row in info], active=active, v=v,
+                rounds=dict(factorize_solve=int(rounds[0]), sensitivity=int(rounds[1])), dims=dims)

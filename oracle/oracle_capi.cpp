@@ -185,7 +185,7 @@ extern "C"
     int oracle_hardware_threads() { return static_cast<int>(std::thread::hardware_concurrency()); }
 
     /// LexLSI on flat arrays (layout: include/lexls/lsi_runner.h).  params: [max_fact, tol_lin_dep, tol_wrong, tol_correct, tol_feas,
-    /// cycling(0/1), cycling_max, cycling_relax, deactivate_first_wrong_sign(0/1)] or NULL for defaults.
+    /// cycling(0/1), cycling_max, cycling_relax, deactivate_first_wrong_sign(0/1), use_resumable_form(0/1)] or NULL for defaults.
     int oracle_lsi_run(uint32_t nVar, uint32_t nObj, const uint32_t *dims, const int32_t *types, const double *data, const uint32_t *var_index,
                        const uint8_t *active_guess, const double *x0, const double *params, double *x_out, int32_t *info6, uint8_t *active_out, double *v_out)
     {
@@ -206,7 +206,17 @@ extern "C"
                 par.deactivate_first_wrong_sign  = params[8] != 0;
             }
             runner::LsiInfo info;
-            runner::solve<OLSI>(p, par, x_out, &info, active_out, v_out);
+            if (params && params[9] != 0) // the resumable form of the driver (what lock-step batches use)
+            {
+                OLSI lsi;
+                runner::setup(lsi, p, par);
+                lsi.solve_resumable();
+                runner::collect(lsi, p, x_out, &info, active_out, v_out);
+            }
+            else
+            {
+                runner::solve<OLSI>(p, par, x_out, &info, active_out, v_out);
+            }
             if (info6) std::memcpy(info6, &info, sizeof(info));
             return 0;
         }

@@ -108,7 +108,8 @@ def lsi_run(nvar, objectives, active_guess=None, x0=None, **params):
     v = np.zeros(total)
     guess = None if active_guess is None else np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint8) for g in active_guess]))
     x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
-    par = pack_params(**params)
+    resumable = float(bool(params.pop("resumable", False)))
+    par = np.append(pack_params(**params), resumable)
     rc = lib().oracle_lsi_run(C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, _u32p), _p(types, _i32p), _p(data, _dp),
                               _p(var_index if var_index.size else None, _u32p), _p(guess, _u8p), _p(x0a, _dp), _p(par, _dp),
                               _p(x, _dp), _p(info, _i32p), _p(active, _u8p), _p(v, _dp))

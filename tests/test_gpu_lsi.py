@@ -69,3 +69,32 @@ def test_lsi_error_behaviour(hip):
     bad = [dict(A=np.eye(2, n), lb=[1.0, 0.0], ub=[0.0, 1.0])]  # lb > ub -> the reference throws (lexlsi.h:430)
     with pytest.raises(Exception, match="Lower bound is greater than upper bound"):
         lexlsi.lsi_solve(n, bad)
+
+
+def test_lock_step_batch_equals_individual_solves(hip, oracle):
+    """BASELINE configs[4] in small: one batched device call per active-set round for all instances; every instance must
+    end exactly where its stand-alone (oracle-backed) solve ends."""
+    n, dims, batch = 20, [6, 5, 5, 6], 24
+    problems = [P.lsi_problem(500 + b, n, dims) for b in range(batch)]
+    r = lexlsi.lsi_batch_solve(n, problems)
+    iters = []
+    for b in range(batch):
+        o = oracle.lsi_run(n, problems[b])
+        assert r["info"][b] == o["info"], b
+        np.testing.assert_array_equal(r["x"][b], o["x"])
+        np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
+        iters.append(o["info"]["factorizations"])
+    assert r["rounds"]["factorize_solve"] == max(iters)  # lock step: as many device rounds as the slowest instance needs
+
+
+def test_lock_step_batch_warm_started(hip, oracle):
+    n, dims, batch = 40, [12] * 5, 8
+    base = [oracle.lsi_run(n, P.lsi_problem(900 + b, n, dims)) for b in range(batch)]
+    problems = [P.lsi_problem(900 + b, n, dims, perturb=0.05) for b in range(batch)]
+    guess = [[np.where(a == 3, 0, a) for a in base[b]["active"]] for b in range(batch)]
+    x0 = np.stack([base[b]["x"] for b in range(batch)])
+    r = lexlsi.lsi_batch_solve(n, problems, active_guess=guess, x0=x0)
+    for b in range(batch):
+        o = oracle.lsi_run(n, problems[b], active_guess=guess[b], x0=base[b]["x"])
+        assert r["info"][b] == o["info"], b
+        np.testing.assert_array_equal(r["x"][b], o["x"])

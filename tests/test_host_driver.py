@@ -82,3 +82,29 @@ def test_shard_ranges():
         assert all(blocks[r][1] == blocks[r + 1][0] for r in range(w - 1))
         sizes = sharding.shard_sizes(n, w)
         assert max(sizes) - min(sizes) <= 1 and sum(sizes) == n
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_resumable_driver_equals_classic(oracle, seed):
+    """the lock-step form of the active-set driver (begin/advance) must take exactly the same trajectory as solve()"""
+    n, dims = 20, [6, 5, 5, 6]
+    objs = P.lsi_problem(100 + seed, n, dims)
+    a, b = oracle.lsi_run(n, objs), oracle.lsi_run(n, objs, resumable=True)
+    assert a["info"] == b["info"]
+    np.testing.assert_array_equal(a["x"], b["x"])
+    for u, w in zip(a["active"], b["active"]):
+        np.testing.assert_array_equal(u, w)
+
+
+def test_resumable_driver_with_warm_start_and_removals(oracle):
+    n, dims = 40, [12] * 5
+    objs = P.lsi_problem(7, n, dims)
+    a, b = oracle.lsi_run(n, objs), oracle.lsi_run(n, objs, resumable=True)
+    assert a["info"] == b["info"] and a["info"]["deactivations"] > 0
+    np.testing.assert_array_equal(a["x"], b["x"])
+    guess = [np.where(t == 3, 0, t) for t in a["active"]]
+    objs2 = P.lsi_problem(7, n, dims, perturb=0.05)
+    c = oracle.lsi_run(n, objs2, active_guess=guess, x0=a["x"])
+    d = oracle.lsi_run(n, objs2, active_guess=guess, x0=a["x"], resumable=True)
+    assert c["info"] == d["info"]
+    np.testing.assert_array_equal(c["x"], d["x"])
