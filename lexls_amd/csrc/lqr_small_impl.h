@@ -158,9 +158,10 @@ namespace lexls
 
             // ---- LDS carve-up ----
             double *X        = smem;                  // NC*MD : level transposition scratch
-            double *EX       = X + NC * MD;           // 128   : [0,64) pivot-column exchange, [64,64+MD) 1/R_qq, [96,..) pivot lanes
+            double *EX       = X + NC * MD;           // 128   : [0,64) pivot-column exchange, [64,64+MD) 1/R_qq, [96,104) pivot lanes, [104,120) zeros
             double *idg_s    = EX + 64;               // MD: reciprocal diagonal of the level being factorised
             int *pivl_s      = reinterpret_cast<int *>(EX + 96); // MD: lane of the q-th pivot column
+            double *ZB       = EX + 104;              // 16 zeros: what non-trailing columns "read" in the Gauss update
             double *IMG      = EX + 128;              // img_doubles : compact [R T | rhs] images of the levels
             double *xs       = IMG + img_doubles;     // 64    : solution by position
             uint32_t *perm_s = reinterpret_cast<uint32_t *>(xs + 64); // 64
@@ -183,6 +184,7 @@ namespace lexls
             double *hhs = a.hh + (size_t)b * cap;
             for (int i = lane; i < cap; i += 64) hhs[i] = 0.0; // initialize(), lexlse.h:1683
             perm_s[lane] = lane;
+            if (lane < 16) ZB[lane] = 0.0;
 
             int pos        = (lane < n) ? lane : (lane == n ? n : 0x3fffffff);
             int ColIndex   = 0;
@@ -440,45 +442,81 @@ namespace lexls
                     const int rk        = FULL ? MD : rank;
                     const int Fn        = F + dim;
                     const bool below    = lane >= Fn && lane < M;
-                    double Lv[MD];
-#pragma unroll
-                    for (int q = 0; q < MD; q++) Lv[q] = 0.0;
+
+                    // ---- L <- A_left R^-1, column-oriented: after L_p is final, ONE batch of loads brings row p of R and every
+                    //      later column absorbs it (same accumulation order per column as the row-oriented form: p ascending) ----
+                    double acc[MD], Lv[MD], idg[MD];
+                    int pq[MD];
 #pragma unroll
                     for (int q = 0; q < MD; q++)
                     {
-                        if (q < rk) // one uniform guard per pivot (folds away when FULL)
-                        {
-                            const int pq = uni(pivl_s[q]);
-                            double s     = select_reg<NC>(T, pq);
+                        const bool on = FULL || q < rk;
+                        pq[q]         = on ? uni(pivl_s[q]) : 0;
+                        idg[q]        = on ? idg_s[q] : 0.0;
+                        acc[q]        = on ? select_reg<NC>(T, pq[q]) : 0.0;
+                        Lv[q]         = 0.0;
+                    }
 #pragma unroll
-                            for (int p2 = 0; p2 < MD; p2++)
-                                if (p2 < q) s = dfma(-Lv[p2], img[q * stride + p2], s);
-                            Lv[q] = s * idg_s[q];
-                            if (write_factor) store_reg<NC>(T, pq, Lv[q], below);
-#ifdef LEXLS_WAVE_SCHED_FENCE
-                            __builtin_amdgcn_sched_barrier(0);
-#endif
+                    for (int p2 = 0; p2 < MD; p2++)
+                    {
+                        if (FULL || p2 < rk)
+                        {
+                            Lv[p2] = acc[p2] * idg[p2];
+                            double rrow[MD];
+#pragma unroll
+                            for (int q = 0; q < MD; q++)
+                                if (q > p2) rrow[q] = (FULL || q < rk) ? img[q * stride + p2] : 0.0; // R[p2][q], wave-uniform
+#pragma unroll
+                            for (int q = 0; q < MD; q++)
+                                if (q > p2) acc[q] = dfma(-Lv[p2], rrow[q], acc[q]);
+                            if (write_factor) store_reg<NC>(T, pq[p2], Lv[p2], below);
                         }
                     }
+#pragma unroll
+                    for (int q = 0; q < MD; q++) Lv[q] = below ? -Lv[q] : 0.0; // rows that are not below this level must not change
                     STAMP(7)
-                    // Trailing -= L * Up for every column that is still free, and the RHS.  Lv[p] == 0 for p >= rank and the
-                    // image's padding row is zero, so the chain runs over the (even) stride without per-element guards.
+
+                    // ---- Trailing += (-L) * Up over the still-free columns and the RHS, in chunks of CH physical columns:
+                    //      pivot index outermost inside a chunk, so the CH fma chains advance side by side (no chain waits for
+                    //      its own previous link) and the broadcast loads of U stream ahead.  Columns that are not trailing read
+                    //      a block of zeros: their row-per-lane entries are left untouched without any branch. ----
                     const unsigned long long tmask = __ballot(((lane < n) && (pos >= ColIndex)) || (lane == n));
-#pragma unroll
-                    for (int j = 0; j < NC; j++)
-                    {
-                        if (j <= n && ((tmask >> j) & 1ull))
-                        {
-                            const int slot  = (j < n) ? __builtin_amdgcn_readlane(pos, j) : n;
-                            const double *u = static_cast<const double *>(__builtin_assume_aligned(img + (slot - Fc) * stride, 16));
-                            double t        = T[j];
-#pragma unroll
-                            for (int p2 = 0; p2 < MD; p2++)
-                                if (FULL || p2 < stride) t = dfma(-Lv[p2], u[p2], t);
-                            if (below) T[j] = t;
-#ifdef LEXLS_WAVE_SCHED_FENCE
-                            if ((j % LEXLS_WAVE_SCHED_FENCE) == LEXLS_WAVE_SCHED_FENCE - 1) __builtin_amdgcn_sched_barrier(0); // bound the live ranges of hoisted LDS loads
+#ifndef LEXLS_GEMM_CH
+#define LEXLS_GEMM_CH 1
 #endif
+                    constexpr int CH               = LEXLS_GEMM_CH;
+#pragma unroll
+                    for (int j0 = 0; j0 < NC; j0 += CH)
+                    {
+                        if (((tmask >> j0) & ((1ull << CH) - 1ull)) == 0ull) continue; // no trailing column in this chunk
+                        const double2 *u[CH];
+#pragma unroll
+                        for (int c = 0; c < CH; c++)
+                        {
+                            const int j = j0 + c;
+                            u[c]        = reinterpret_cast<const double2 *>(ZB);
+                            if (j < NC && j <= n)
+                            {
+                                const int slot = (j < n) ? __builtin_amdgcn_readlane(pos, j < 64 ? j : 0) : n;
+                                if ((tmask >> j) & 1ull) u[c] = reinterpret_cast<const double2 *>(img + (slot - Fc) * stride);
+                            }
+                        }
+#pragma unroll
+                        for (int pp = 0; pp < MD / 2; pp++)
+                        {
+                            if (FULL || 2 * pp < stride)
+                            {
+                                double2 uv[CH];
+#pragma unroll
+                                for (int c = 0; c < CH; c++) uv[c] = u[c][pp];
+#pragma unroll
+                                for (int c = 0; c < CH; c++)
+                                    if (j0 + c < NC)
+                                    {
+                                        T[j0 + c < NC ? j0 + c : 0] = dfma(Lv[2 * pp], uv[c].x, T[j0 + c < NC ? j0 + c : 0]);
+                                        T[j0 + c < NC ? j0 + c : 0] = dfma(Lv[2 * pp + 1], uv[c].y, T[j0 + c < NC ? j0 + c : 0]);
+                                    }
+                            }
                         }
                     }
                     STAMP(8)

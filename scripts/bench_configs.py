@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline bench.py line): the other BASELINE configs and the secondary kernels.
+Prints one JSON object; run on the GPU box:  python scripts/bench_configs.py > gpurun_out/configs.json"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import lexls_amd  # noqa: E402
+from lexls_amd import lexlsi, problems as P  # noqa: E402
+from oracle import oracle_ctypes as oc  # noqa: E402
+
+
+def timed(fn, sync, reps):
+    fn(); sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+out = {}
+
+# ---- configs[1]: single large equality problem n=512, 4 x 256 -------------------------------------------------------
+n, dims = 512, [256] * 4
+lod = P.lse_batch(20260001, 1, n, dims)
+s = lexls_amd.BatchedLexLSE(1, n, dims)
+s.setProblem(lod)
+t = timed(lambda: s.factorize_solve(True), s.synchronize, 5)
+flops = P.flop_model(n, dims)["total"]
+tc, _ = oc.lse_time(lod, dims, n, 1, 3)
+out["config1_single_large"] = dict(kernel=s.last_kernel(), ms=1e3 * t, gflops=flops / t / 1e9, cpu_oracle_ms=1e3 * tc / 3, cpu_oracle_gflops=flops / (tc / 3) / 1e9,
+                                   note="generic one-workgroup kernel (matrix in HBM/L2): correctness path, not yet a tuned large-problem kernel")
+
+# ---- secondary kernels on the IK batch ---------------------------------------------------------------------------------
+n, dims, batch = 40, [12] * 5, 4096
+lod = P.lse_batch_fast(20260100, batch, n, dims)
+s = lexls_amd.BatchedLexLSE(batch, n, dims)
+s.setProblem(lod)
+s.setCtrType(np.full((batch, 60), 2, np.uint8))
+s.factorize_solve(True)
+fac_bytes = batch * 60 * 41 * 8
+import ctypes as C
+from lexls_amd import capi
+L = capi.lib()
+for name, fn in [("residual(get_v)", lambda: L.lexls_lse_residual(s._h)),
+                 ("sensitivity(level 3)", lambda: L.lexls_lse_sensitivity(s._h, None, C.c_int32(3), C.c_double(1e-8), C.c_double(1e-12))),
+                 ("solve(from factor)", lambda: L.lexls_lse_solve(s._h))]:
+    t = timed(fn, s.synchronize, 20)
+    out[name] = dict(ms=1e3 * t, factor_read_GBs=fac_bytes / t / 1e9)
+
+n2, dims2 = 40, [6] * 5
+lod2 = P.lse_batch_fast(5, 1024, n2, dims2)
+s2 = lexls_amd.BatchedLexLSE(1024, n2, dims2)
+s2.setProblem(lod2)
+s2.factorize_solve(True)
+t = timed(lambda: L.lexls_lse_solve_least_norm(s2._h), s2.synchronize, 5)
+out["least_norm_givens(1024 x n=40, 5x6)"] = dict(ms=1e3 * t)
+
+# ---- configs[4]: lock-step batched LSI, warm-started ----------------------------------------------------------------------
+n, dims, batch = 40, [12] * 5, int(os.environ.get("LSI_BATCH", "256"))
+t0 = time.perf_counter()
+base_problems = [P.lsi_problem(20260500 + b, n, dims) for b in range(batch)]
+cold = lexlsi.lsi_batch_solve(n, base_problems)
+t_cold = time.perf_counter() - t0
+problems = [P.lsi_problem(20260500 + b, n, dims, perturb=0.05) for b in range(batch)]
+guess = [[np.where(a == 3, 0, a) for a in np.split(cold["active"][b], np.cumsum(cold["dims"])[:-1])] for b in range(batch)]
+t0 = time.perf_counter()
+warm = lexlsi.lsi_batch_solve(n, problems, active_guess=guess, x0=cold["x"])
+t_warm = time.perf_counter() - t0
+fc = np.array([i["factorizations"] for i in cold["info"]])
+fw = np.array([i["factorizations"] for i in warm["info"]])
+out["config4_lsi_lockstep"] = dict(batch=batch, cold=dict(seconds=t_cold, mean_factorizations=float(fc.mean()), max=int(fc.max()), rounds=cold["rounds"],
+                                                         solved=int(sum(i["status"] == 0 for i in cold["info"]))),
+                                   warm=dict(seconds=t_warm, mean_factorizations=float(fw.mean()), max=int(fw.max()), rounds=warm["rounds"],
+                                             solved=int(sum(i["status"] == 0 for i in warm["info"])), factorizations_per_s=float(fw.sum() / t_warm)),
+                                   note="includes host driver work and per-round PCIe staging of the gathered rows (SURVEY 8(f) item 1 is the next step)")
+print(json.dumps(out, indent=1))
