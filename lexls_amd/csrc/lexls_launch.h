@@ -17,7 +17,7 @@ namespace lexls
     hipError_t launch_sensitivity(const LseArgs &a, const int32_t *d_obj_index, int32_t obj_all, double tolW, double tolC, hipStream_t s);
     hipError_t launch_leastnorm(const LseArgs &a, hipStream_t s);
 
-    // lqr_small.hip — one wavefront per problem, problem in VGPRs (n+1 <= 64, rows <= 64, level dims <= 16, no fixed variables)
+    // lqr_small.hip — one wavefront per problem, problem in VGPRs (n+1 <= 64, rows <= 64, level dims <= 16)
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed);
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, hipStream_t s, const char **variant);
 } // namespace lexls

@@ -14,7 +14,8 @@ namespace lexls
 
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed)
     {
-        return !has_fixed && a.nVar + 1 <= 64 && max_rows <= 64 && max_level_dim <= 16 && a.nObj <= 16;
+        (void)has_fixed; // fixed variables are handled in-kernel
+        return a.nVar + 1 <= 64 && max_rows <= 64 && max_level_dim <= 16 && a.nObj <= 16;
     }
 
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, hipStream_t s, const char **variant)

@@ -189,15 +189,56 @@ namespace lexls
             int pos        = (lane < n) ? lane : (lane == n ? n : 0x3fffffff);
             int ColIndex   = 0;
             int TotalRank  = 0;
+
+            // ---- fixed variables (lexlse.h:132-156): their columns take the first positions — an update of the position map
+            //      that follows the reference's chained index rule — and their contribution moves to the RHS ----
+            const int nf = a.nfixed ? (int)a.nfixed[b] : 0;
+            if (nf > 0)
+            {
+                __syncthreads();
+                if (lane < nf)
+                {
+                    perm_s[lane] = a.fixed_idx[(size_t)b * n + lane]; // working copy of fixed_var_index; ends as column_permutations
+                    EX[lane]     = a.fixed_val[(size_t)b * n + lane];
+                }
+                __syncthreads();
+                for (int kf = 0; kf < nf; kf++)
+                {
+                    const int coeff = uni((int)perm_s[kf]);
+                    // the first later entry that refers to position kf now refers to coeff (lexlse.h:146-153)
+                    const unsigned long long hit = __ballot(lane > kf && lane < nf && (int)perm_s[lane] == kf);
+                    if (hit && lane == (int)__builtin_ctzll(hit)) perm_s[lane] = (uint32_t)coeff;
+                    // swap the columns at positions kf and coeff (lexlse.h:141-144)
+                    const int la = (int)__builtin_ctzll(__ballot(lane < n && pos == kf));
+                    const int lb = (int)__builtin_ctzll(__ballot(lane < n && pos == coeff));
+                    if (lane == la) pos = coeff;
+                    if (lane == lb) pos = kf;
+                    __syncthreads();
+                }
+                double shift = 0.0; // RHS -= sum_k LOD(:, position k) * x_k, k ascending (lexlse.h:155)
+                for (int kf = 0; kf < nf; kf++)
+                {
+                    const int lk = (int)__builtin_ctzll(__ballot(lane < n && pos == kf));
+                    shift        = dfma(select_reg<NC>(T, lk), EX[kf], shift);
+                }
+                if (EXACT)
+                    T[NC - 1] -= shift;
+                else
+                    store_reg<NC>(T, n, select_reg<NC>(T, n) - shift, true);
+                ColIndex  = nf;
+                TotalRank = nf;
+                __syncthreads();
+            }
+            const bool all_fixed = ColIndex >= n; // lexlse.h:164-175: nothing left to factorise
             uint32_t imgp  = 0; // bump pointer into IMG
-            bool exhausted = false;
+            bool exhausted = all_fixed;
             int F          = 0;
             STAMP(0)
 
             for (int k = 0; k < nObj; k++)
             {
                 const int dim_rt = (int)dims[k];
-                const int Fc     = ColIndex;
+                const int Fc     = all_fixed ? 0 : ColIndex; // the reference leaves first_col_index at 0 when it returns early
                 int rank         = 0;
 
                 double hh[MD];
@@ -533,7 +574,7 @@ namespace lexls
 
             // ---- solve(): block back-substitution on the compact images (lexlse.h:1015-1045) ----
             __syncthreads();
-            xs[lane] = 0.0;
+            xs[lane] = (lane < nf) ? a.fixed_val[(size_t)b * n + lane] : 0.0; // x.head(nVarFixed) = fixed values (lexlse.h:1384)
             if (lane <= n) phys_s[(lane < n) ? pos : n] = (uint8_t)lane;
             __syncthreads();
             {

@@ -124,7 +124,8 @@ def test_wave_kernel_tied_norms(hip, oracle):
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
-def test_fixed_variables(hip, oracle):
+@BOTH_PATHS
+def test_fixed_variables(hip, oracle, force_generic):
     n, dims, batch = 12, [4, 4, 6], 10
     lod = P.lse_batch(31, batch, n, dims)
     nfixed = np.array([0, 1, 2, 3, 4, 5, 12, 2, 1, 3], np.uint32)
@@ -135,9 +136,27 @@ def test_fixed_variables(hip, oracle):
         perm = np.argsort(P.uniform(500 + b, n))
         idx[b, :nfixed[b]] = perm[:nfixed[b]]
         val[b, :nfixed[b]] = P.normal(600 + b, n)[:nfixed[b]]
-    s, ref = run_both(hip, oracle, lod, dims, n, nfixed=nfixed, fixed_idx=idx, fixed_val=val, fixed_type=typ)
+    s, ref = run_both(hip, oracle, lod, dims, n, force_generic=force_generic, nfixed=nfixed, fixed_idx=idx, fixed_val=val, fixed_type=typ)
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
+    assert s.last_kernel().startswith("lqr_generic" if force_generic else "lqr_wave")
+
+
+def test_fixed_variables_chained_indices(hip, oracle):
+    """fixed indices that point at positions already used by earlier swaps exercise the chained index rule (lexlse.h:146-153)"""
+    n, dims, batch = 8, [3, 4], 6
+    lod = P.lse_batch(131, batch, n, dims)
+    idx = np.zeros((batch, n), np.uint32)
+    val = np.zeros((batch, n))
+    pats = [[3, 0, 1], [1, 0, 2], [2, 1, 0], [7, 0, 1], [0, 1, 2], [5, 0, 5 - 5 + 3]]
+    for b in range(batch):
+        idx[b, :3] = pats[b]
+        val[b, :3] = P.normal(140 + b, 3)
+    nfixed = np.full(batch, 3, np.uint32)
+    for fg in (False, True):
+        s, ref = run_both(hip, oracle, lod, dims, n, force_generic=fg, nfixed=nfixed, fixed_idx=idx, fixed_val=val)
+        assert_factor_equal(s, ref, dims, n)
+        np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
 def test_medium_problem_256_thread_variant(hip, oracle):
