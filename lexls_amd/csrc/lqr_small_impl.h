@@ -111,6 +111,17 @@ namespace lexls
 
         __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+        /// f(integral_constant<int, I>) for I = B .. E-1: a loop whose index is a compile-time constant in the body
+        template <int B, int E, class F>
+        __device__ __forceinline__ void for_each_index(F &&f)
+        {
+            if constexpr (B < E)
+            {
+                f(std::integral_constant<int, B>{});
+                for_each_index<B + 1, E>(f);
+            }
+        }
+
 // Diagnostic build only (-DLEXLS_WAVE_STAMPS): per-phase shader-clock totals of every wave go to the (otherwise unused)
 // lambda buffer; the product build contains no stamp.  Phases: 0 load, 1 transpose, 2 pivot search, 3 norms+rank test,
 // 4 householder scalars (exchange, sqrt, division), 5 apply+downdate, 6 image store, 7 trsm, 8 gemm, 9 solve, 10 output.
@@ -343,39 +354,46 @@ namespace lexls
                             const double diag = degenerate ? c0 : beta;
                             const double den  = c0 - beta;
 
-                            // spread the pivot column over the lanes: lane t gets v_{counter+t}
-                            __syncthreads();
-                            if (lane == pl)
+                            // spread the pivot column over the lanes: lane r gets v_r for the rows r below the pivot row
+                            // (v_readlane -> v_writelane pairs: no LDS round trip, no barrier on the pivot's critical path)
+                            double num = 1.0;
                             {
-#pragma unroll
-                                for (int r = 0; r < MD; r++)
-                                    if (r > counter) EX[r - counter] = hh[r];
+                                int nlo = __double2loint(num), nhi = __double2hiint(num);
+                                for_each_index<1, MD>([&](auto rc) {
+                                    constexpr int r = decltype(rc)::value;
+                                    if (r > counter && r < dim)
+                                    {
+                                        const int slo = __builtin_amdgcn_readlane(__double2loint(hh[r]), pl);
+                                        const int shi = __builtin_amdgcn_readlane(__double2hiint(hh[r]), pl);
+                                        int tlo = nlo, thi = nhi; // (inline asm cannot bind a by-reference capture directly)
+                                        asm("v_writelane_b32 %0, %1, %2" : "+v"(tlo) : "s"(slo), "n"(r));
+                                        asm("v_writelane_b32 %0, %1, %2" : "+v"(thi) : "s"(shi), "n"(r));
+                                        nlo = tlo;
+                                        nhi = thi;
+                                    }
+                                });
+                                num = __hiloint2double(nhi, nlo);
                             }
-                            __syncthreads();
-                            double num = (lane > 0 && lane < R) ? EX[lane] : 1.0;
-                            double dnm = den;
+                            const bool ess_lane = lane > counter && lane < dim;
+                            double dnm          = ess_lane ? den : diag; // lanes without a role compute 1/diag (lane 63 is read)
                             if (lane == 0)
                             {
                                 num = beta - c0;
                                 dnm = beta;
                             }
-                            if (lane >= R)
-                            {
-                                num = 1.0;
-                                dnm = diag;
-                            }
                             const double quo = num / dnm; // ONE division sequence: tau | essential part | 1/R_jj
                             if (lane == 63) idg_s[counter] = quo;
                             STAMP(4)
                             // wave-uniform tau and essentials (SGPR pairs); zero beyond the level's rows and when H is the identity
-                            const double quo_e = (degenerate || lane >= R) ? 0.0 : quo;
+                            const double quo_e = (degenerate || !(ess_lane || lane == 0)) ? 0.0 : quo;
                             const double tau   = rdlane(quo_e, 0);
-                            double e[MD];
+                            double e[MD]; // e[r] = essential entry of row r (absolute row inside the level)
 #pragma unroll
-                            for (int t = 0; t < MD; t++) e[t] = 0.0;
-#pragma unroll
-                            for (int t = 1; t < MD; t++)
-                                if (t < MD - counter) e[t] = rdlane(quo_e, t);
+                            for (int r = 0; r < MD; r++) e[r] = 0.0;
+                            for_each_index<1, MD>([&](auto rc) {
+                                constexpr int r = decltype(rc)::value;
+                                if (r > counter) e[r] = rdlane(quo_e, r);
+                            });
 
                             // the pivot column now holds beta and the essential part (zeros if degenerate)
                             if (lane == pl)
@@ -383,7 +401,7 @@ namespace lexls
                                 hh[counter] = diag;
 #pragma unroll
                                 for (int r = 0; r < MD; r++)
-                                    if (r > counter) hh[r] = e[r - counter];
+                                    if (r > counter) hh[r] = e[r];
                             }
                             // apply H to the trailing columns and the RHS (lexlse.h:243-246); branch-free: zero essentials are no-ops
                             const bool trailing = ((lane < n) && (pos > ColIndex)) || (lane == n);
@@ -392,12 +410,12 @@ namespace lexls
                                 double tmp = 0.0;
 #pragma unroll
                                 for (int r = 0; r < MD; r++)
-                                    if (r > counter) tmp = dfma(e[r - counter], hh[r], tmp);
+                                    if (r > counter) tmp = dfma(e[r], hh[r], tmp);
                                 tmp += hh[counter];
                                 hh[counter] = dfma(-tau, tmp, hh[counter]);
 #pragma unroll
                                 for (int r = 0; r < MD; r++)
-                                    if (r > counter) hh[r] = dfma(-(tau * e[r - counter]), tmp, hh[r]);
+                                    if (r > counter) hh[r] = dfma(-(tau * e[r]), tmp, hh[r]);
                             }
                             if (lane == 0) hhs[row] = tau;
                         }
