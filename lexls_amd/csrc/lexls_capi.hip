@@ -40,7 +40,9 @@ struct lexls_lse_s
     hipStream_t stream;
     uint32_t batch, nVar, nObj, cap, max_rows, max_level_dim;
     int force_generic;
-    std::vector<uint32_t> maxdim;
+    std::vector<uint32_t> maxdim, level_max;
+    void *d_large_state;
+    double *d_norms;
     double tol;
     bool dims_set, has_fixed, factor_valid, factor_in_hbm;
     const char *last_kernel;
@@ -181,7 +183,7 @@ extern "C"
         (void)hipSetDevice(h->device);
         void *ptrs[] = {h->d_in_owned, h->d_fac,     h->d_x,      h->d_hh,        h->d_v,        h->d_lambda,     h->d_maxabs,
                         h->d_scratch,  h->d_fixed_val, h->d_perm,   h->d_rank,      h->d_fcol,     h->d_totalrank,  h->d_dims,
-                        h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx,      h->d_skip};
+                        h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx,      h->d_skip,       h->d_large_state, h->d_norms};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         delete h;
@@ -216,6 +218,7 @@ extern "C"
         if (!h_dims) return fail(LEXLS_ERR_INVALID, "set_obj_dim: null dims");
         std::vector<uint32_t> d((size_t)h->batch * h->nObj);
         uint32_t max_rows = 0, max_level = 0;
+        h->level_max.assign(h->nObj, 0);
         for (uint32_t b = 0; b < h->batch; b++)
         {
             uint32_t m = 0;
@@ -226,6 +229,7 @@ extern "C"
                 d[(size_t)b * h->nObj + k] = v;
                 m += v;
                 if (v > max_level) max_level = v;
+                if (v > h->level_max[k]) h->level_max[k] = v;
             }
             if (m > max_rows) max_rows = m;
         }
@@ -327,9 +331,22 @@ extern "C"
         const char *variant = "";
         const LseArgs a     = h->args();
         if (!h->force_generic && wave_kernel_supports(a, h->max_rows, h->max_level_dim, h->has_fixed))
+        {
             HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->stream, &variant)); // always solves as well
+        }
+        else if (!h->force_generic && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
+        {
+            if (!h->d_large_state) HIP_TRY(hipMalloc(&h->d_large_state, large_state_bytes(h->batch)));
+            if (!h->d_norms) HIP_TRY(hipMalloc((void **)&h->d_norms, 8 * (size_t)h->batch * h->nVar));
+            HIP_TRY(launch_lqr_large(a, h->level_max.data(), h->max_rows, h->d_large_state, h->d_norms, h->stream));
+            if (do_solve) HIP_TRY(launch_solve_generic(a, h->stream));
+            variant      = "lqr_large<multi-launch>";
+            write_factor = true;
+        }
         else
+        {
             HIP_TRY(launch_lqr_generic(a, h->max_rows, write_factor, do_solve, h->stream, &variant));
+        }
         h->last_kernel   = variant;
         h->factor_valid  = true;
         h->factor_in_hbm = write_factor || std::strstr(variant, "hbm") != nullptr;

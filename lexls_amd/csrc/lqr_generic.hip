@@ -831,6 +831,13 @@ namespace lexls
         }
     } // namespace
 
+    bool generic_fits_lds(const LseArgs &a0, uint32_t max_rows)
+    {
+        LseArgs a = a0;
+        a.ldp     = odd_ld(max_rows);
+        return lqr_lds_bytes(a, 1024, true) <= kMaxLdsBytes;
+    }
+
     hipError_t launch_lqr_generic(LseArgs a, uint32_t max_rows, bool write_factor, bool do_solve, hipStream_t s, const char **variant)
     {
         a.ldp             = odd_ld(max_rows);

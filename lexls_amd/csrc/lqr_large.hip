@@ -1,0 +1,493 @@
+// Large-problem lexicographic-QR path (BASELINE configs[1]: n = 512, 4 levels x 256 rows): the matrix (4.2 MB) does not fit
+// a CU's LDS, so the factorization is spread over the whole chip, ONE KERNEL LAUNCH PER STAGE instead of one persistent
+// workgroup — no in-kernel grid barrier, no spinning: stages are ordered by the stream.
+//
+//   per level:   level_begin   (initial squared column norms, one lane per column)
+//   per pivot:   pivot         (one workgroup: first-maximum search, fresh/tail norms, Householder scalars, column swap,
+//                               essential part)                                                  [serial part of the pivot]
+//                apply         (one workgroup per tile of TC trailing columns, tile staged in LDS with coalesced loads:
+//                               ordered dot product + update per column, norm down-date)         [parallel part]
+//   per level:   level_end, trsm (row-per-lane, multipliers in LDS), gemm (row-per-lane x TJ columns in registers)
+//
+// Same arithmetic contract as the other kernels (oracle/lexlse_oracle.h): every chain is evaluated in the same order, so the
+// result is bit-identical to the oracle's.  Whether a stage has anything to do (rank break, columns exhausted) is decided on
+// the device from a small per-problem state record; the host only reads `exhausted` back once per level to stop launching.
+#include "lexls_kernels.h"
+#include "lexls_launch.h"
+
+#include <cfloat>
+#include <vector>
+
+namespace lexls
+{
+    struct LargeState
+    {
+        uint32_t ColIndex, rank, exhausted, F, dim, Fc, last_id, cur, piv, row, R, degenerate, totalrank, stop_level;
+        double tau, diag, den;
+    };
+
+    namespace
+    {
+        __device__ __forceinline__ double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#ifndef LEXLS_LARGE_TC
+#define LEXLS_LARGE_TC 8
+#endif
+        constexpr int TC = LEXLS_LARGE_TC; // trailing columns per apply-workgroup
+        constexpr int TJ = 8;  // trailing columns per lane in the Gauss update
+
+        __device__ __forceinline__ bool skipped(const LseArgs &a, uint32_t b) { return a.skip && a.skip[b]; }
+
+        __global__ __launch_bounds__(256) void large_init(LseArgs a, LargeState *st)
+        {
+            const uint32_t b = blockIdx.y;
+            if (skipped(a, b)) return;
+            const size_t ps  = (size_t)a.cap * (a.nVar + 1);
+            const double *in = a.in + b * ps;
+            double *W        = a.fac + b * ps;
+            const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+            if (in != W)
+                for (size_t e = tid; e < ps; e += nth) W[e] = in[e];
+            for (size_t i = tid; i < a.cap; i += nth) a.hh[(size_t)b * a.cap + i] = 0.0;
+            for (size_t i = tid; i < a.nVar; i += nth) a.perm[(size_t)b * a.nVar + i] = (uint32_t)i;
+            if (tid == 0)
+            {
+                LargeState z = {};
+                st[b]        = z;
+            }
+        }
+
+        __global__ __launch_bounds__(64) void large_level_begin(LseArgs a, LargeState *st, double *norms, uint32_t level)
+        {
+            const uint32_t b = blockIdx.y;
+            if (skipped(a, b)) return;
+            const uint32_t n = a.nVar, cap = a.cap;
+            const uint32_t *dims = a.dims + (size_t)b * a.nObj;
+            uint32_t F = 0;
+            for (uint32_t k = 0; k < level; k++) F += dims[k];
+            const uint32_t dim = dims[level];
+            LargeState *s      = st + b;
+            const uint32_t c0  = s->ColIndex;
+            const double *W    = a.fac + (size_t)b * cap * (n + 1);
+            const uint32_t k   = blockIdx.x * 64 + threadIdx.x;
+            if (k < n && k >= c0 && !s->exhausted)
+            {
+                double acc = 0.0;
+                for (uint32_t i = 0; i < dim; i++)
+                {
+                    const double w = W[F + i + (size_t)k * cap];
+                    acc            = dfma(w, w, acc);
+                }
+                norms[(size_t)b * n + k] = acc;
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0)
+            {
+                s->F    = F;
+                s->dim  = dim;
+                s->Fc   = c0;
+                s->rank = 0;
+            }
+        }
+
+        /// serial part of one pivot (lexlse.h:205-242): one workgroup per problem
+        __global__ __launch_bounds__(1024) void large_pivot(LseArgs a, LargeState *st, double *norms_all, uint32_t level, uint32_t counter)
+        {
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.y, tid = threadIdx.x;
+            if (skipped(a, b)) return;
+            LargeState *s = st + b;
+            if (s->exhausted || counter >= s->dim || s->stop_level == level + 1) return;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            uint32_t M           = 0;
+            for (uint32_t k = 0; k < nObj; k++) M += dims[k];
+            double *W      = a.fac + (size_t)b * cap * (n + 1);
+            double *norms  = norms_all + (size_t)b * n;
+            const uint32_t c = s->ColIndex, row = s->F + counter, R = s->dim - counter;
+
+            double *colv    = smem;                 // R
+            double *red_v   = colv + ((R + 1) & ~1u); // 1024
+            uint32_t *red_i = reinterpret_cast<uint32_t *>(red_v + 1024);
+            double *sc      = reinterpret_cast<double *>(red_i + 1024); // fresh, tail, tau, diag, den, flags
+
+            // first maximum of the down-dated norms
+            double bv   = -INFINITY;
+            uint32_t bi = 0xffffffffu;
+            for (uint32_t k = c + tid; k < n; k += 1024)
+                if (norms[k] > bv)
+                {
+                    bv = norms[k];
+                    bi = k;
+                }
+            red_v[tid] = bv;
+            red_i[tid] = bi;
+            __syncthreads();
+            for (int h = 512; h > 0; h >>= 1)
+            {
+                if (tid < (uint32_t)h)
+                {
+                    const double v2   = red_v[tid + h];
+                    const uint32_t i2 = red_i[tid + h];
+                    if (v2 > red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid]))
+                    {
+                        red_v[tid] = v2;
+                        red_i[tid] = i2;
+                    }
+                }
+                __syncthreads();
+            }
+            const uint32_t piv = red_i[0];
+
+            // stage the pivot column (coalesced) and run the two ordered chains on two different waves
+            for (uint32_t i = tid; i < R; i += 1024) colv[i] = W[row + i + (size_t)piv * cap];
+            __syncthreads();
+            if (tid == 0)
+            {
+                double f = 0.0;
+#pragma unroll 16
+                for (uint32_t i = 0; i < R; i++) f = dfma(colv[i], colv[i], f);
+                sc[0] = f;
+            }
+            if (tid == 64)
+            {
+                double t = 0.0;
+#pragma unroll 16
+                for (uint32_t i = 1; i < R; i++) t = dfma(colv[i], colv[i], t);
+                sc[1] = t;
+            }
+            __syncthreads();
+            const double fresh = sc[0];
+            if (fresh < a.tol) // rank test on the squared norm (lexlse.h:214)
+            {
+                if (tid == 0)
+                {
+                    norms[piv]    = fresh;
+                    s->stop_level = level + 1;
+                }
+                return;
+            }
+            const double c0v = colv[0];
+            double tau = 0.0, diag = c0v, den = 1.0;
+            int degenerate = 0;
+            if (R > 1)
+            {
+                const double tailSq = sc[1];
+                if (tailSq <= DBL_MIN)
+                    degenerate = 1;
+                else
+                {
+                    double beta = sqrt(dfma(c0v, c0v, tailSq));
+                    if (c0v >= 0.0) beta = -beta;
+                    diag = beta;
+                    den  = c0v - beta;
+                    tau  = (beta - c0v) / beta;
+                }
+            }
+            // column swap over ALL rows (lexlse.h:222-232) fused with writing beta / the essential part
+            for (uint32_t i = tid; i < M; i += 1024)
+            {
+                const double a1 = W[i + (size_t)c * cap];
+                const double a2 = (i >= row && i < row + R) ? colv[i - row] : W[i + (size_t)piv * cap];
+                double newc     = a2;
+                if (R > 1)
+                {
+                    if (i == row)
+                        newc = diag;
+                    else if (i > row && i < row + R)
+                        newc = degenerate ? 0.0 : a2 / den;
+                }
+                W[i + (size_t)c * cap] = newc;
+                if (piv != c) W[i + (size_t)piv * cap] = a1;
+            }
+            if (tid == 0)
+            {
+                norms[piv]                  = fresh;
+                a.perm[(size_t)b * n + c]   = piv;
+                const double t              = norms[c];
+                norms[c]                    = norms[piv];
+                norms[piv]                  = t;
+                if (R > 1) a.hh[(size_t)b * cap + row] = tau;
+                s->cur        = c;
+                s->piv        = piv;
+                s->row        = row;
+                s->R          = R;
+                s->tau        = tau;
+                s->diag       = diag;
+                s->den        = den;
+                s->degenerate = degenerate;
+                s->last_id    = (level << 16) | counter;
+                s->ColIndex   = c + 1;
+                s->rank       = s->rank + 1;
+                if (c + 1 == n) s->exhausted = 1;
+            }
+        }
+
+        /// parallel part of one pivot (lexlse.h:243-266): a tile of TC trailing columns per workgroup
+        __global__ __launch_bounds__(256) void large_apply(LseArgs a, const LargeState *st, double *norms_all, uint32_t level, uint32_t counter)
+        {
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.y, tid = threadIdx.x;
+            if (skipped(a, b)) return;
+            const LargeState *s = st + b;
+            if (s->last_id != ((level << 16) | counter) || s->stop_level == level + 1) return;
+            const uint32_t n = a.nVar, cap = a.cap;
+            const uint32_t c = s->cur, row = s->row, R = s->R;
+            const uint32_t j0 = c + 1 + blockIdx.x * TC;
+            if (j0 > n) return;
+            const uint32_t nc = (n + 1 - j0 < (uint32_t)TC) ? n + 1 - j0 : TC;
+            double *W         = a.fac + (size_t)b * cap * (n + 1);
+            double *norms     = norms_all + (size_t)b * n;
+            const double tau  = s->tau;
+            const uint32_t ld = R | 1u; // odd: lane t walks column t of the tile without bank conflicts
+            double *tile      = smem;   // TC * ld
+            double *es        = tile + (size_t)TC * ld; // R - 1
+
+#ifdef LEXLS_LARGE_STAMPS
+            long long t0 = clock64(), t1 = t0, t2 = t0, t3 = t0;
+#endif
+            if (R > 1 && tau != 0.0)
+            {
+                for (uint32_t i = tid; i + 1 < R; i += 256) es[i] = W[row + 1 + i + (size_t)c * cap];
+                for (uint32_t i = tid; i < R; i += 256) // all TC loads of a row in flight before the first LDS store
+                {
+                    double v[TC];
+#pragma unroll
+                    for (int t = 0; t < TC; t++) v[t] = ((uint32_t)t < nc) ? W[row + i + (size_t)(j0 + t) * cap] : 0.0;
+#pragma unroll
+                    for (int t = 0; t < TC; t++) tile[t * ld + i] = v[t];
+                }
+                __syncthreads();
+#ifdef LEXLS_LARGE_STAMPS
+                t1 = clock64();
+#endif
+                if (tid < nc)
+                {
+                    // restrict: the essential part and the column never overlap, so the LDS reads may run ahead of the stores
+                    double *__restrict__ col      = tile + tid * ld;
+                    const double *__restrict__ ev = es;
+                    double tmp                    = 0.0;
+#pragma unroll 16
+                    for (uint32_t i = 1; i < R; i++) tmp = dfma(ev[i - 1], col[i], tmp);
+                    tmp += col[0];
+                    col[0] = dfma(-tau, tmp, col[0]);
+                    // chunks of 16: all LDS reads of a chunk are issued before its first store (the compiler will not
+                    // move a read above a store to the same LDS array on its own)
+                    uint32_t i = 1;
+                    for (; i + 16 <= R; i += 16)
+                    {
+                        double e16[16], c16[16];
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                        {
+                            e16[k] = ev[i - 1 + k];
+                            c16[k] = col[i + k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 16; k++) col[i + k] = dfma(-(tau * e16[k]), tmp, c16[k]);
+                    }
+                    for (; i < R; i++) col[i] = dfma(-(tau * ev[i - 1]), tmp, col[i]);
+                    if (j0 + tid < n && c + 1 < n) norms[j0 + tid] = dfma(-col[0], col[0], norms[j0 + tid]);
+                }
+                __syncthreads();
+#ifdef LEXLS_LARGE_STAMPS
+                t2 = clock64();
+#endif
+                for (uint32_t i = tid; i < R; i += 256)
+                {
+                    double v[TC];
+#pragma unroll
+                    for (int t = 0; t < TC; t++) v[t] = tile[t * ld + i];
+#pragma unroll
+                    for (int t = 0; t < TC; t++)
+                        if ((uint32_t)t < nc) W[row + i + (size_t)(j0 + t) * cap] = v[t];
+                }
+#ifdef LEXLS_LARGE_STAMPS
+                __syncthreads();
+                t3 = clock64();
+                if (tid == 0 && blockIdx.x == 0)
+                {
+                    double *dbg = a.lambda + (size_t)b * (n + cap);
+                    dbg[0] += (double)(t1 - t0);
+                    dbg[1] += (double)(t2 - t1);
+                    dbg[2] += (double)(t3 - t2);
+                    dbg[3] += 1.0;
+                }
+#endif
+            }
+            else if (tid < nc && j0 + tid < n && c + 1 < n)
+            {
+                const double w  = W[row + (size_t)(j0 + tid) * cap];
+                norms[j0 + tid] = dfma(-w, w, norms[j0 + tid]);
+            }
+        }
+
+        __global__ void large_level_end(LseArgs a, LargeState *st, uint32_t level)
+        {
+            const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+            if (b >= a.batch || skipped(a, b)) return;
+            LargeState *s                        = st + b;
+            a.rank[(size_t)b * a.nObj + level]   = s->rank;
+            a.fcol[(size_t)b * a.nObj + level]   = s->Fc;
+            s->totalrank += s->rank;
+            a.totalrank[b] = s->totalrank;
+        }
+
+        /// L <- A_left R^-1 for the rows below the level (lexlse.h:450-452): one row per lane, multipliers in LDS
+        __global__ __launch_bounds__(64) void large_trsm(LseArgs a, const LargeState *st, uint32_t level)
+        {
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.y, lane = threadIdx.x;
+            if (skipped(a, b)) return;
+            const LargeState *s = st + b;
+            const uint32_t rank = s->rank;
+            if (rank == 0 || level + 1 >= a.nObj) return;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            uint32_t M           = 0;
+            for (uint32_t k = 0; k < nObj; k++) M += dims[k];
+            const uint32_t F = s->F, Fc = s->Fc, Fn = F + s->dim;
+            const uint32_t gi = Fn + blockIdx.x * 64 + lane;
+            const bool on     = gi < M;
+            double *W         = a.fac + (size_t)b * cap * (n + 1);
+            double *__restrict__ L    = smem;                     // rank x 64, L[q * 64 + lane]
+            double *__restrict__ Rrow = smem + (size_t)rank * 64; // rank: row p of R, staged once per p
+            for (uint32_t q = 0; q < rank; q++) L[q * 64 + lane] = on ? W[gi + (size_t)(Fc + q) * cap] : 0.0;
+            for (uint32_t p = 0; p < rank; p++)
+            {
+                __syncthreads();
+                for (uint32_t q = p + lane; q < rank; q += 64) Rrow[q] = W[F + p + (size_t)(Fc + q) * cap];
+                __syncthreads();
+                const double inv = 1.0 / Rrow[p];
+                const double Lp  = L[p * 64 + lane] * inv;
+                L[p * 64 + lane] = Lp;
+                uint32_t q = p + 1;
+                for (; q + 8 <= rank; q += 8) // chunks of 8: reads first, then the stores
+                {
+                    double r8[8], l8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                    {
+                        r8[k] = Rrow[q + k];
+                        l8[k] = L[(q + k) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) L[(q + k) * 64 + lane] = dfma(-Lp, r8[k], l8[k]);
+                }
+                for (; q < rank; q++) L[q * 64 + lane] = dfma(-Lp, Rrow[q], L[q * 64 + lane]);
+            }
+            if (on)
+                for (uint32_t q = 0; q < rank; q++) W[gi + (size_t)(Fc + q) * cap] = L[q * 64 + lane];
+        }
+
+        /// Trailing -= L * Up (lexlse.h:454-469): one row per lane, TJ trailing columns per lane in registers
+        __global__ __launch_bounds__(64) void large_gemm(LseArgs a, const LargeState *st, uint32_t level)
+        {
+            const uint32_t b = blockIdx.z, lane = threadIdx.x;
+            if (skipped(a, b)) return;
+            const LargeState *s = st + b;
+            const uint32_t rank = s->rank;
+            if (rank == 0 || level + 1 >= a.nObj) return;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            uint32_t M           = 0;
+            for (uint32_t k = 0; k < nObj; k++) M += dims[k];
+            const uint32_t F = s->F, Fc = s->Fc, Fn = F + s->dim, c = s->ColIndex;
+            const uint32_t gi = Fn + blockIdx.x * 64 + lane;
+            const uint32_t j0 = c + blockIdx.y * TJ;
+            if (j0 > n) return;
+            const bool on = gi < M;
+            double *W     = a.fac + (size_t)b * cap * (n + 1);
+            double acc[TJ];
+#pragma unroll
+            for (int t = 0; t < TJ; t++) acc[t] = (on && j0 + t <= n) ? W[gi + (size_t)(j0 + t) * cap] : 0.0;
+#pragma unroll 4
+            for (uint32_t p = 0; p < rank; p++)
+            {
+                const double l = on ? W[gi + (size_t)(Fc + p) * cap] : 0.0;
+#pragma unroll
+                for (int t = 0; t < TJ; t++)
+                {
+                    const double u = (j0 + t <= n) ? W[F + p + (size_t)(j0 + t) * cap] : 0.0; // wave-uniform
+                    acc[t]         = dfma(-l, u, acc[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TJ; t++)
+                if (on && j0 + t <= n) W[gi + (size_t)(j0 + t) * cap] = acc[t];
+        }
+
+        __global__ void large_finish(LseArgs a, const LargeState *st)
+        {
+            const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+            if (b >= a.batch || skipped(a, b)) return;
+            // columns beyond TotalRank keep the identity permutation; levels after exhaustion already carry first_col = n
+            a.totalrank[b] = st[b].totalrank;
+        }
+    } // namespace
+
+    bool large_kernel_supports(const LseArgs &a, uint32_t max_level_dim, bool has_fixed)
+    {
+        const size_t trsm_lds = 8 * (size_t)((a.nVar < max_level_dim) ? a.nVar : max_level_dim) * 65;
+        const size_t piv_lds  = 8 * ((size_t)max_level_dim + 2 + 1024 + 16) + 4 * 1024;
+        const size_t app_lds  = 8 * ((size_t)TC * (max_level_dim | 1u) + max_level_dim);
+        return !has_fixed && trsm_lds <= kMaxLdsBytes && piv_lds <= kMaxLdsBytes && app_lds <= kMaxLdsBytes && max_level_dim < 65536 && a.nObj < 65536;
+    }
+
+    size_t large_state_bytes(uint32_t batch) { return sizeof(LargeState) * (size_t)batch; }
+
+    /// h_level_max[k] = max over the batch of dims[k]; h_rows_max = max rows of one problem
+    hipError_t launch_lqr_large(const LseArgs &a, const uint32_t *h_level_max, uint32_t h_rows_max, void *d_state, double *d_norms, hipStream_t s)
+    {
+        LargeState *st    = static_cast<LargeState *>(d_state);
+        const uint32_t B  = a.batch, n = a.nVar;
+        hipError_t e      = hipSuccess;
+        auto set_lds      = [&](const void *k, size_t bytes) {
+            if (e == hipSuccess && bytes > 64 * 1024) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        };
+        uint32_t maxdim = 0;
+        for (uint32_t k = 0; k < a.nObj; k++) maxdim = h_level_max[k] > maxdim ? h_level_max[k] : maxdim;
+        const size_t piv_lds  = 8 * ((size_t)((maxdim + 1) & ~1u) + 1024 + 16) + 4 * 1024;
+        const size_t app_lds  = 8 * ((size_t)TC * (maxdim | 1u) + maxdim);
+        const size_t trsm_lds = 8 * (size_t)((n < maxdim) ? n : maxdim) * 65;
+        set_lds(reinterpret_cast<const void *>(large_pivot), piv_lds);
+        set_lds(reinterpret_cast<const void *>(large_apply), app_lds);
+        set_lds(reinterpret_cast<const void *>(large_trsm), trsm_lds);
+        if (e != hipSuccess) return e;
+
+        hipLaunchKernelGGL(large_init, dim3(64, B), dim3(256), 0, s, a, st);
+        std::vector<LargeState> host(B);
+        bool all_exhausted = false;
+        uint32_t rows_seen = 0;
+        for (uint32_t level = 0; level < a.nObj; level++)
+        {
+            hipLaunchKernelGGL(large_level_begin, dim3((n + 63) / 64, B), dim3(64), 0, s, a, st, d_norms, level);
+            if (!all_exhausted)
+                for (uint32_t counter = 0; counter < h_level_max[level]; counter++)
+                {
+                    hipLaunchKernelGGL(large_pivot, dim3(1, B), dim3(1024), piv_lds, s, a, st, d_norms, level, counter);
+                    hipLaunchKernelGGL(large_apply, dim3((n + TC) / TC, B), dim3(256), app_lds, s, a, st, d_norms, level, counter);
+                }
+            hipLaunchKernelGGL(large_level_end, dim3((B + 63) / 64), dim3(64), 0, s, a, st, level);
+            rows_seen += h_level_max[level];
+            const uint32_t below = h_rows_max > rows_seen ? h_rows_max - rows_seen : 0;
+            if (level + 1 < a.nObj && below > 0)
+            {
+                hipLaunchKernelGGL(large_trsm, dim3((below + 63) / 64, B), dim3(64), trsm_lds, s, a, st, level);
+                hipLaunchKernelGGL(large_gemm, dim3((below + 63) / 64, (n + TJ) / TJ, B), dim3(64), 0, s, a, st, level);
+            }
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            if (!all_exhausted && level + 1 < a.nObj) // one small read-back per level: stop launching pivots once no column is left anywhere
+            {
+                e = hipMemcpyAsync(host.data(), st, sizeof(LargeState) * B, hipMemcpyDeviceToHost, s);
+                if (e != hipSuccess) return e;
+                e = hipStreamSynchronize(s);
+                if (e != hipSuccess) return e;
+                all_exhausted = (a.skip == nullptr); // skipped problems carry stale state: never stop early then
+                for (uint32_t b = 0; b < B && all_exhausted; b++)
+                    if (!host[b].exhausted) all_exhausted = false;
+            }
+        }
+        hipLaunchKernelGGL(large_finish, dim3((B + 63) / 64), dim3(64), 0, s, a, st);
+        return hipGetLastError();
+    }
+} // namespace lexls

@@ -35,7 +35,7 @@ t = timed(lambda: s.factorize_solve(True), s.synchronize, 5)
 flops = P.flop_model(n, dims)["total"]
 tc, _ = oc.lse_time(lod, dims, n, 1, 3)
 out["config1_single_large"] = dict(kernel=s.last_kernel(), ms=1e3 * t, gflops=flops / t / 1e9, cpu_oracle_ms=1e3 * tc / 3, cpu_oracle_gflops=flops / (tc / 3) / 1e9,
-                                   note="generic one-workgroup kernel (matrix in HBM/L2): correctness path, not yet a tuned large-problem kernel")
+                                   note="multi-launch large path: one launch per pivot stage (serial pivot kernel + tiled apply over the chip), ordered chains as in the oracle")
 
 # ---- secondary kernels on the IK batch ---------------------------------------------------------------------------------
 n, dims, batch = 40, [12] * 5, 4096

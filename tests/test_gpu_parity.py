@@ -168,24 +168,42 @@ def test_medium_problem_256_thread_variant(hip, oracle):
     assert s.last_kernel() == "lqr_generic<256,lds>"
 
 
-def test_hbm_resident_variant(hip, oracle):
+@BOTH_PATHS
+def test_hbm_resident_variants(hip, oracle, force_generic):
+    """problems too large for a CU's LDS: the multi-launch large path, and the one-workgroup generic fallback"""
     n, dims = 200, [100, 100, 100, 100]
     lod = P.lse_batch(43, 2, n, dims)
-    s, ref = run_both(hip, oracle, lod, dims, n)
-    assert s.last_kernel() == "lqr_generic<1024,hbm>"
+    s, ref = run_both(hip, oracle, lod, dims, n, force_generic=force_generic)
+    assert s.last_kernel() == ("lqr_generic<1024,hbm>" if force_generic else "lqr_large<multi-launch>")
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
 def test_config2_single_large(hip, oracle):
-    """BASELINE.json configs[1]: n=512, 4 levels x 256 rows."""
+    """BASELINE.json configs[1]: n=512, 4 levels x 256 rows (large path)."""
     n, dims = 512, [256] * 4
     lod = P.lse_batch(20260001, 1, n, dims)
     s, ref = run_both(hip, oracle, lod, dims, n)
+    assert s.last_kernel() == "lqr_large<multi-launch>"
     assert (ref["rank"] == [256, 256, 0, 0]).all()
-    np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
-    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
+
+
+def test_large_path_rank_deficient_and_ragged(hip, oracle):
+    n, cap_dims = 150, [90, 90, 90]
+    rdims = np.array([[90, 90, 90], [60, 0, 85], [90, 40, 7]], np.uint32)
+    full = np.zeros((3, n + 1, 270))
+    full[0, :, :270] = P.rank_deficient_problem(801, n, [90, 90, 90], [50, 40, 30])
+    for b in (1, 2):
+        m = int(rdims[b].sum())
+        full[b, :, :m] = P.lse_problem(802 + b, n, rdims[b])
+    s, ref = run_both(hip, oracle, full, rdims, n, maxdim=np.array(cap_dims, np.uint32))
+    assert s.last_kernel() == "lqr_large<multi-launch>"
+    assert ref["rank"][0].tolist() == [50, 40, 30]
+    assert_factor_equal(s, ref, rdims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    np.testing.assert_array_equal(s.get_v(), ref["v"])
 
 
 def test_residuals(hip, oracle):
