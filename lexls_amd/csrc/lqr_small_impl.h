@@ -41,25 +41,33 @@ namespace lexls
             return __hiloint2double(hi, lo);
         }
 
-        template <int CTRL, int ROWMASK>
-        __device__ __forceinline__ double dpp_max(double v)
+        /// max of two doubles as ONE v_max_f64 (the builtin adds canonicalising v_max x,x around it; keys are never NaN)
+        __device__ __forceinline__ double vmax(double x, double y)
         {
-            const int lo  = __double2loint(v), hi = __double2hiint(v);
-            const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
-            const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
-            return __builtin_fmax(v, __hiloint2double(hi2, lo2));
+            double r;
+            asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+            return r;
         }
 
-        /// maximum over the 64 lanes, returned as a wave-uniform value
+        template <int CTRL>
+        __device__ __forceinline__ double dpp_max(double v)
+        {
+            // source-only DPP moves (no tied "old" operand -> no register copies); every lane of the 16-lane row is written
+            const int lo2 = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+            const int hi2 = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+            return vmax(v, __hiloint2double(hi2, lo2));
+        }
+
+        /// maximum over the 64 lanes, returned as a wave-uniform value: butterfly inside each 16-lane DPP row, then the four
+        /// row results are combined through SGPRs
         __device__ __forceinline__ double wave_max(double v)
         {
-            v = dpp_max<0xB1, 0xF>(v);  // quad_perm [1,0,3,2]
-            v = dpp_max<0x4E, 0xF>(v);  // quad_perm [2,3,0,1]
-            v = dpp_max<0x141, 0xF>(v); // row_half_mirror
-            v = dpp_max<0x140, 0xF>(v); // row_mirror
-            v = dpp_max<0x142, 0xA>(v); // row_bcast:15 -> rows 1,3
-            v = dpp_max<0x143, 0xC>(v); // row_bcast:31 -> rows 2,3
-            return rdlane(v, 63);
+            v = dpp_max<0xB1>(v);  // quad_perm [1,0,3,2]
+            v = dpp_max<0x4E>(v);  // quad_perm [2,3,0,1]
+            v = dpp_max<0x141>(v); // row_half_mirror
+            v = dpp_max<0x140>(v); // row_mirror
+            const double r0 = rdlane(v, 0), r1 = rdlane(v, 16), r2 = rdlane(v, 32), r3 = rdlane(v, 48);
+            return __builtin_fmax(__builtin_fmax(r0, r1), __builtin_fmax(r2, r3));
         }
 
         /// T[idx] for a wave-uniform idx: a scalar branch tree instead of dynamic register indexing
@@ -413,9 +421,11 @@ namespace lexls
                                     if (r > counter) tmp = dfma(e[r], hh[r], tmp);
                                 tmp += hh[counter];
                                 hh[counter] = dfma(-tau, tmp, hh[counter]);
+                                double ntau = -tau; // held in a VGPR: "e[r] * ntau" then has a single SGPR operand (one instruction)
+                                asm volatile("" : "+v"(ntau));
 #pragma unroll
                                 for (int r = 0; r < MD; r++)
-                                    if (r > counter) hh[r] = dfma(-(tau * e[r]), tmp, hh[r]);
+                                    if (r > counter) hh[r] = dfma(e[r] * ntau, tmp, hh[r]);
                             }
                             if (lane == 0) hhs[row] = tau;
                         }
