@@ -4,7 +4,12 @@
 #include <lexls/lexls.h>
 #include <lexls/lsi_runner.h>
 
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
+#include <thread>
 
 using namespace LexLS;
 
@@ -48,10 +53,13 @@ namespace
         uint32_t B = 0, n = 0, nObjL = 0, cap = 0;
         size_t pstride = 0;
         std::vector<uint32_t> maxdim, dims, nfixed, fixed_idx, rank, totalrank;
-        std::vector<double> fixed_val, lod, x, maxabs;
+        std::vector<double> fixed_val, x, maxabs;
+        double *lod = NULL; // B x cap x (n+1), PINNED: it is uploaded every active-set round
         std::vector<uint8_t> fixed_type, ctr_type, skip;
         std::vector<int32_t> sens, objidx;
         int rounds_fs = 0, rounds_sens = 0;
+        double t_up = 0, t_kern = 0, t_down = 0, t_sens = 0; // seconds, reported when LEXLS_LSI_TIMING is set
+        static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
         void create(int device, uint32_t B_, uint32_t n_, uint32_t nObjL_, const uint32_t *maxdim_)
         {
@@ -69,7 +77,8 @@ namespace
             fixed_val.assign((size_t)B * n, 0.0);
             fixed_type.assign((size_t)B * n, CTR_ACTIVE_UB);
             ctr_type.assign((size_t)B * cap, CTR_INACTIVE);
-            lod.assign((size_t)B * pstride, 0.0);
+            if (hipHostMalloc((void **)&lod, 8 * (size_t)B * pstride, hipHostMallocDefault) != hipSuccess) throw Exception("hipHostMalloc failed for the LSI staging buffer");
+            std::memset(lod, 0, 8 * (size_t)B * pstride);
             x.assign((size_t)B * n, 0.0);
             rank.assign((size_t)B * nObjL, 0);
             totalrank.assign(B, 0);
@@ -81,17 +90,22 @@ namespace
         ~BatchCtx()
         {
             if (h) lexls_lse_destroy(h);
+            if (lod) (void)hipHostFree(lod);
         }
 
         /// one batched factorize+solve for every instance with skip == 0
         void factorize_solve()
         {
+            const double t0 = now();
             hip_check(lexls_lse_set_obj_dim(h, dims.data(), 1));
             hip_check(lexls_lse_set_fixed(h, nfixed.data(), fixed_idx.data(), fixed_val.data(), fixed_type.data()));
             hip_check(lexls_lse_set_ctr_type(h, ctr_type.data()));
-            hip_check(lexls_lse_set_problem_host(h, lod.data()));
+            hip_check(lexls_lse_set_problem_host(h, lod));
             hip_check(lexls_lse_set_skip(h, skip.data()));
+            const double t1 = now();
             hip_check(lexls_lse_factorize_solve(h, 1));
+            hip_check(lexls_lse_synchronize(h));
+            const double t2 = now();
             std::vector<double> xn((size_t)B * n);
             std::vector<uint32_t> tr(B), rk((size_t)B * nObjL);
             hip_check(lexls_lse_get_x(h, xn.data()));
@@ -103,14 +117,19 @@ namespace
                     totalrank[b] = tr[b];
                 }
             rounds_fs++;
+            t_up += t1 - t0;
+            t_kern += t2 - t1;
+            t_down += now() - t2;
         }
 
         /// one batched ObjectiveSensitivity: objidx[b] < 0 skips instance b
         void sensitivity(double tolW, double tolC)
         {
+            const double t0 = now();
             hip_check(lexls_lse_sensitivity(h, objidx.data(), 0, tolW, tolC));
             hip_check(lexls_lse_get_sensitivity(h, sens.data(), maxabs.data()));
             rounds_sens++;
+            t_sens += now() - t0;
         }
     };
 
@@ -135,8 +154,7 @@ namespace
         void setParameters(const ParametersLexLSE &p)
         {
             if (p.regularization_type != REGULARIZATION_NONE) throw Exception("lexls_hip: only REGULARIZATION_NONE is implemented on the device path");
-            tol = p.tol_linear_dependence;
-            if (c) hip_check(lexls_lse_set_tolerance(c->h, tol));
+            tol = p.tol_linear_dependence; // the batch handle's tolerance is set once by the batch driver
         }
         void setRegularizationFactor(Index, RealScalar) {}
         void setObjDim(Index *ObjDim_)
@@ -166,7 +184,7 @@ namespace
         void setCtrType(Index ObjIndex, Index CtrIndex, ConstraintActivationType type) { c->ctr_type[(size_t)b * c->cap + first_row[ObjIndex] + CtrIndex] = static_cast<uint8_t>(type); }
         void setCtrStrided(Index CtrIndex, const RealScalar *row, Index stride, RealScalar rhs)
         {
-            double *L = c->lod.data() + (size_t)b * c->pstride;
+            double *L = c->lod + (size_t)b * c->pstride;
             for (Index j = 0; j < c->n; j++) L[CtrIndex + (size_t)j * c->cap] = row[(size_t)j * stride];
             L[CtrIndex + (size_t)c->n * c->cap] = rhs;
         }
@@ -206,6 +224,35 @@ namespace
     };
 
     typedef internal::LexLSI_T<SlotLSE> SlotLSI;
+
+    /// host-side parallel loop over the instances of a batch (they are independent; each touches only its own slot)
+    template <class F>
+    void parallel_for(uint32_t count, F &&f)
+    {
+        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+        const uint32_t nt = std::min<uint32_t>(std::min<uint32_t>(hw, 32u), (count + 15) / 16);
+        if (nt <= 1)
+        {
+            for (uint32_t b = 0; b < count; b++) f(b);
+            return;
+        }
+        std::vector<std::thread> th;
+        std::vector<std::exception_ptr> err(nt);
+        for (uint32_t t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                try
+                {
+                    for (uint32_t b = t; b < count; b += nt) f(b);
+                }
+                catch (...)
+                {
+                    err[t] = std::current_exception();
+                }
+            });
+        for (auto &x : th) x.join();
+        for (auto &e : err)
+            if (e) std::rethrow_exception(e);
+    }
 } // namespace
 
 extern "C"
@@ -229,13 +276,14 @@ extern "C"
                 per_data += (size_t)h_dims[k] * (h_types[k] == 1 ? 2 : nVar + 2);
                 total += h_dims[k];
             }
+            const double t_begin = BatchCtx::now();
             BatchCtx ctx;
             ctx.create(device, batch, nVar, nObj - off, h_dims + off);
+            hip_check(lexls_lse_set_tolerance(ctx.h, par.tol_linear_dependence));
 
             std::vector<std::unique_ptr<SlotLSI>> lsi(batch);
             std::vector<runner::LsiProblem> prob(batch);
-            for (uint32_t b = 0; b < batch; b++)
-            {
+            parallel_for(batch, [&](uint32_t b) {
                 lsi[b].reset(new SlotLSI());
                 lsi[b]->getLexLSE().bind(&ctx, b);
                 prob[b] = {nVar,
@@ -248,7 +296,9 @@ extern "C"
                            h_x0 ? h_x0 + (size_t)b * nVar : NULL};
                 runner::setup(*lsi[b], prob[b], par);
                 lsi[b]->begin();
-            }
+            });
+
+            const double t_setup = BatchCtx::now() - t_begin;
 
             // lock-step rounds: serve every pending factorize+solve in one call, every pending sensitivity in one call
             while (true)
@@ -290,6 +340,10 @@ extern "C"
                                 h_v ? h_v + (size_t)b * total : NULL);
                 if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
             }
+            if (std::getenv("LEXLS_LSI_TIMING"))
+                std::fprintf(stderr, "lexls_lsi_batch_solve: total %.4f s = setup %.4f + upload %.4f + factorize_solve %.4f + download %.4f + sensitivity %.4f + host driver %.4f (%d+%d rounds)\n",
+                             BatchCtx::now() - t_begin, t_setup, ctx.t_up, ctx.t_kern, ctx.t_down, ctx.t_sens,
+                             BatchCtx::now() - t_begin - t_setup - ctx.t_up - ctx.t_kern - ctx.t_down - ctx.t_sens, ctx.rounds_fs, ctx.rounds_sens);
             if (h_rounds2)
             {
                 h_rounds2[0] = ctx.rounds_fs;
