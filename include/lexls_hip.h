@@ -122,8 +122,9 @@ int lexls_lse_device_ptr(lexls_lse_t h, int which, void **d_ptr);
 
 /* name of the kernel variant the last factorize/factorize_solve call dispatched to (diagnostics) */
 const char *lexls_lse_last_kernel(lexls_lse_t h);
-/* diagnostics: force_generic != 0 disables the shape-specialised kernels (parity tests run both paths) */
-int lexls_lse_set_kernel_policy(lexls_lse_t h, int force_generic);
+/* diagnostics (parity tests run every path): policy 0 = automatic dispatch; 1 = only the generic one-workgroup-per-problem kernel;
+ * 2 = automatic, but without the left-looking wave kernel (the register-resident wave kernel serves the small shapes) */
+int lexls_lse_set_kernel_policy(lexls_lse_t h, int policy);
 
 /* ---- inequality problems: the reference's LexLSI active-set driver (lexlsi.h), kept on the host -------------
  * The driver is host C++ (include/lexls/lexlsi.h, same logic as the reference's lexlsi.h/objective.h/workingset.h);

@@ -330,11 +330,11 @@ extern "C"
         HIP_TRY(hipSetDevice(h->device));
         const char *variant = "";
         const LseArgs a     = h->args();
-        if (!h->force_generic && wave_kernel_supports(a, h->max_rows, h->max_level_dim, h->has_fixed))
+        if (h->force_generic != 1 && wave_kernel_supports(a, h->max_rows, h->max_level_dim, h->has_fixed))
         {
-            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->stream, &variant)); // always solves as well
+            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, h->force_generic != 2, h->stream, &variant)); // always solves as well
         }
-        else if (!h->force_generic && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
+        else if (h->force_generic != 1 && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
         {
             if (!h->d_large_state) HIP_TRY(hipMalloc(&h->d_large_state, large_state_bytes(h->batch)));
             if (!h->d_norms) HIP_TRY(hipMalloc((void **)&h->d_norms, 8 * (size_t)h->batch * h->nVar));

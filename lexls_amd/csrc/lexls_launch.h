@@ -19,7 +19,8 @@ namespace lexls
 
     // lqr_small.hip — one wavefront per problem, problem in VGPRs (n+1 <= 64, rows <= 64, level dims <= 16)
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed);
-    hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, hipStream_t s, const char **variant);
+    hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, bool left_looking, hipStream_t s,
+                               const char **variant);
 
     // lqr_large.hip — problems too large for one CU's LDS: one launch per stage, the whole chip per problem
     bool generic_fits_lds(const LseArgs &a, uint32_t max_rows);

@@ -1,0 +1,2 @@
+#include "lqr_lwave_impl.h"
+LEXLS_LWAVE_INSTANCE(launch_lwave_41x12e_f, 41, 12, true, true)

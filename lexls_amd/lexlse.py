@@ -170,7 +170,7 @@ class BatchedLexLSE:
 
     def set_kernel_policy(self, force_generic: bool):
         """diagnostics: route every factorization through the generic kernels"""
-        capi.check(capi.lib().lexls_lse_set_kernel_policy(self._h, C.c_int(1 if force_generic else 0)))
+        capi.check(capi.lib().lexls_lse_set_kernel_policy(self._h, C.c_int(int(force_generic))))
 
     def last_kernel(self) -> str:
         return capi.lib().lexls_lse_last_kernel(self._h).decode()

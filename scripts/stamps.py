@@ -1,15 +1,15 @@
 """Diagnostic: per-phase shader-clock shares of the wave kernel (needs a -DLEXLS_WAVE_STAMPS build via LEXLS_HIP_LIB)."""
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, '.')
 import numpy as np
 import lexls_amd
 from lexls_amd import problems as P
-n, dims, batch = 40, [12]*5, 4096
+n, dims, batch = 40, [12]*5, int(os.environ.get('STAMP_BATCH', '4096'))
 lod = P.lse_batch_fast(20260100, batch, n, dims)
 s = lexls_amd.BatchedLexLSE(batch, n, dims); s.setProblem(lod)
 for _ in range(3): s.factorize_solve(False)
 s.synchronize()
 lam = s.getWorkspace()[:, :11]
-names = ["load", "transpose", "pivot search", "norms+rank", "hh scalars", "apply", "image", "trsm", "gemm", "solve", "output"]
+names = ["load", "transpose/level load", "pivot search", "norms+rank", "hh scalars", "apply", "image", "trsm/eliminate", "gemm", "solve", "output"]
 med = np.median(lam, axis=0); tot = med.sum()
 for nm, v in zip(names, med): print(f"{nm:14s} {v:10.0f} cycles  {100*v/tot:5.1f}%")
-print("total", tot, "cycles/wave (median); kernel", s.last_kernel())
+print("batch", batch, "total", tot, "cycles/wave (median); kernel", s.last_kernel())

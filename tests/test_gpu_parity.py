@@ -41,7 +41,8 @@ def assert_factor_equal(s, ref, dims, nvar):
         np.testing.assert_array_equal(f[b, :, :m[b]], ref["factor"][b, :, :m[b]])
 
 
-BOTH_PATHS = pytest.mark.parametrize("force_generic", [False, True], ids=["specialised", "generic"])
+# kernel policy (include/lexls_hip.h): 0 = automatic dispatch, 1 = generic kernel only, 2 = automatic without the left-looking wave kernel
+BOTH_PATHS = pytest.mark.parametrize("force_generic", [0, 1, 2], ids=["specialised", "generic", "register-resident"])
 
 
 @BOTH_PATHS
@@ -52,7 +53,7 @@ def test_ik_batch_bit_exact(hip, oracle, force_generic):
     assert (ref["rank"] == [12, 12, 12, 4, 0]).all()
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
-    assert s.last_kernel() == ("lqr_generic<64,lds>" if force_generic else "lqr_wave<41,12,exact>")
+    assert s.last_kernel() == {0: "lqr_lwave<41,12,exact>", 1: "lqr_generic<64,lds>", 2: "lqr_wave<41,12,exact>"}[force_generic]
 
 
 @BOTH_PATHS
@@ -104,22 +105,26 @@ def test_ragged_batch(hip, oracle, force_generic):
 
 
 @pytest.mark.parametrize("n,dims", [(63, [16, 16, 16, 16]), (30, [14, 9, 16]), (40, [6] * 5), (5, [12, 12]), (40, [12, 0, 12, 12, 12]), (12, [1, 1, 1, 1, 1, 1, 1, 1])])
-def test_wave_kernel_shapes(hip, oracle, n, dims):
+@pytest.mark.parametrize("policy", [0, 2], ids=["left-looking-if-it-fits", "register-resident"])
+def test_wave_kernel_shapes(hip, oracle, n, dims, policy):
     lod = P.lse_batch(1000 + n, 9, n, dims)
-    s, ref = run_both(hip, oracle, lod, dims, n)
-    assert s.last_kernel().startswith("lqr_wave")
+    s, ref = run_both(hip, oracle, lod, dims, n, force_generic=policy)
+    assert "wave<" in s.last_kernel()
+    if policy == 0 and n <= 40 and max(dims) <= 12:
+        assert s.last_kernel().startswith("lqr_lwave")
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
-def test_wave_kernel_tied_norms(hip, oracle):
+@pytest.mark.parametrize("policy", [0, 2], ids=["left-looking", "register-resident"])
+def test_wave_kernel_tied_norms(hip, oracle, policy):
     """duplicated columns: exact ties in the pivot search must resolve to the first position (maxCoeff semantics)."""
     n, dims = 10, [4, 4, 4]
     lod = P.lse_batch(77, 4, n, dims)
     lod[:, 3, :] = lod[:, 1, :]
     lod[:, 7, :] = lod[:, 1, :]
     lod[:, 5, :] = -lod[:, 2, :]
-    s, ref = run_both(hip, oracle, lod, dims, n)
+    s, ref = run_both(hip, oracle, lod, dims, n, force_generic=policy)
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
@@ -139,7 +144,7 @@ def test_fixed_variables(hip, oracle, force_generic):
     s, ref = run_both(hip, oracle, lod, dims, n, force_generic=force_generic, nfixed=nfixed, fixed_idx=idx, fixed_val=val, fixed_type=typ)
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
-    assert s.last_kernel().startswith("lqr_generic" if force_generic else "lqr_wave")
+    assert s.last_kernel().startswith("lqr_generic" if force_generic == 1 else "lqr_wave")
 
 
 def test_fixed_variables_chained_indices(hip, oracle):
@@ -174,7 +179,7 @@ def test_hbm_resident_variants(hip, oracle, force_generic):
     n, dims = 200, [100, 100, 100, 100]
     lod = P.lse_batch(43, 2, n, dims)
     s, ref = run_both(hip, oracle, lod, dims, n, force_generic=force_generic)
-    assert s.last_kernel() == ("lqr_generic<1024,hbm>" if force_generic else "lqr_large<multi-launch>")
+    assert s.last_kernel() == ("lqr_generic<1024,hbm>" if force_generic == 1 else "lqr_large<multi-launch>")
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
