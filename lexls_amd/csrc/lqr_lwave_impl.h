@@ -141,7 +141,6 @@ namespace lexls
 #pragma unroll
                     for (int r = 0; r < MD; r++) hh[r] = 0.0;
                 }
-                if (k + 1 < nObj && (!exhausted || write_factor) && dims[k + 1] > 0) warm = touch_level(F + dim_rt, (int)dims[k + 1]);
                 STAMP(1)
 
                 // =====================================================================================
@@ -179,9 +178,10 @@ namespace lexls
                         for (int p = 0; p < HB; p++) arow[h * HB + p] = TB[p * MD + (lane < MD ? lane : 0)];
                         wave_lds_fence();
                     }
-#ifndef LEXLS_X_NOTRSM
                     // (2) L <- A R^-1 inside the lane that holds the row (lexlse.h:441-446): p ascending, every later column absorbs
-                    //     L_p at once; R[p][p'] and 1/R_pp are wave-uniform LDS reads that do not depend on the chain
+                    //     L_p at once; R[p][p'] and 1/R_pp are wave-uniform LDS reads.  The pin after every step keeps the scheduler from
+                    //     issuing all 66 reads first (it then spills what it loaded); fetching row p+1 by hand while row p is in use
+                    //     was measured: more registers, no gain at 4 waves/SIMD
 #pragma unroll
                     for (int p = 0; p < MD; p++)
                     {
@@ -192,8 +192,6 @@ namespace lexls
                             if (p2 > p && (FULL || p2 < rq)) arow[p2] = dfma(-arow[p], imgq[p * wq + p2], arow[p2]);
                         pin_values<MD>(arow); // one row of R in registers at a time
                     }
-#endif
-#ifndef LEXLS_X_NOGEMM
                     // (3) hand the multipliers to every lane, half a block at a time, and update the columns behind level q's pivots
                     //     (lexlse.h:448-471): per row an ordered chain over p, exactly as in the right-looking form
                     const bool behind = lane <= n && ((lane == n) || pos >= Fcq + rq);
@@ -231,9 +229,7 @@ namespace lexls
                             pin_values<MD>(hh); // one multiplier column in registers at a time
                         }
                     }
-#endif
                 };
-#ifndef LEXLS_X_NOELIM
                 if (work)
                 {
                     for (int q = 0; q < k; q++)
@@ -242,13 +238,10 @@ namespace lexls
                         if (rq == 0) continue;
                         if (rq == MD && dim_rt == MD)
                             eliminate(std::true_type{}, q);
-#ifndef LEXLS_LWAVE_FULLONLY
                         else
                             eliminate(std::false_type{}, q);
-#endif
                     }
                 }
-#endif
                 STAMP(7)
 
                 // =====================================================================================
@@ -262,6 +255,9 @@ namespace lexls
                     double nrm = 0.0;
 #pragma unroll
                     for (int r = 0; r < MD; r++) nrm = dfma(hh[r], hh[r], nrm);
+                    // the next level's block starts its way into L2 now (after the first use of hh, so that the wait for hh does
+                    // not also wait for these)
+                    if (k + 1 < nObj && dims[k + 1] > 0) warm = touch_level(F + dim_rt, (int)dims[k + 1]);
 
                     double mytau = 0.0; // lane r: tau of the level's row r (0 where no reflector was made, lexlse.h:239,1683)
                     bool go      = true; // wave-uniform: false once the level hit its rank / the columns ran out
@@ -271,6 +267,15 @@ namespace lexls
                         if (!(go && counter < dim)) continue;
                         const int R   = dim - counter; // compile-time when FULL
 
+                        // -- fresh norm and Householder tail norm of EVERY column (lexlse.h:210-211, :241): only the pivot's are used, but
+                        //    the chains do not depend on the pivot search, so they fill its DPP / readlane latencies --
+                        double fr = 0.0, tl = 0.0;
+#pragma unroll
+                        for (int r = 0; r < MD; r++)
+                        {
+                            if (r >= counter) fr = dfma(hh[r], hh[r], fr);
+                            if (r > counter) tl = dfma(hh[r], hh[r], tl);
+                        }
                         // -- pivot: first maximum (by position) of the down-dated norms (lexlse.h:205-206) --
                         const bool cand      = (lane < n) && (pos >= ColIndex);
                         const double key     = cand ? nrm : -INFINITY;
@@ -295,14 +300,6 @@ namespace lexls
                         pl = uni(pl);
                         STAMP(2)
 
-                        // -- fresh norm of the pivot column and the Householder tail norm (lexlse.h:210-211, :241) --
-                        double fr = 0.0, tl = 0.0;
-#pragma unroll
-                        for (int r = 0; r < MD; r++)
-                        {
-                            if (r >= counter) fr = dfma(hh[r], hh[r], fr);
-                            if (r > counter) tl = dfma(hh[r], hh[r], tl);
-                        }
                         const double fresh = rdlane(fr, pl);
                         if (lane == pl) nrm = fresh;
                         if (fresh < a.tol) // rank test on the squared norm (lexlse.h:214)
@@ -359,35 +356,54 @@ namespace lexls
                             wave_lds_fence(); // same wave, LDS is in order: no barrier, no wait for outstanding global traffic
                             double e[MD]; // e[r] = essential entry of row r (absolute row inside the level); wave-uniform values
 #pragma unroll
-                            for (int r = 0; r < MD; r++) e[r] = EB[r];
+                            for (int r = 0; r < MD; r++) e[r] = (r == 0 || r > counter) ? EB[r] : 0.0;
                             const double tau = e[0];
 
-                            // the pivot column now holds beta and the essential part (zeros if degenerate)
-                            if (lane == pl)
+                            if constexpr (write_factor)
                             {
-                                hh[counter] = diag;
-                                if (write_factor) // the essential part is only ever read back from the factor
+                                // the pivot column now holds beta and the essential part (zeros if degenerate)
+                                if (lane == pl)
                                 {
+                                    hh[counter] = diag;
 #pragma unroll
                                     for (int r = 0; r < MD; r++)
                                         if (r > counter) hh[r] = e[r];
                                 }
+                                // apply H to the trailing columns and the RHS (lexlse.h:243-246); zero essentials are no-ops
+                                const bool trailing = ((lane < n) && (pos > ColIndex)) || (lane == n);
+                                if (tau != 0.0 && trailing)
+                                {
+                                    double tmp = 0.0;
+#pragma unroll
+                                    for (int r = 0; r < MD; r++)
+                                        if (r > counter) tmp = dfma(e[r], hh[r], tmp);
+                                    tmp += hh[counter];
+                                    hh[counter] = dfma(-tau, tmp, hh[counter]);
+                                    const double ntau = -tau;
+#pragma unroll
+                                    for (int r = 0; r < MD; r++)
+                                        if (r > counter) hh[r] = dfma(e[r] * ntau, tmp, hh[r]);
+                                }
                             }
-                            // apply H to the trailing columns and the RHS (lexlse.h:243-246); branch-free: zero essentials are no-ops
-                            const bool trailing = ((lane < n) && (pos > ColIndex)) || (lane == n);
-                            if (tau != 0.0 && trailing)
+                            else
                             {
-                                double tmp = 0.0;
+                                // x-only: below row `counter` the columns that are NOT trailing hold multipliers and essential parts, which
+                                // are only ever read back from the factor — so H is applied to every lane (no divergent region, no
+                                // register copies around it) and the pivot's diagonal entry is put in place afterwards
+                                if (uni(tau != 0.0 ? 1 : 0))
+                                {
+                                    double tmp = 0.0;
 #pragma unroll
-                                for (int r = 0; r < MD; r++)
-                                    if (r > counter) tmp = dfma(e[r], hh[r], tmp);
-                                tmp += hh[counter];
-                                hh[counter] = dfma(-tau, tmp, hh[counter]);
-                                double ntau = -tau; // held in a VGPR: "e[r] * ntau" then has a single SGPR operand (one instruction)
-                                asm volatile("" : "+v"(ntau));
+                                    for (int r = 0; r < MD; r++)
+                                        if (r > counter) tmp = dfma(e[r], hh[r], tmp);
+                                    tmp += hh[counter];
+                                    hh[counter] = dfma(-tau, tmp, hh[counter]);
+                                    const double ntau = -tau;
 #pragma unroll
-                                for (int r = 0; r < MD; r++)
-                                    if (r > counter) hh[r] = dfma(e[r] * ntau, tmp, hh[r]);
+                                    for (int r = 0; r < MD; r++)
+                                        if (r > counter) hh[r] = dfma(e[r] * ntau, tmp, hh[r]);
+                                }
+                                if (lane == pl) hh[counter] = diag;
                             }
                             if (lane == counter) mytau = tau; // hh_scalars of this level leave in one store
                         }

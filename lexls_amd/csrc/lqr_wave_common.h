@@ -37,7 +37,8 @@ namespace lexls
         }
 
         /// maximum over the 64 lanes, returned as a wave-uniform value: butterfly inside each 16-lane DPP row, then the four
-        /// row results are combined through SGPRs
+        /// row results are combined through SGPRs (two more DPP steps — row_bcast:15 / row_bcast:31 — need fewer instructions
+        /// but lengthen the dependent chain: measured slower)
         __device__ __forceinline__ double wave_max(double v)
         {
             v = dpp_max<0xB1>(v);  // quad_perm [1,0,3,2]
@@ -45,7 +46,7 @@ namespace lexls
             v = dpp_max<0x141>(v); // row_half_mirror
             v = dpp_max<0x140>(v); // row_mirror
             const double r0 = rdlane(v, 0), r1 = rdlane(v, 16), r2 = rdlane(v, 32), r3 = rdlane(v, 48);
-            return __builtin_fmax(__builtin_fmax(r0, r1), __builtin_fmax(r2, r3));
+            return vmax(vmax(r0, r1), vmax(r2, r3)); // three v_max_f64 (fmax() would canonicalise every operand first)
         }
 
         /// T[idx] for a wave-uniform idx: a scalar branch tree instead of dynamic register indexing
