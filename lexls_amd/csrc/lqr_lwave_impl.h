@@ -467,7 +467,7 @@ namespace lexls
                     for (int r = 0; r < MD; r++)
                         if (r < dim) out[F + r + (size_t)lane * cap] = hh[r];
                 }
-                __syncthreads();
+                wave_lds_fence();
                 STAMP(6)
                 F += dim;
             }
@@ -475,7 +475,7 @@ namespace lexls
             // ---- solve(): block back-substitution on the compact images (lexlse.h:1015-1045) ----
             if (lane <= NC) xs[lane] = 0.0;
             if (lane <= n) phys_s[(lane < n) ? pos : n] = (uint8_t)lane;
-            __syncthreads();
+            wave_lds_fence();
             {
                 int acc = 0;
                 for (int k = nObj; k--;)
@@ -492,7 +492,7 @@ namespace lexls
                         const int slot = __builtin_amdgcn_ds_bpermute(src << 2, (int)((slots >> (8 * k)) & 0xffull)); // slot of ANOTHER lane's column
                         if (lane < acc) offs[lane] = (uint16_t)(slot - Fc);
                     }
-                    __syncthreads();
+                    wave_lds_fence();
                     double s = 0.0;
                     if (lane < rank)
                     {
@@ -510,7 +510,7 @@ namespace lexls
                         if (lane < j) s = dfma(-img[lane * w + j], xj, s);
                     }
                     if (lane < rank) xs[Fc + lane] = s;
-                    __syncthreads();
+                    wave_lds_fence();
                     acc += rank;
                 }
             }
