@@ -8,7 +8,11 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 using namespace LexLS;
@@ -225,34 +229,104 @@ namespace
 
     typedef internal::LexLSI_T<SlotLSE> SlotLSI;
 
-    /// host-side parallel loop over the instances of a batch (they are independent; each touches only its own slot)
-    template <class F>
-    void parallel_for(uint32_t count, F &&f)
+    /// Persistent host worker pool for the per-instance work of a lock-step batch (the instances are independent; each touches only
+    /// its own LexLSI object and its own slot of the staging arrays).  Created once per lexls_lsi_batch_solve call: the active-set
+    /// rounds are short (~1 ms of host work for 1024 instances), so threads must not be spawned per round.
+    class WorkerPool
     {
-        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-        const uint32_t nt = std::min<uint32_t>(std::min<uint32_t>(hw, 32u), (count + 15) / 16);
-        if (nt <= 1)
+    public:
+        explicit WorkerPool(uint32_t workers)
         {
-            for (uint32_t b = 0; b < count; b++) f(b);
-            return;
+            for (uint32_t i = 0; i < workers; i++) th.emplace_back([this]() { loop(); });
         }
-        std::vector<std::thread> th;
-        std::vector<std::exception_ptr> err(nt);
-        for (uint32_t t = 0; t < nt; t++)
-            th.emplace_back([&, t]() {
+        ~WorkerPool()
+        {
+            {
+                std::lock_guard<std::mutex> lk(m);
+                stop = true;
+            }
+            cv_start.notify_all();
+            for (auto &t : th) t.join();
+        }
+        static uint32_t default_workers(uint32_t batch)
+        {
+            const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+            const uint32_t nt = std::min<uint32_t>(std::min<uint32_t>(hw, 16u), batch / 64);
+            return nt > 1 ? nt - 1 : 0; // the calling thread works too
+        }
+        /// f(b) for b in [0, count); returns when all are done; rethrows the first exception
+        void run(uint32_t count_, const std::function<void(uint32_t)> &f)
+        {
+            if (th.empty() || count_ < 128)
+            {
+                for (uint32_t b = 0; b < count_; b++) f(b);
+                return;
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                job     = &f;
+                count   = count_;
+                pending = static_cast<uint32_t>(th.size());
+                next.store(0);
+                err = nullptr;
+                gen++;
+            }
+            cv_start.notify_all();
+            work();
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&]() { return pending == 0; });
+            job = nullptr;
+            if (err) std::rethrow_exception(err);
+        }
+
+    private:
+        void work()
+        {
+            const uint32_t chunk = 16;
+            for (;;)
+            {
+                const uint32_t b0 = next.fetch_add(chunk);
+                if (b0 >= count) break;
+                const uint32_t b1 = std::min(count, b0 + chunk);
                 try
                 {
-                    for (uint32_t b = t; b < count; b += nt) f(b);
+                    for (uint32_t b = b0; b < b1; b++) (*job)(b);
                 }
                 catch (...)
                 {
-                    err[t] = std::current_exception();
+                    std::lock_guard<std::mutex> lk(m);
+                    if (!err) err = std::current_exception();
                 }
-            });
-        for (auto &x : th) x.join();
-        for (auto &e : err)
-            if (e) std::rethrow_exception(e);
-    }
+            }
+        }
+        void loop()
+        {
+            uint64_t seen = 0;
+            for (;;)
+            {
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv_start.wait(lk, [&]() { return stop || gen != seen; });
+                    if (stop) return;
+                    seen = gen;
+                }
+                work();
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    if (--pending == 0) cv_done.notify_one();
+                }
+            }
+        }
+        std::vector<std::thread> th;
+        std::mutex m;
+        std::condition_variable cv_start, cv_done;
+        const std::function<void(uint32_t)> *job = nullptr;
+        uint32_t count = 0, pending = 0;
+        std::atomic<uint32_t> next{0};
+        uint64_t gen = 0;
+        bool stop    = false;
+        std::exception_ptr err;
+    };
 } // namespace
 
 extern "C"
@@ -283,7 +357,8 @@ extern "C"
 
             std::vector<std::unique_ptr<SlotLSI>> lsi(batch);
             std::vector<runner::LsiProblem> prob(batch);
-            parallel_for(batch, [&](uint32_t b) {
+            WorkerPool pool(WorkerPool::default_workers(batch));
+            pool.run(batch, [&](uint32_t b) {
                 lsi[b].reset(new SlotLSI());
                 lsi[b]->getLexLSE().bind(&ctx, b);
                 prob[b] = {nVar,
@@ -315,8 +390,9 @@ extern "C"
                 if (any_fs)
                 {
                     ctx.factorize_solve();
-                    for (uint32_t b = 0; b < batch; b++)
+                    pool.run(batch, [&](uint32_t b) {
                         if (!ctx.skip[b]) lsi[b]->advance();
+                    });
                 }
                 for (uint32_t b = 0; b < batch; b++)
                 {
@@ -327,8 +403,9 @@ extern "C"
                 if (any_sens)
                 {
                     ctx.sensitivity(par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
-                    for (uint32_t b = 0; b < batch; b++)
+                    pool.run(batch, [&](uint32_t b) {
                         if (ctx.objidx[b] >= 0) lsi[b]->advance();
+                    });
                 }
                 if (!any_fs && !any_sens) throw Exception("lexls_lsi_batch_solve: an instance is alive but requests nothing");
             }

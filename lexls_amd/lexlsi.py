@@ -71,19 +71,37 @@ def lsi_solve_dat(path: str, nvar: int, one_based=True, use_active_guess=False, 
     return dict(x=x, solution=sol, info=dict(zip(INFO_KEYS, info.tolist())))
 
 
-def lsi_batch_solve(nvar: int, problems, active_guess=None, x0=None, device: int = 0, **params):
-    """Lock-step batch of LexLSI problems of one structure (BASELINE configs[4]).  `problems`: list of objective lists
-    (same dims / types); `active_guess`: per problem list of per-objective flag arrays, or None; `x0`: (batch, nvar) or None."""
+class PackedBatch:
+    """A batch of same-structure LexLSI problems in the flat layout lexls_lsi_batch_solve takes (include/lexls_hip.h): build it once
+    with pack_batch() when the same constraint data is solved repeatedly (warm starts) — flattening Python objective lists costs far
+    more than the solve."""
+
+    def __init__(self, nvar, dims, types, data, var_index):
+        self.nvar, self.dims, self.types, self.data, self.var_index = nvar, dims, types, data, var_index
+        self.batch, self.total = data.shape[0], int(dims.sum())
+
+
+def pack_batch(nvar: int, problems) -> PackedBatch:
     flat = [flatten(nvar, objs) for objs in problems]
     dims, types = flat[0][0], flat[0][1]
     for f in flat:
         if not (np.array_equal(f[0], dims) and np.array_equal(f[1], types)):
             raise ValueError("all problems of a batch must share dims and objective types")
-    batch, total = len(problems), int(dims.sum())
     data = np.ascontiguousarray(np.stack([f[2] for f in flat]))
     var_index = np.ascontiguousarray(np.stack([f[3] for f in flat])) if flat[0][3].size else None
+    return PackedBatch(nvar, dims, types, data, var_index)
+
+
+def lsi_batch_solve(nvar: int, problems, active_guess=None, x0=None, device: int = 0, **params):
+    """Lock-step batch of LexLSI problems of one structure (BASELINE configs[4]).  `problems`: list of objective lists
+    (same dims / types) or a PackedBatch; `active_guess`: per problem list of per-objective flag arrays, a (batch, total) uint8
+    array, or None; `x0`: (batch, nvar) or None."""
+    pk = problems if isinstance(problems, PackedBatch) else pack_batch(nvar, problems)
+    dims, types, data, var_index, batch, total = pk.dims, pk.types, pk.data, pk.var_index, pk.batch, pk.total
     guess = None
-    if active_guess is not None:
+    if isinstance(active_guess, np.ndarray):
+        guess = np.ascontiguousarray(active_guess.reshape(batch, total), np.uint8)
+    elif active_guess is not None:
         guess = np.ascontiguousarray(np.stack([np.concatenate([np.asarray(g, np.uint8) for g in ag]) for ag in active_guess]))
     x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
     x, info = np.zeros((batch, nvar)), np.zeros((batch, 6), np.int32)
