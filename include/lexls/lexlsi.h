@@ -144,6 +144,9 @@ namespace LexLS
 
             /// lexlsi.h:350-435: general objective, data = [A, lb, ub]; rows with |lb-ub| < 1e-15 and a
             /// non-zero normal are activated as equalities
+            /// see Objective::setDataOffset (batched device backend only)
+            void setDataOffset(Index ObjIndex, size_t off) { objectives[ObjIndex].setDataOffset(off); }
+
             void setData(Index ObjIndex, const dMatrixConstRef &data)
             {
                 if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");

@@ -52,6 +52,7 @@ namespace LexLS
                 else
                 {
                     lsi.setData(k, dMatrixConstRef(p.data + off, dims[k], p.nVar + 2));
+                    lsi.setDataOffset(k, off);
                 }
                 off += objective_size(p, k);
             }

@@ -5,6 +5,8 @@
 // it follows.  Dense products are evaluated row-by-row with a left-to-right fma chain (the
 // reference leaves the order to Eigen's GEMV).
 #pragma once
+#include <type_traits>
+#include <utility>
 
 #include <lexls/typedefs.h>
 #include <lexls/workingset.h>
@@ -13,6 +15,27 @@ namespace LexLS
 {
     namespace internal
     {
+        /// detects LSE::setCtrIndexed(Index row, size_t first_element, Index leading_dimension, unsigned use_ub) -> bool
+        template <class LSE>
+        struct has_setCtrIndexed
+        {
+            template <class T>
+            static auto test(int) -> decltype(std::declval<T &>().setCtrIndexed(Index(), size_t(), Index(), 0u), std::true_type());
+            template <class>
+            static std::false_type test(...);
+            typedef decltype(test<LSE>(0)) type;
+        };
+        template <class LSE>
+        inline bool try_setCtrIndexed(LSE &l, Index row, size_t first_element, Index ld, unsigned use_ub, std::true_type)
+        {
+            return l.setCtrIndexed(row, first_element, ld, use_ub);
+        }
+        template <class LSE>
+        inline bool try_setCtrIndexed(LSE &, Index, size_t, Index, unsigned, std::false_type)
+        {
+            return false;
+        }
+
         class Objective
         {
         public:
@@ -238,7 +261,11 @@ namespace LexLS
                         else if (type == CTR_ACTIVE_LB)
                             rhs = data(c, nVar);
                         lexlse.setCtrType(ObjIndex, k, type);
-                        lexlse.setCtrStrided(counter, &data(c, 0), data.rows(), rhs);
+                        // a backend that keeps the constraint data resident (batched device path) only needs
+                        // to know WHICH row and which bound; everybody else gets the numbers
+                        if (!try_setCtrIndexed(lexlse, counter, data_offset + c, data.rows(), type == CTR_ACTIVE_LB ? 0u : 1u,
+                                               typename has_setCtrIndexed<LSE>::type()))
+                            lexlse.setCtrStrided(counter, &data(c, 0), data.rows(), rhs);
                         counter++;
                     }
                     lexlse.setRegularizationFactor(ObjIndex, regularization_factor);
@@ -349,6 +376,9 @@ namespace LexLS
 
             /// objective.h:793-815
             void setData(const dMatrixConstRef &data_) { data = data_; }
+            /// position of this objective's [A | lb | ub] block (column-major, first element) inside the caller's flat data of
+            /// the problem; only meaningful to backends that gather rows from a resident copy of that flat data
+            void setDataOffset(size_t off) { data_offset = off; }
             void setData(const Index *var_index_, const dMatrixConstRef &data_)
             {
                 for (Index k = 0; k < nCtr; k++) var_index(k) = var_index_[k];
@@ -405,6 +435,7 @@ namespace LexLS
             ObjectiveType obj_type;
             iVectorType var_index;
             dMatrixType data;
+            size_t data_offset = 0;
             WorkingSet working_set;
             dVectorType v;
             dVectorType dv;

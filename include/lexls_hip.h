@@ -86,6 +86,14 @@ int lexls_lse_set_skip(lexls_lse_t h, const uint8_t *h_skip);
 int lexls_lse_set_problem_host(lexls_lse_t h, const double *h_lod);
 /* zero-copy variant: the caller's device buffer becomes the (read-only) input of later factorizations */
 int lexls_lse_set_problem_device(lexls_lse_t h, const double *d_lod);
+/* Device-side assembly of the equality problems of a LexLSI iteration — replaces the row copies of Objective::formLexLSE
+ * (objective.h:434-494).  set_constraint_data keeps, per problem, `per_problem` doubles of constraint data
+ * resident on the device (the objectives' [A | lb | ub] blocks back to back, each column-major — the flat layout of lexls_lsi_solve);
+ * gather_problem then builds every non-skipped problem's LOD from two batch x cap uint32 arrays: row r of the LOD is
+ * [ data[src + j*ld], j < nVar | data[src + (nVar + ub)*ld] ] with src = h_row_src[r], ld = h_row_ld[r] & 0x7fffffff,
+ * ub = h_row_ld[r] >> 31 (0: right-hand side = lb, 1: ub — objective.h:472-486); rows with h_row_ld[r] == 0 are left alone. */
+int lexls_lse_set_constraint_data(lexls_lse_t h, const double *h_data, uint64_t per_problem);
+int lexls_lse_gather_problem(lexls_lse_t h, const uint32_t *h_row_src, const uint32_t *h_row_ld);
 
 /* ---- the hot path ------------------------------------------------------------------------------ */
 

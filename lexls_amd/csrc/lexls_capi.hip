@@ -48,6 +48,9 @@ struct lexls_lse_s
     const char *last_kernel;
 
     double *d_in_owned;
+    double *d_cdata;          // resident constraint data of the batch (lexls_lse_set_constraint_data)
+    uint64_t cdata_per_problem;
+    uint32_t *d_row_src, *d_row_ld;
     const double *d_in;
     double *d_fac, *d_x, *d_hh, *d_v, *d_lambda, *d_maxabs, *d_scratch, *d_fixed_val;
     uint32_t *d_perm, *d_rank, *d_fcol, *d_totalrank, *d_dims, *d_nfixed, *d_fixed_idx;
@@ -137,6 +140,9 @@ extern "C"
         h->factor_valid = h->factor_in_hbm = false;
         h->last_kernel = "";
         h->d_in_owned  = nullptr;
+        h->d_cdata     = nullptr;
+        h->cdata_per_problem = 0;
+        h->d_row_src = h->d_row_ld = nullptr;
         h->d_in        = nullptr;
         h->d_scratch   = nullptr;
 
@@ -183,7 +189,7 @@ extern "C"
         (void)hipSetDevice(h->device);
         void *ptrs[] = {h->d_in_owned, h->d_fac,     h->d_x,      h->d_hh,        h->d_v,        h->d_lambda,     h->d_maxabs,
                         h->d_scratch,  h->d_fixed_val, h->d_perm,   h->d_rank,      h->d_fcol,     h->d_totalrank,  h->d_dims,
-                        h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx,      h->d_skip,       h->d_large_state, h->d_norms};
+                        h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx,      h->d_skip,       h->d_large_state, h->d_norms, h->d_cdata, h->d_row_src, h->d_row_ld};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         delete h;
@@ -309,6 +315,54 @@ extern "C"
         if (!h->d_in_owned) HIP_TRY(hipMalloc((void **)&h->d_in_owned, bytes));
         HIP_TRY(hipMemcpyAsync(h->d_in_owned, h_lod, bytes, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        h->d_in         = h->d_in_owned;
+        h->factor_valid = false;
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_constraint_data(lexls_lse_t h, const double *h_data, uint64_t per_problem)
+    {
+        CHECK_HANDLE(h);
+        if (!h_data || per_problem == 0) return fail(LEXLS_ERR_INVALID, "set_constraint_data: null / empty");
+        HIP_TRY(hipSetDevice(h->device));
+        const size_t bytes = 8 * (size_t)h->batch * per_problem;
+        if (h->d_cdata && h->cdata_per_problem != per_problem)
+        {
+            HIP_TRY(hipFree(h->d_cdata));
+            h->d_cdata = nullptr;
+        }
+        if (!h->d_cdata) HIP_TRY(hipMalloc((void **)&h->d_cdata, bytes));
+        h->cdata_per_problem = per_problem;
+        HIP_TRY(hipMemcpyAsync(h->d_cdata, h_data, bytes, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_gather_problem(lexls_lse_t h, const uint32_t *h_row_src, const uint32_t *h_row_ld)
+    {
+        CHECK_HANDLE(h);
+        if (!h_row_src || !h_row_ld) return fail(LEXLS_ERR_INVALID, "gather_problem: null");
+        if (!h->d_cdata) return fail(LEXLS_ERR_INVALID, "gather_problem: call lexls_lse_set_constraint_data first");
+        const size_t B = h->batch, cap = h->cap;
+        // every element a row refers to must lie inside the problem's resident block (the kernel does not check)
+        for (size_t i = 0; i < B * cap; i++)
+        {
+            const uint64_t ld = h_row_ld[i] & 0x7fffffffu;
+            if (ld && (uint64_t)h_row_src[i] + (uint64_t)(h->nVar + 1) * ld >= h->cdata_per_problem)
+                return fail(LEXLS_ERR_INVALID, "gather_problem: row reference outside the constraint data");
+        }
+        HIP_TRY(hipSetDevice(h->device));
+        if (!h->d_row_src) HIP_TRY(hipMalloc((void **)&h->d_row_src, 4 * B * cap));
+        if (!h->d_row_ld) HIP_TRY(hipMalloc((void **)&h->d_row_ld, 4 * B * cap));
+        if (!h->d_in_owned)
+        {
+            HIP_TRY(hipMalloc((void **)&h->d_in_owned, 8 * B * h->problem_elems()));
+            HIP_TRY(hipMemsetAsync(h->d_in_owned, 0, 8 * B * h->problem_elems(), h->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(h->d_row_src, h_row_src, 4 * B * cap, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_row_ld, h_row_ld, 4 * B * cap, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(launch_gather_rows(h->args(), h->d_cdata, h->cdata_per_problem, h->d_row_src, h->d_row_ld, h->d_in_owned, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream)); // the host arrays may be reused by the caller
         h->d_in         = h->d_in_owned;
         h->factor_valid = false;
         return LEXLS_OK;

@@ -61,6 +61,8 @@ namespace
         double *lod = NULL; // B x cap x (n+1), PINNED: it is uploaded every active-set round
         std::vector<uint8_t> fixed_type, ctr_type, skip;
         std::vector<int32_t> sens, objidx;
+        std::vector<uint32_t> row_src, row_ld; // B x cap: where each LOD row comes from in the resident constraint data (device gather)
+        bool gather = false;                   // constraint data resident on the device: only row references travel per round
         int rounds_fs = 0, rounds_sens = 0;
         double t_up = 0, t_kern = 0, t_down = 0, t_sens = 0; // seconds, reported when LEXLS_LSI_TIMING is set
         static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -90,6 +92,8 @@ namespace
             sens.assign((size_t)B * 3, 0);
             objidx.assign(B, -1);
             maxabs.assign(B, 0.0);
+            row_src.assign((size_t)B * cap, 0);
+            row_ld.assign((size_t)B * cap, 0);
         }
         ~BatchCtx()
         {
@@ -104,8 +108,11 @@ namespace
             hip_check(lexls_lse_set_obj_dim(h, dims.data(), 1));
             hip_check(lexls_lse_set_fixed(h, nfixed.data(), fixed_idx.data(), fixed_val.data(), fixed_type.data()));
             hip_check(lexls_lse_set_ctr_type(h, ctr_type.data()));
-            hip_check(lexls_lse_set_problem_host(h, lod));
             hip_check(lexls_lse_set_skip(h, skip.data()));
+            if (gather)
+                hip_check(lexls_lse_gather_problem(h, row_src.data(), row_ld.data()));
+            else
+                hip_check(lexls_lse_set_problem_host(h, lod));
             const double t1 = now();
             hip_check(lexls_lse_factorize_solve(h, 1));
             hip_check(lexls_lse_synchronize(h));
@@ -171,6 +178,15 @@ namespace
                 r += ObjDim_[k];
             }
             nVarFixedInit = 0;
+            if (c->gather) std::fill(c->row_ld.begin() + (size_t)b * c->cap, c->row_ld.begin() + (size_t)(b + 1) * c->cap, 0u);
+        }
+        /// row `CtrIndex` of the LOD = row of the resident constraint data (Objective::formLexLSE); false: not available, send numbers
+        bool setCtrIndexed(Index CtrIndex, size_t first_element, Index ld, unsigned use_ub)
+        {
+            if (!c->gather) return false;
+            c->row_src[(size_t)b * c->cap + CtrIndex] = static_cast<uint32_t>(first_element);
+            c->row_ld[(size_t)b * c->cap + CtrIndex]  = static_cast<uint32_t>(ld) | (use_ub ? 0x80000000u : 0u);
+            return true;
         }
         void setFixedVariablesCount(Index nf)
         {
@@ -354,6 +370,11 @@ extern "C"
             BatchCtx ctx;
             ctx.create(device, batch, nVar, nObj - off, h_dims + off);
             hip_check(lexls_lse_set_tolerance(ctx.h, par.tol_linear_dependence));
+            if (per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING")) // (diagnostic switch: assemble on the host, stage over PCIe)
+            {
+                hip_check(lexls_lse_set_constraint_data(ctx.h, h_data, per_data));
+                ctx.gather = true;
+            }
 
             std::vector<std::unique_ptr<SlotLSI>> lsi(batch);
             std::vector<runner::LsiProblem> prob(batch);

@@ -881,6 +881,38 @@ namespace lexls
         return hipGetLastError();
     }
 
+    namespace
+    {
+        /// LOD <- rows of the resident constraint data (Objective::formLexLSE, objective.h:434-494, done on the device): one
+        /// workgroup per problem; consecutive threads write consecutive rows of one LOD column (coalesced stores)
+        __global__ __launch_bounds__(256) void gather_rows_kernel(LseArgs a, const double *cdata, uint64_t per_problem, const uint32_t *row_src,
+                                                                  const uint32_t *row_ld, double *dst)
+        {
+            const uint32_t b = blockIdx.x;
+            if (a.skip && a.skip[b]) return;
+            const uint32_t n = a.nVar, cap = a.cap;
+            const double *src   = cdata + (size_t)b * per_problem;
+            double *out         = dst + (size_t)b * cap * (n + 1);
+            const uint32_t *rs  = row_src + (size_t)b * cap;
+            const uint32_t *rl  = row_ld + (size_t)b * cap;
+            for (uint32_t idx = threadIdx.x; idx < cap * (n + 1); idx += blockDim.x)
+            {
+                const uint32_t r = idx % cap, j = idx / cap;
+                const uint32_t l = rl[r];
+                if (l == 0) continue;
+                const uint32_t ld = l & 0x7fffffffu, ub = l >> 31;
+                out[idx] = src[rs[r] + (size_t)(j < n ? j : n + ub) * ld];
+            }
+        }
+    } // namespace
+
+    hipError_t launch_gather_rows(const LseArgs &a, const double *d_cdata, uint64_t per_problem, const uint32_t *d_row_src, const uint32_t *d_row_ld,
+                                  double *d_dst, hipStream_t s)
+    {
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(a.batch), dim3(256), 0, s, a, d_cdata, per_problem, d_row_src, d_row_ld, d_dst);
+        return hipGetLastError();
+    }
+
     hipError_t launch_residual(const LseArgs &a, hipStream_t s)
     {
         const size_t lds = 8 * ((size_t)a.cap + 2);

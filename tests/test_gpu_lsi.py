@@ -98,3 +98,35 @@ def test_lock_step_batch_warm_started(hip, oracle):
         o = oracle.lsi_run(n, problems[b], active_guess=guess[b], x0=base[b]["x"])
         assert r["info"][b] == o["info"], b
         np.testing.assert_array_equal(r["x"][b], o["x"])
+
+
+def test_lock_step_device_gather_equals_host_staging(hip, oracle, monkeypatch):
+    """the lock-step driver keeps the constraint data resident and gathers the active rows on the device
+    (lexls_lse_gather_problem); assembling the same problems on the host and staging them over PCIe must give identical
+    trajectories and bit-identical results."""
+    n, dims, batch = 40, [12] * 5, 16
+    pk = lexlsi.pack_batch(n, [P.lsi_problem(1300 + b, n, dims) for b in range(batch)])
+    dev = lexlsi.lsi_batch_solve(n, pk)
+    monkeypatch.setenv("LEXLS_LSI_HOST_STAGING", "1")
+    host = lexlsi.lsi_batch_solve(n, pk)
+    assert dev["info"] == host["info"] and dev["rounds"] == host["rounds"]
+    np.testing.assert_array_equal(dev["x"], host["x"])
+    np.testing.assert_array_equal(dev["active"], host["active"])
+    np.testing.assert_array_equal(dev["v"], host["v"])
+
+
+def test_gather_problem_rejects_out_of_range_rows(hip):
+    import ctypes as C
+    from lexls_amd import capi
+    s = hip.BatchedLexLSE(2, 4, [3, 2])
+    data = np.zeros((2, 5 * 6))
+    L = capi.lib()
+    capi.check(L.lexls_lse_set_constraint_data(s._h, data.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(30)))
+    src = np.zeros((2, 5), np.uint32)
+    ld = np.zeros((2, 5), np.uint32)
+    ld[1, 0] = 5
+    src[1, 0] = 6  # 6 + (4+1)*5 = 31 >= 30
+    rc = L.lexls_lse_gather_problem(s._h, src.ctypes.data_as(C.POINTER(C.c_uint32)), ld.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert rc != 0 and b"outside" in L.lexls_last_error()
+    src[1, 0] = 4  # last element touched: 4 + 5*5 = 29
+    capi.check(L.lexls_lse_gather_problem(s._h, src.ctypes.data_as(C.POINTER(C.c_uint32)), ld.ctypes.data_as(C.POINTER(C.c_uint32))))
