@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="problems per GPU")
     ap.add_argument("--keep-factor", action="store_true", help="also write the factor to HBM (40,360 B/problem variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the real thing); gloo only to rehearse the multi-rank control flow on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -47,10 +49,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank if args.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    coll_device = "cuda" if args.dist_backend == "nccl" else "cpu"  # where the few collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend="gloo")
 
     import lexls_amd
     from lexls_amd import problems as P
@@ -62,7 +69,7 @@ def main():
     lod_dev = torch.from_numpy(lod_host).cuda()
 
     stream = torch.cuda.Stream()
-    solver = lexls_amd.BatchedLexLSE(batch, NVAR, DIMS, device=local_rank)
+    solver = lexls_amd.BatchedLexLSE(batch, NVAR, DIMS, device=device_index)
     solver.set_stream(stream.cuda_stream)
     solver.setProblemDevice(lod_dev.data_ptr())
 
@@ -86,14 +93,14 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream: average launch duration
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # correctness guard outside the timed region: solution checksum per shard, gathered on every rank
     x = solver.get_x()
     ranks_ok = bool((solver.getRanks()[0] == np.array([12, 12, 12, 4, 0])).all())
-    checksum = torch.tensor([float(np.abs(x).sum()), float(ranks_ok)], dtype=torch.float64, device="cuda")
+    checksum = torch.tensor([float(np.abs(x).sum()), float(ranks_ok)], dtype=torch.float64, device=coll_device)
     if world > 1:
         gathered = [torch.zeros_like(checksum) for _ in range(world)]
         dist.all_gather(gathered, checksum)
