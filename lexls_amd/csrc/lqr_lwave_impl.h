@@ -46,12 +46,18 @@ namespace lexls
 #define LEXLS_LWAVE_OCC 4
 #endif
         template <int NC, int MD, bool EXACT, bool WF>
-        __global__ __launch_bounds__(64, LEXLS_LWAVE_OCC) void lqr_lwave_kernel(LseArgs a, uint32_t img_doubles)
+// waves (= problems) per workgroup: the waves never synchronise with each other — fewer, fatter workgroups only shorten the dispatch ramp
+#ifndef LEXLS_LWAVE_WPB
+#define LEXLS_LWAVE_WPB 4
+#endif
+        __global__ __launch_bounds__(64 * LEXLS_LWAVE_WPB, LEXLS_LWAVE_OCC) void lqr_lwave_kernel(LseArgs a, uint32_t img_doubles, uint32_t lds_doubles_per_wave)
         {
             constexpr bool write_factor = WF;
             extern __shared__ double smem[];
-            const int lane       = threadIdx.x;
-            const uint32_t b     = blockIdx.x;
+            const int lane       = threadIdx.x & 63;
+            const uint32_t wib   = threadIdx.x >> 6; // wave in block: owns its own slice of the dynamic LDS
+            const uint32_t b     = blockIdx.x * LEXLS_LWAVE_WPB + wib;
+            if (b >= a.batch) return; // no barrier anywhere in this kernel
             const int n          = EXACT ? NC - 1 : (int)a.nVar;
             const int cap        = (int)a.cap;
             const int nObj       = (int)a.nObj;
@@ -59,7 +65,7 @@ namespace lexls
             if (a.skip && a.skip[b]) return; // uniform per wave
 
             // ---- LDS carve-up (see launch_lwave_t for the byte count) ----
-            double *IMG      = smem;                                       // img_doubles: compact images of the levels
+            double *IMG      = smem + (size_t)wib * lds_doubles_per_wave;  // img_doubles: compact images of the levels
             double *xs       = IMG + img_doubles;                          // NC+1: solution by position (back-substitution only)
             double *EX       = xs;                                         // 2*16 : lane exchange while the levels are processed (aliases xs)
             double *EB       = xs + 16;
@@ -486,28 +492,35 @@ namespace lexls
                     const double *img = IMG + uni((int)meta[4 * k + 2]);
                     const int w       = n + 1 - Fc;
                     const int c0      = Fc + rank; // == first_col_index of the next level with rank > 0
-                    // later column swaps also permuted this level's T block: final position -> physical column -> image column
-                    {
-                        const int src  = (lane < acc) ? (int)phys_s[c0 + lane] : 0;
-                        const int slot = __builtin_amdgcn_ds_bpermute(src << 2, (int)((slots >> (8 * k)) & 0xffull)); // slot of ANOTHER lane's column
-                        if (lane < acc) offs[lane] = (uint16_t)(slot - Fc);
-                    }
-                    wave_lds_fence();
-                    double s = 0.0;
-                    if (lane < rank)
-                    {
-                        const double *row = img + lane * w;
-                        s                 = row[n - Fc];
+                    // later column swaps also permuted this level's T block: final position -> physical column -> image column.
+                    // Lane j resolves the image column of solved position c0+j and holds x at that position; both reach the row
+                    // lanes through SGPRs, so the ordered chain below only waits for its own LDS stream
+                    const int src    = (lane < acc) ? (int)phys_s[c0 + lane] : 0;
+                    const int myoff  = __builtin_amdgcn_ds_bpermute(src << 2, (int)((slots >> (8 * k)) & 0xffull)) - Fc; // slot of ANOTHER lane's column
+                    const double xv  = (lane < acc) ? xs[c0 + lane] : 0.0;
+                    const double *row = img + (lane < rank ? lane : 0) * w;
+                    // everything the triangular part needs is independent of the chain: fetch it up front
+                    double col[MD];
+#pragma unroll
+                    for (int j = 0; j < MD; j++) col[j] = (j < rank && lane < j) ? row[j] : 0.0;
+                    const double dg = row[lane < rank ? lane : 0];
+                    double s        = row[n - Fc];
 #pragma unroll 4
-                        for (int j = 0; j < acc; j++) s = dfma(-row[offs[j]], xs[c0 + j], s);
-                    }
-                    for (int j = rank; j--;)
+                    for (int j = 0; j < acc; j++)
                     {
-                        const double rjj = img[j * w + j]; // uniform address
+                        const int oj    = __builtin_amdgcn_readlane(myoff, j);
+                        const double xj = rdlane(xv, j);
+                        s               = dfma(-row[oj], xj, s);
+                    }
+#pragma unroll
+                    for (int j = MD; j--;)
+                    {
+                        if (j >= rank) continue;
+                        const double rjj = rdlane(dg, j);
                         const double sj  = rdlane(s, j);
                         const double xj  = sj / rjj;
                         if (lane == j) s = xj;
-                        if (lane < j) s = dfma(-img[lane * w + j], xj, s);
+                        if (lane < j) s = dfma(-col[j], xj, s);
                     }
                     if (lane < rank) xs[Fc + lane] = s;
                     wave_lds_fence();
@@ -570,14 +583,16 @@ namespace lexls
         hipError_t launch_lwave_t(const LseArgs &a, hipStream_t s)
         {
             const uint32_t img = lwave_image_doubles(a.nVar, a.nObj, MD);
-            const size_t lds   = 8 * ((size_t)img + 2 * (NC + 1) + 6 * MD) + 4 * 4 * (size_t)a.nObj + 2 * 64 + 3 * 64;
+            const size_t lds1  = (8 * ((size_t)img + 2 * (NC + 1) + 6 * MD) + 4 * 4 * (size_t)a.nObj + 2 * 64 + 3 * 64 + 15) & ~(size_t)15; // one wave
+            const size_t lds   = lds1 * LEXLS_LWAVE_WPB;
             if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
             if (lds > 64 * 1024)
             {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_lwave_kernel<NC, MD, EXACT, WF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
             }
-            hipLaunchKernelGGL((lqr_lwave_kernel<NC, MD, EXACT, WF>), dim3(a.batch), dim3(64), lds, s, a, img);
+            const uint32_t blocks = (a.batch + LEXLS_LWAVE_WPB - 1) / LEXLS_LWAVE_WPB;
+            hipLaunchKernelGGL((lqr_lwave_kernel<NC, MD, EXACT, WF>), dim3(blocks), dim3(64 * LEXLS_LWAVE_WPB), lds, s, a, img, (uint32_t)(lds1 / 8));
             return hipGetLastError();
         }
     } // namespace
