@@ -10,7 +10,7 @@
 //
 // Differences a caller can observe: Eigen types are replaced by the containers of typedefs.h
 // (dMatrixConstRef is a (ptr, rows, cols, ld) view); setCtr takes a pointer to nVar doubles;
-// regularization types other than REGULARIZATION_NONE and solveLeastNorm_2/_3/solveGeneralNorm throw.
+// regularization types other than REGULARIZATION_NONE, solveLeastNorm_3 and solveGeneralNorm throw.
 #pragma once
 
 #include <lexls/typedefs.h>
@@ -159,8 +159,13 @@ namespace LexLS
                 check(lexls_lse_solve_least_norm(h));
                 check(lexls_lse_get_x(h, x.data()));
             }
-            void solveLeastNorm_2() { throw Exception("lexls_hip: solveLeastNorm_2 has no device path (use solveLeastNorm_1)"); }
-            void solveLeastNorm_3() { throw Exception("lexls_hip: solveLeastNorm_3 has no device path (use solveLeastNorm_1)"); }
+            /// lexlse.h:1138-1213
+            void solveLeastNorm_2()
+            {
+                check(lexls_lse_solve_least_norm_2(h));
+                check(lexls_lse_get_x(h, x.data()));
+            }
+            void solveLeastNorm_3() { throw Exception("lexls_hip: solveLeastNorm_3 needs the Tikhonov null-space basis (regularization family: no device path); use solveLeastNorm_1 or _2"); }
 
             /// lexlse.h:611-762; on return getWorkspace().head(nVarFixed + nLambda) = [lambda_fixed; lambda]
             bool ObjectiveSensitivity(Index ObjIndex, Index &CtrIndex2Remove, int &ObjIndex2Remove, RealScalar tol_wrong_sign_lambda,

@@ -106,6 +106,8 @@ int lexls_lse_solve(lexls_lse_t h);
 int lexls_lse_factorize_solve(lexls_lse_t h, int keep_factor);
 /* replaces solveLeastNorm_1() (lexlse.h:1052-1131, Givens sweep); needs a factorization */
 int lexls_lse_solve_least_norm(lexls_lse_t h);
+/* replaces solveLeastNorm_2() (lexlse.h:1138-1213, normal equations of the free variables + Cholesky); needs a factorization */
+int lexls_lse_solve_least_norm_2(lexls_lse_t h);
 /* replaces get_v() (lexlse.h:1560-1582); needs a factorization */
 int lexls_lse_residual(lexls_lse_t h);
 /* replaces bool ObjectiveSensitivity(ObjIndex, CtrIndex2Remove, ObjIndex2Remove, tolWrong, tolCorrect,

@@ -434,6 +434,15 @@ extern "C"
         return LEXLS_OK;
     }
 
+    int lexls_lse_solve_least_norm_2(lexls_lse_t h)
+    {
+        if (int rc = need_factor(h, "lexls_lse_solve_least_norm_2")) return rc;
+        HIP_TRY(hipSetDevice(h->device));
+        if (!h->d_scratch) HIP_TRY(hipMalloc((void **)&h->d_scratch, 8 * (size_t)h->batch * 2 * h->nVar * h->nVar));
+        HIP_TRY(launch_leastnorm2(h->args(), h->stream));
+        return LEXLS_OK;
+    }
+
     int lexls_lse_residual(lexls_lse_t h)
     {
         if (int rc = need_factor(h, "lexls_lse_residual")) return rc;

@@ -799,6 +799,153 @@ namespace lexls
             __syncthreads();
             for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
         }
+        /// solveLeastNorm_2 (lexlse.h:1138-1213): least-norm solution through the normal equations of the free variables.
+        /// One 64-lane workgroup per problem on the factor in HBM; [R T | rhs] and D live in the per-problem scratch.
+        /// Arithmetic order as oracle/lexlse_oracle.h::solveLeastNorm_2 (bit-identical).
+        template <int NT>
+        __global__ __launch_bounds__(NT) void leastnorm2_kernel(LseArgs a)
+        {
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.x, tid = threadIdx.x;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const double *W  = a.fac + (size_t)b * cap * (n + 1);
+            const size_t ld  = cap;
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            const uint32_t *rk = a.rank + (size_t)b * nObj, *fc = a.fcol + (size_t)b * nObj;
+            const uint32_t *perm = a.perm + (size_t)b * n;
+            const uint32_t nf    = a.nfixed ? a.nfixed[b] : 0;
+
+            uint32_t nVarRank = 0;
+            for (uint32_t k = 0; k < nObj; k++) nVarRank += rk[k];
+            const uint32_t nVarFree = n - (nVarRank + nf);
+            const uint32_t ncol     = nVarRank + nVarFree;
+            const size_t lr         = nVarRank ? nVarRank : 1;
+            double *RT              = a.scratch + (size_t)b * 2 * n * n; // nVarRank x (ncol + 1), column-major, ld = nVarRank
+            double *D               = RT + lr * (ncol + 1);              // nVarFree x nVarFree, column-major (lower part used)
+            const size_t ldd        = nVarFree ? nVarFree : 1;
+            double *d               = smem;     // n
+            double *xs              = smem + n; // n
+
+            for (uint32_t e = tid; e < lr * (ncol + 1); e += NT) RT[e] = 0.0;
+            for (uint32_t i = tid; i < n; i += NT)
+            {
+                d[i]  = 0.0;
+                xs[i] = (i < nf) ? a.fixed_val[(size_t)b * n + i] : 0.0;
+            }
+            __syncthreads();
+            {
+                uint32_t counter = 0, col_dim = ncol, F = 0;
+                for (uint32_t k = 0; k < nObj; k++) // compact [R T | rhs] copy (lexlse.h:1166-1177)
+                {
+                    const uint32_t rank = rk[k], Fc = fc[k];
+                    for (uint32_t e = tid; e < rank * col_dim; e += NT)
+                    {
+                        const uint32_t i = e % rank, j = e / rank;
+                        if (j >= i) RT[counter + i + (counter + j) * lr] = W[F + i + (Fc + j) * ld];
+                    }
+                    for (uint32_t i = tid; i < rank; i += NT) RT[counter + i + ncol * lr] = W[F + i + n * ld];
+                    counter += rank;
+                    col_dim -= rank;
+                    F += dims[k];
+                }
+            }
+            __syncthreads();
+            // T <- R^-1 [T | rhs]: one column per lane, column-oriented back-substitution (lexlse.h:1180)
+            for (uint32_t c = nVarRank + tid; c <= ncol; c += NT)
+                for (uint32_t j = nVarRank; j--;)
+                {
+                    const double t = RT[j + c * lr] / RT[j + j * lr];
+                    RT[j + c * lr] = t;
+                    for (uint32_t i = 0; i < j; i++) RT[i + c * lr] = dfma(-RT[i + j * lr], t, RT[i + c * lr]);
+                }
+            __syncthreads();
+            // D = I + T^T T (lower), d = T^T t_rhs (lexlse.h:1182-1188)
+            for (uint32_t e = tid; e < nVarFree * nVarFree; e += NT)
+            {
+                const uint32_t i = e % nVarFree, j = e / nVarFree;
+                if (i < j) continue;
+                double acc = 0.0;
+                for (uint32_t k = 0; k < nVarRank; k++) acc = dfma(RT[k + (nVarRank + i) * lr], RT[k + (nVarRank + j) * lr], acc);
+                D[i + j * ldd] = (i == j) ? acc + 1.0 : acc;
+            }
+            for (uint32_t j = tid; j < nVarFree; j += NT)
+            {
+                double acc = 0.0;
+                for (uint32_t k = 0; k < nVarRank; k++) acc = dfma(RT[k + (nVarRank + j) * lr], RT[k + ncol * lr], acc);
+                d[j] = acc;
+            }
+            __syncthreads();
+            for (uint32_t j = 0; j < nVarFree; j++) // Cholesky, left-looking by columns (lexlse.h:1190)
+            {
+                if (tid == 0)
+                {
+                    double sjj = D[j + j * ldd];
+                    for (uint32_t k = 0; k < j; k++) sjj = dfma(-D[j + k * ldd], D[j + k * ldd], sjj);
+                    D[j + j * ldd] = sqrt(sjj);
+                }
+                __syncthreads();
+                const double ljj = D[j + j * ldd];
+                for (uint32_t i = j + 1 + tid; i < nVarFree; i += NT)
+                {
+                    double v = D[i + j * ldd];
+                    for (uint32_t k = 0; k < j; k++) v = dfma(-D[i + k * ldd], D[j + k * ldd], v);
+                    D[i + j * ldd] = v / ljj;
+                }
+                __syncthreads();
+            }
+            for (uint32_t j = 0; j < nVarFree; j++) // L y = d
+            {
+                if (tid == 0) d[j] = d[j] / D[j + j * ldd];
+                __syncthreads();
+                const double yj = d[j];
+                for (uint32_t i = j + 1 + tid; i < nVarFree; i += NT) d[i] = dfma(-D[i + j * ldd], yj, d[i]);
+                __syncthreads();
+            }
+            for (uint32_t j = nVarFree; j--;) // L^T z = y
+            {
+                if (tid == 0) d[j] = d[j] / D[j + j * ldd];
+                __syncthreads();
+                const double zj = d[j];
+                for (uint32_t i = tid; i < j; i += NT) d[i] = dfma(-D[j + i * ldd], zj, d[i]);
+                __syncthreads();
+            }
+            for (uint32_t i = tid; i < nVarFree; i += NT) xs[nf + nVarRank + i] = d[i];
+            __syncthreads();
+            {
+                uint32_t counter = 0, F = 0;
+                for (uint32_t k = 0; k < nObj; k++) // x_rank = rhs - T_LOD x_free (lexlse.h:1193-1204)
+                {
+                    const uint32_t rank = rk[k];
+                    for (uint32_t i = tid; i < rank; i += NT)
+                    {
+                        double acc = 0.0;
+                        for (uint32_t c = 0; c < nVarFree; c++) acc = dfma(W[F + i + (size_t)(nVarRank + nf + c) * ld], xs[nf + nVarRank + c], acc);
+                        xs[nf + counter + i] = W[F + i + n * ld] - acc;
+                    }
+                    counter += rank;
+                    F += dims[k];
+                }
+            }
+            __syncthreads();
+            for (uint32_t j = nVarRank; j--;) // R^-1 on x.segment(nVarFixed, nVarRank) (lexlse.h:1205)
+            {
+                if (tid == 0) xs[nf + j] = xs[nf + j] / RT[j + j * lr];
+                __syncthreads();
+                const double xj = xs[nf + j];
+                for (uint32_t i = tid; i < j; i += NT) xs[nf + i] = dfma(-RT[i + j * lr], xj, xs[nf + i]);
+                __syncthreads();
+            }
+            if (tid == 0)
+                for (uint32_t k = a.totalrank[b]; k--;) // x = P x
+                {
+                    const uint32_t pk = perm[k];
+                    const double t    = xs[k];
+                    xs[k]             = xs[pk];
+                    xs[pk]            = t;
+                }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
+        }
     } // namespace
 
     // ---------------------------------------------------------------------------------------------
@@ -940,6 +1087,16 @@ namespace lexls
         hipError_t e = set_lds(leastnorm_kernel<64>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((leastnorm_kernel<64>), dim3(a.batch), dim3(64), lds, s, a);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_leastnorm2(const LseArgs &a, hipStream_t s)
+    {
+        const size_t lds = 8 * (2 * (size_t)a.nVar + 4);
+        if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
+        hipError_t e = set_lds(leastnorm2_kernel<64>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((leastnorm2_kernel<64>), dim3(a.batch), dim3(64), lds, s, a);
         return hipGetLastError();
     }
 } // namespace lexls

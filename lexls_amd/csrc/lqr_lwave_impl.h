@@ -505,7 +505,6 @@ namespace lexls
                     for (int j = 0; j < MD; j++) col[j] = (j < rank && lane < j) ? row[j] : 0.0;
                     const double dg = row[lane < rank ? lane : 0];
                     double s        = row[n - Fc];
-#pragma unroll 4
                     for (int j = 0; j < acc; j++)
                     {
                         const int oj    = __builtin_amdgcn_readlane(myoff, j);

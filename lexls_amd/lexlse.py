@@ -103,6 +103,10 @@ class BatchedLexLSE:
     def solveLeastNorm_1(self):
         capi.check(capi.lib().lexls_lse_solve_least_norm(self._h))
 
+    def solveLeastNorm_2(self):
+        """lexlse.h:1138-1213: least-norm solution through the normal equations of the free variables"""
+        capi.check(capi.lib().lexls_lse_solve_least_norm_2(self._h))
+
     def ObjectiveSensitivity(self, ObjIndex, tol_wrong_sign_lambda=1e-8, tol_correct_sign_lambda=1e-12):
         """ObjIndex: int (all problems) or per-problem int32 array (negative = skip). Returns (found, ctr, obj, maxAbs)."""
         if np.isscalar(ObjIndex):

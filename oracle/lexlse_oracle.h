@@ -3,7 +3,7 @@
 //
 // Scalar CPU restatement of the reference's equality solver LexLS::internal::LexLSE
 // (/root/reference/include/lexls/lexlse.h), REGULARIZATION_NONE path: factorize() :117-506,
-// solve() :1015-1045, solveLeastNorm_1() :1052-1131, ObjectiveSensitivity() :511-602 and :611-762,
+// solve() :1015-1045, solveLeastNorm_1() :1052-1131, solveLeastNorm_2() :1138-1213, ObjectiveSensitivity() :511-602 and :611-762,
 // findDescentDirection() :866-987, get_v() :1560-1582, setters :1381-1552, initialize() :1672-1693.
 //
 // PINNING STATUS.  The reference executes every arithmetic statement inside Eigen 3, which is not
@@ -435,6 +435,96 @@ namespace lexls_oracle
             }
 
             for (Index i = 0; i < ncol; i++) x(nVarFixed + i) = rhs[i]; // :1129
+            apply_permutation();
+        }
+
+        /// lexlse.h:1138-1213 (least-norm solution through the normal equations of the free variables):
+        /// T <- R^-1 [T | rhs];  (I + T^T T) y = T^T t_rhs by Cholesky;  x_free = y;  x_rank = R^-1 (rhs - T_LOD x_free).
+        /// Arithmetic contract of the pieces Eigen leaves unspecified: products T^T T, T^T t and T_LOD x_free are ascending fma chains
+        /// from 0; Cholesky is the left-looking column form (s = D_jj - sum_k L_jk^2 accumulated into s, L_ij = (D_ij - sum_k L_ik L_jk) / L_jj);
+        /// both triangular solves with L are column-oriented with a true division, like back_substitute().
+        void solveLeastNorm_2()
+        {
+            Index nVarRank = 0;
+            for (Index k = 0; k < nObj; k++) nVarRank += obj_info[k].rank;
+            const Index nVarFree = nVar - (nVarRank + nVarFixed);
+            const Index ncol     = nVarRank + nVarFree;
+
+            dMatrixType RT(nVarRank, ncol + 1); // [R T | rhs]
+            Index counter = 0, col_dim = ncol;
+            for (Index k = 0; k < nObj; k++) // :1166-1177
+            {
+                const Index F = obj_info[k].first_row_index, Fc = obj_info[k].first_col_index, rank = obj_info[k].rank;
+                for (Index i = 0; i < rank; i++)
+                {
+                    for (Index j = i; j < col_dim; j++) RT(counter + i, counter + j) = LOD(F + i, Fc + j);
+                    RT(counter + i, ncol) = LOD(F + i, nVar);
+                }
+                counter += rank;
+                col_dim -= rank;
+            }
+            for (Index c = nVarRank; c <= ncol; c++) // :1180  T <- R^-1 T (the rhs column included), column by column
+                for (Index j = nVarRank; j--;)
+                {
+                    RT(j, c) = RT(j, c) / RT(j, j);
+                    for (Index i = 0; i < j; i++) RT(i, c) = std::fma(-RT(i, j), RT(j, c), RT(i, c));
+                }
+            dMatrixType D(nVarFree, nVarFree);
+            std::vector<double> d(nVarFree, 0.0);
+            for (Index j = 0; j < nVarFree; j++) // :1182-1188
+            {
+                for (Index i = j; i < nVarFree; i++)
+                {
+                    double acc = 0.0;
+                    for (Index k = 0; k < nVarRank; k++) acc = std::fma(RT(k, nVarRank + i), RT(k, nVarRank + j), acc);
+                    D(i, j) = acc;
+                }
+                D(j, j) += 1.0;
+                double acc = 0.0;
+                for (Index k = 0; k < nVarRank; k++) acc = std::fma(RT(k, nVarRank + j), RT(k, ncol), acc);
+                d[j] = acc;
+            }
+            for (Index j = 0; j < nVarFree; j++) // :1190 LLT
+            {
+                double sjj = D(j, j);
+                for (Index k = 0; k < j; k++) sjj = std::fma(-D(j, k), D(j, k), sjj);
+                D(j, j) = std::sqrt(sjj);
+                for (Index i = j + 1; i < nVarFree; i++)
+                {
+                    double v = D(i, j);
+                    for (Index k = 0; k < j; k++) v = std::fma(-D(i, k), D(j, k), v);
+                    D(i, j) = v / D(j, j);
+                }
+            }
+            for (Index j = 0; j < nVarFree; j++) // :1191 L y = d
+            {
+                d[j] = d[j] / D(j, j);
+                for (Index i = j + 1; i < nVarFree; i++) d[i] = std::fma(-D(i, j), d[j], d[i]);
+            }
+            for (Index j = nVarFree; j--;) // L^T z = y
+            {
+                d[j] = d[j] / D(j, j);
+                for (Index i = 0; i < j; i++) d[i] = std::fma(-D(j, i), d[j], d[i]);
+            }
+            for (Index i = 0; i < nVarFree; i++) x(nVarFixed + nVarRank + i) = d[i];
+
+            counter = 0;
+            for (Index k = 0; k < nObj; k++) // :1193-1204
+            {
+                const Index F = obj_info[k].first_row_index, rank = obj_info[k].rank;
+                for (Index i = 0; i < rank; i++)
+                {
+                    double acc = 0.0;
+                    for (Index c = 0; c < nVarFree; c++) acc = std::fma(LOD(F + i, nVarRank + nVarFixed + c), x(nVarFixed + nVarRank + c), acc);
+                    x(nVarFixed + counter + i) = LOD(F + i, nVar) - acc;
+                }
+                counter += rank;
+            }
+            for (Index j = nVarRank; j--;) // :1205 R^-1 on x.segment(nVarFixed, nVarRank)
+            {
+                x(nVarFixed + j) = x(nVarFixed + j) / RT(j, j);
+                for (Index i = 0; i < j; i++) x(nVarFixed + i) = std::fma(-RT(i, j), x(nVarFixed + j), x(nVarFixed + i));
+            }
             apply_permutation();
         }
 

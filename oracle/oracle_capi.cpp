@@ -28,7 +28,7 @@ namespace
         const double *fixed_val;   // batch x nVar
         const uint8_t *fixed_type; // batch x nVar
         const uint8_t *ctr_type;   // batch x cap or NULL
-        int solve_option;          // 0 basic solution, 1 least-norm (Givens), <0 factorize only
+        int solve_option;          // 0 basic solution, 1 least-norm (Givens), 2 least-norm (normal equations), <0 factorize only
         int sens_obj;              // -1: none, else the level passed to ObjectiveSensitivity
         double tol_wrong, tol_correct;
         // outputs (any may be NULL)
@@ -67,6 +67,7 @@ namespace
         lse.factorize();
         if (a.solve_option == 0) lse.solve();
         else if (a.solve_option == 1) lse.solveLeastNorm_1();
+        else if (a.solve_option == 2) lse.solveLeastNorm_2();
 
         if (a.x)
             for (uint32_t i = 0; i < n; i++) a.x[static_cast<size_t>(b) * n + i] = lse.get_x()(i);

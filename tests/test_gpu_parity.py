@@ -284,6 +284,38 @@ def test_least_norm_givens(hip, oracle):
         assert np.abs(Vt[30:] @ s.get_x()[b]).max() < 1e-10
 
 
+def test_least_norm_normal_equations(hip, oracle):
+    """solveLeastNorm_2 (lexlse.h:1138-1213): bit-identical to the oracle; equal to the Givens variant within the tolerance the
+    reference's MATLAB suites use (1e-10); with fixed variables and a rank-deficient level as well."""
+    n, dims, batch = 40, [6] * 5, 8
+    lod = P.lse_batch(61, batch, n, dims)
+    ref = oracle.lse_run(lod, dims, n, solve_option=2)
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.setProblem(lod)
+    s.factorize()
+    s.solveLeastNorm_2()
+    x2 = s.get_x().copy()
+    np.testing.assert_array_equal(x2, ref["x"])
+    s.solveLeastNorm_1()
+    assert np.abs(s.get_x() - x2).max() < 1e-10
+    # fixed variables + a duplicated row (rank deficiency)
+    n, dims, batch = 12, [3, 4, 2], 5
+    lod = P.lse_batch(62, batch, n, dims)
+    lod[:, :, 4] = lod[:, :, 3]
+    nfixed = np.full(batch, 2, np.uint32)
+    idx = np.zeros((batch, n), np.uint32)
+    idx[:, :2] = [5, 1]
+    val = np.zeros((batch, n))
+    val[:, :2] = P.normal(63, 2)
+    ref = oracle.lse_run(lod, dims, n, solve_option=2, nfixed=nfixed, fixed_idx=idx, fixed_val=val)
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.fixVariables(nfixed, idx, val)
+    s.setProblem(lod)
+    s.factorize()
+    s.solveLeastNorm_2()
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+
+
 def test_full_size_batch_4096(hip, oracle):
     """BASELINE.json configs[2]: batch 4096 x (n=40, 5x12) against the oracle on all problems."""
     n, dims, batch = 40, [12] * 5, 4096

@@ -156,3 +156,19 @@ def test_flop_and_byte_model():
     assert P.algorithmic_bytes(40, [12] * 5) == 20000
     assert P.algorithmic_bytes(512, [256] * 4) == 4206592
     assert P.algorithmic_bytes(40, [12] * 5, write_factor=True) == 40360
+
+
+def test_least_norm_normal_equations_equals_givens_and_pinv(oracle):
+    """solveLeastNorm_2 (lexlse.h:1138-1213) against solveLeastNorm_1 and against the minimum-norm solution numpy computes for an
+    under-determined single-level problem (tolerance of the reference's MATLAB suites: 1e-10)."""
+    n, dims = 40, [6] * 5
+    lod = P.lse_batch(61, 4, n, dims)
+    x1 = oracle.lse_run(lod, dims, n, solve_option=1)["x"]
+    x2 = oracle.lse_run(lod, dims, n, solve_option=2)["x"]
+    assert np.abs(x1 - x2).max() < 1e-10
+    n, dims = 9, [5]
+    lod = P.lse_batch(5, 3, n, dims)
+    x2 = oracle.lse_run(lod, dims, n, solve_option=2)["x"]
+    for b in range(3):
+        A, rhs = lod[b, :n, :].T, lod[b, n, :]
+        assert np.abs(np.linalg.pinv(A) @ rhs - x2[b]).max() < 1e-10
