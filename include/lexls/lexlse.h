@@ -185,10 +185,41 @@ namespace LexLS
                 }
                 return s3[0] != 0;
             }
-            /// lexlse.h:511-602 (deactivate_first_wrong_sign): not on the device path
-            void ObjectiveSensitivity(Index, RealScalar, RealScalar, std::vector<ConstraintInfo> &)
+            /// lexlse.h:511-602 (all wrong-sign multipliers, for deactivate_first_wrong_sign).  The multipliers come from the device
+            /// (same kernel as the overload above); the scan of lexlse.h:866-910 runs here, in the reference's order (level ObjIndex,
+            /// then ObjIndex-1 ... 0, then the fixed variables) and with its quirk for the fixed variables (it reads Lambda/ObjDim where
+            /// LambdaFixed/nVarFixed are meant, lexlse.h:599-600; clipped to nVarFixed as in oracle/lexlse_oracle.h).  The
+            /// CORRECT_SIGN_OF_LAMBDA marks of THIS overload then replace the ones the kernel made.
+            void ObjectiveSensitivity(Index ObjIndex, RealScalar tol_wrong_sign_lambda, RealScalar tol_correct_sign_lambda,
+                                      std::vector<ConstraintInfo> &ctr_wrong_sign)
             {
-                throw Exception("lexls_hip: the 'collect all wrong-sign multipliers' overload has no device path (deactivate_first_wrong_sign)");
+                if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");
+                check(lexls_lse_sensitivity(h, NULL, static_cast<int32_t>(ObjIndex), tol_wrong_sign_lambda, tol_correct_sign_lambda));
+                std::vector<double> lam(nVar + cap);
+                check(lexls_lse_get_lambda(h, lam.data()));
+                for (Index i = 0; i < nVar + cap && i < dWorkspace.size(); i++) dWorkspace(i) = lam[i];
+                const double *Lambda = lam.data() + nVarFixed;
+                auto scan = [&](int obj, bool fixed, Index first, Index count) {
+                    for (Index k = 0; k < count; k++)
+                    {
+                        const Index ind = fixed ? k : first + k;
+                        uint8_t &type   = fixed ? fixed_type[ind] : ctr_type[ind];
+                        if (type == CTR_ACTIVE_EQ || type == CORRECT_SIGN_OF_LAMBDA) continue;
+                        double a = Lambda[ind];
+                        if (type == CTR_ACTIVE_LB) a = -a;
+                        if (a > tol_correct_sign_lambda)
+                            type = static_cast<uint8_t>(CORRECT_SIGN_OF_LAMBDA);
+                        else if (a < -tol_wrong_sign_lambda)
+                            ctr_wrong_sign.push_back(ConstraintInfo(obj, static_cast<int>(k)));
+                    }
+                };
+                for (Index k = ObjIndex + 1; k--;) scan(static_cast<int>(k), false, first_row[k], dims[k]);
+                if (nVarFixed > 0)
+                {
+                    scan(-1, true, 0, std::min(dims[0], nVarFixed));
+                    check(lexls_lse_set_fixed_type(h, fixed_type.data()));
+                }
+                check(lexls_lse_set_ctr_type(h, ctr_type.data()));
             }
 
             /// lexlse.h:1560-1582

@@ -77,6 +77,9 @@ int lexls_lse_set_obj_dim(lexls_lse_t h, const uint32_t *h_dims, int per_problem
  * number of fixed variables, then (batch x nVar, first nfixed[b] entries used) index / value /
  * ConstraintActivationType.  h_nfixed == NULL clears all fixed variables. */
 int lexls_lse_set_fixed(lexls_lse_t h, const uint32_t *h_nfixed, const uint32_t *h_index, const double *h_value, const uint8_t *h_type);
+/* activation types of the fixed variables only (batch x nVar bytes, fixVariable order, lexlse.h:1381-1419); unlike lexls_lse_set_fixed
+ * it keeps the factorization valid — the types only matter to ObjectiveSensitivity (lexlse.h:866-987 marks CORRECT_SIGN_OF_LAMBDA) */
+int lexls_lse_set_fixed_type(lexls_lse_t h, const uint8_t *h_type);
 /* replaces setCtrType (lexlse.h:1548): batch x cap ConstraintActivationType bytes, row order of LOD */
 int lexls_lse_set_ctr_type(lexls_lse_t h, const uint8_t *h_types);
 /* lock-step batches (batched LexLSI): problems whose flag is non-zero are left untouched by the next

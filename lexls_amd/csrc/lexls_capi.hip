@@ -281,6 +281,16 @@ extern "C"
         return LEXLS_OK;
     }
 
+    int lexls_lse_set_fixed_type(lexls_lse_t h, const uint8_t *h_type)
+    {
+        CHECK_HANDLE(h);
+        if (!h_type) return fail(LEXLS_ERR_INVALID, "set_fixed_type: null");
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpyAsync(h->d_fixed_type, h_type, (size_t)h->batch * h->nVar, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return LEXLS_OK; // activation types only matter to the dual solve: the factorization stays valid
+    }
+
     int lexls_lse_set_ctr_type(lexls_lse_t h, const uint8_t *h_types)
     {
         CHECK_HANDLE(h);

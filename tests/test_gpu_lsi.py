@@ -130,3 +130,17 @@ def test_gather_problem_rejects_out_of_range_rows(hip):
     assert rc != 0 and b"outside" in L.lexls_last_error()
     src[1, 0] = 4  # last element touched: 4 + 5*5 = 29
     capi.check(L.lexls_lse_gather_problem(s._h, src.ctypes.data_as(C.POINTER(C.c_uint32)), ld.ctypes.data_as(C.POINTER(C.c_uint32))))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_deactivate_first_wrong_sign_matches_oracle_driver(hip, oracle, seed):
+    """ParametersLexLSI::deactivate_first_wrong_sign routes the removal search through the 'collect all wrong-sign multipliers'
+    overload (lexlse.h:511-602): multipliers from the device, scan on the host — trajectory identical to the oracle-backed driver."""
+    n, dims = 20, [6, 5, 5, 6]
+    objs = P.lsi_problem(300 + seed, n, dims)
+    d = lexlsi.lsi_solve(n, objs, deactivate_first_wrong_sign=1)
+    o = oracle.lsi_run(n, objs, deactivate_first_wrong_sign=1)
+    assert d["info"] == o["info"]
+    for a, b in zip(d["active"], o["active"]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(d["x"], o["x"])
