@@ -65,6 +65,11 @@ int lexls_lse_destroy(lexls_lse_t h);
 /* all later work of this handle runs on `hip_stream` (a hipStream_t; NULL = null stream) */
 int lexls_lse_set_stream(lexls_lse_t h, void *hip_stream);
 int lexls_lse_synchronize(lexls_lse_t h);
+/* Deferred synchronisation (lock-step LexLSI batches issue ~10 small copies per active-set round): while on, the set_* / gather / get_*
+ * calls only ENQUEUE their copies on the handle's stream.  The caller then owes two things the default mode does not ask for: host input
+ * arrays stay untouched, and host output arrays are only read, after the next lexls_lse_synchronize(); and the arrays should be pinned
+ * (hipHostMalloc) — with pageable memory the runtime stages the copies and nothing is gained. */
+int lexls_lse_set_deferred_sync(lexls_lse_t h, int on);
 
 /* ---- problem definition ----------------------------------------------------------------------- */
 

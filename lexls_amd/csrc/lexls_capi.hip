@@ -48,6 +48,10 @@ struct lexls_lse_s
     const char *last_kernel;
 
     double *d_in_owned;
+    bool deferred_sync;       // lexls_lse_set_deferred_sync: copies are enqueued, not waited for
+    uint32_t *h_dims_pinned;
+    hipEvent_t dims_event;
+    bool dims_event_pending;
     double *d_cdata;          // resident constraint data of the batch (lexls_lse_set_constraint_data)
     uint64_t cdata_per_problem;
     uint32_t *d_row_src, *d_row_ld;
@@ -141,6 +145,10 @@ extern "C"
         h->last_kernel = "";
         h->d_in_owned  = nullptr;
         h->d_cdata     = nullptr;
+        h->deferred_sync = false;
+        h->h_dims_pinned = nullptr;
+        h->dims_event = nullptr;
+        h->dims_event_pending = false;
         h->cdata_per_problem = 0;
         h->d_row_src = h->d_row_ld = nullptr;
         h->d_in        = nullptr;
@@ -192,6 +200,8 @@ extern "C"
                         h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx,      h->d_skip,       h->d_large_state, h->d_norms, h->d_cdata, h->d_row_src, h->d_row_ld};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
+        if (h->h_dims_pinned) (void)hipHostFree(h->h_dims_pinned);
+        if (h->dims_event) (void)hipEventDestroy(h->dims_event);
         delete h;
         return LEXLS_OK;
     }
@@ -211,6 +221,18 @@ extern "C"
         return LEXLS_OK;
     }
 
+    int lexls_lse_set_deferred_sync(lexls_lse_t h, int on)
+    {
+        CHECK_HANDLE(h);
+        if (!on && h->deferred_sync) // leaving the mode: everything enqueued so far completes first
+        {
+            HIP_TRY(hipSetDevice(h->device));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        h->deferred_sync = on != 0;
+        return LEXLS_OK;
+    }
+
     int lexls_lse_set_tolerance(lexls_lse_t h, double tol)
     {
         CHECK_HANDLE(h);
@@ -222,7 +244,21 @@ extern "C"
     {
         CHECK_HANDLE(h);
         if (!h_dims) return fail(LEXLS_ERR_INVALID, "set_obj_dim: null dims");
-        std::vector<uint32_t> d((size_t)h->batch * h->nObj);
+        const size_t nd = (size_t)h->batch * h->nObj;
+        std::vector<uint32_t> d_tmp;
+        uint32_t *d = nullptr;
+        if (h->deferred_sync) // the copy below is not waited for: its source must outlive this call and be DMA-able
+        {
+            HIP_TRY(hipSetDevice(h->device));
+            if (!h->h_dims_pinned) HIP_TRY(hipHostMalloc((void **)&h->h_dims_pinned, 4 * nd, hipHostMallocDefault));
+            else if (h->dims_event_pending) HIP_TRY(hipEventSynchronize(h->dims_event)); // the previous copy out of this buffer is done
+            d = h->h_dims_pinned;
+        }
+        else
+        {
+            d_tmp.resize(nd);
+            d = d_tmp.data();
+        }
         uint32_t max_rows = 0, max_level = 0;
         h->level_max.assign(h->nObj, 0);
         for (uint32_t b = 0; b < h->batch; b++)
@@ -240,8 +276,15 @@ extern "C"
             if (m > max_rows) max_rows = m;
         }
         HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipMemcpyAsync(h->d_dims, d.data(), 4 * d.size(), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream)); // d is a temporary
+        HIP_TRY(hipMemcpyAsync(h->d_dims, d, 4 * nd, hipMemcpyHostToDevice, h->stream));
+        if (h->deferred_sync)
+        {
+            if (!h->dims_event) HIP_TRY(hipEventCreateWithFlags(&h->dims_event, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(h->dims_event, h->stream));
+            h->dims_event_pending = true;
+        }
+        else
+            HIP_TRY(hipStreamSynchronize(h->stream)); // d is a temporary
         h->max_rows      = max_rows ? max_rows : 1;
         h->max_level_dim = max_level;
         h->dims_set     = true;
@@ -276,7 +319,7 @@ extern "C"
             HIP_TRY(hipMemcpyAsync(h->d_fixed_type, h_type, B * n, hipMemcpyHostToDevice, h->stream));
         else
             HIP_TRY(hipMemsetAsync(h->d_fixed_type, CTR_ACTIVE_UB, B * n, h->stream)); // default of fixVariable, lexlse.h:1381
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
         h->has_fixed = any;
         return LEXLS_OK;
     }
@@ -287,7 +330,7 @@ extern "C"
         if (!h_type) return fail(LEXLS_ERR_INVALID, "set_fixed_type: null");
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipMemcpyAsync(h->d_fixed_type, h_type, (size_t)h->batch * h->nVar, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
         return LEXLS_OK; // activation types only matter to the dual solve: the factorization stays valid
     }
 
@@ -297,7 +340,7 @@ extern "C"
         if (!h_types) return fail(LEXLS_ERR_INVALID, "set_ctr_type: null");
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipMemcpyAsync(h->d_ctr_type, h_types, (size_t)h->batch * h->cap, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
         return LEXLS_OK;
     }
 
@@ -311,7 +354,7 @@ extern "C"
         }
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipMemcpyAsync(h->d_skip, h_skip, (size_t)h->batch, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
         h->has_skip = true;
         return LEXLS_OK;
     }
@@ -324,7 +367,7 @@ extern "C"
         const size_t bytes = 8 * (size_t)h->batch * h->problem_elems();
         if (!h->d_in_owned) HIP_TRY(hipMalloc((void **)&h->d_in_owned, bytes));
         HIP_TRY(hipMemcpyAsync(h->d_in_owned, h_lod, bytes, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
         h->d_in         = h->d_in_owned;
         h->factor_valid = false;
         return LEXLS_OK;
@@ -372,7 +415,7 @@ extern "C"
         HIP_TRY(hipMemcpyAsync(h->d_row_src, h_row_src, 4 * B * cap, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(h->d_row_ld, h_row_ld, 4 * B * cap, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(launch_gather_rows(h->args(), h->d_cdata, h->cdata_per_problem, h->d_row_src, h->d_row_ld, h->d_in_owned, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream)); // the host arrays may be reused by the caller
+        if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream)); // the host arrays may be reused by the caller
         h->d_in         = h->d_in_owned;
         h->factor_valid = false;
         return LEXLS_OK;
@@ -469,7 +512,7 @@ extern "C"
         if (h_obj_index)
         {
             HIP_TRY(hipMemcpyAsync(h->d_objidx, h_obj_index, 4 * (size_t)h->batch, hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
             d_obj = h->d_objidx;
         }
         else if (obj_index_all < 0 || (uint32_t)obj_index_all >= h->nObj)
@@ -486,7 +529,7 @@ extern "C"
         if (!dst) return fail(LEXLS_ERR_INVALID, "null output pointer");
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
         return LEXLS_OK;
     }
 

@@ -51,17 +51,46 @@ namespace
         if (rc != LEXLS_OK) throw Exception(std::string("liblexls_hip: ") + lexls_last_error());
     }
 
+    /// host array in pinned memory (hipHostMalloc): the per-round copies of a lock-step batch are enqueued, not waited for
+    /// (lexls_lse_set_deferred_sync), so their sources / destinations must be DMA-able and stable until the round's synchronize
+    template <class T>
+    struct Pinned
+    {
+        T *p     = NULL;
+        size_t n = 0;
+        Pinned() {}
+        Pinned(const Pinned &)            = delete;
+        Pinned &operator=(const Pinned &) = delete;
+        ~Pinned()
+        {
+            if (p) (void)hipHostFree(p);
+        }
+        void assign(size_t n_, T v)
+        {
+            if (p) (void)hipHostFree(p);
+            p = NULL;
+            if (hipHostMalloc((void **)&p, (n_ ? n_ : 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) throw Exception("hipHostMalloc failed (lock-step LSI batch)");
+            n = n_;
+            std::fill(p, p + n, v);
+        }
+        T *data() { return p; }
+        T &operator[](size_t i) { return p[i]; }
+        T *begin() { return p; }
+        T *end() { return p + n; }
+    };
+
     struct BatchCtx
     {
         lexls_lse_t h = NULL;
         uint32_t B = 0, n = 0, nObjL = 0, cap = 0;
         size_t pstride = 0;
-        std::vector<uint32_t> maxdim, dims, nfixed, fixed_idx, rank, totalrank;
-        std::vector<double> fixed_val, x, maxabs;
-        double *lod = NULL; // B x cap x (n+1), PINNED: it is uploaded every active-set round
-        std::vector<uint8_t> fixed_type, ctr_type, skip;
-        std::vector<int32_t> sens, objidx;
-        std::vector<uint32_t> row_src, row_ld; // B x cap: where each LOD row comes from in the resident constraint data (device gather)
+        std::vector<uint32_t> maxdim, rank, totalrank;
+        std::vector<double> x;
+        Pinned<uint32_t> dims, nfixed, fixed_idx, row_src, row_ld, tr_dl; // row_src/row_ld: B x cap, where each LOD row comes from (device gather)
+        Pinned<double> fixed_val, maxabs, x_dl;
+        double *lod = NULL; // B x cap x (n+1), PINNED: host-staging fallback, uploaded every active-set round
+        Pinned<uint8_t> fixed_type, ctr_type, skip;
+        Pinned<int32_t> sens, objidx;
         bool gather = false;                   // constraint data resident on the device: only row references travel per round
         int rounds_fs = 0, rounds_sens = 0;
         double t_up = 0, t_kern = 0, t_down = 0, t_sens = 0; // seconds, reported when LEXLS_LSI_TIMING is set
@@ -81,11 +110,13 @@ namespace
             nfixed.assign(B, 0);
             fixed_idx.assign((size_t)B * n, 0);
             fixed_val.assign((size_t)B * n, 0.0);
-            fixed_type.assign((size_t)B * n, CTR_ACTIVE_UB);
-            ctr_type.assign((size_t)B * cap, CTR_INACTIVE);
+            fixed_type.assign((size_t)B * n, static_cast<uint8_t>(CTR_ACTIVE_UB));
+            ctr_type.assign((size_t)B * cap, static_cast<uint8_t>(CTR_INACTIVE));
             if (hipHostMalloc((void **)&lod, 8 * (size_t)B * pstride, hipHostMallocDefault) != hipSuccess) throw Exception("hipHostMalloc failed for the LSI staging buffer");
             std::memset(lod, 0, 8 * (size_t)B * pstride);
             x.assign((size_t)B * n, 0.0);
+            x_dl.assign((size_t)B * n, 0.0);
+            tr_dl.assign(B, 0);
             rank.assign((size_t)B * nObjL, 0);
             totalrank.assign(B, 0);
             skip.assign(B, 0);
@@ -115,17 +146,15 @@ namespace
                 hip_check(lexls_lse_set_problem_host(h, lod));
             const double t1 = now();
             hip_check(lexls_lse_factorize_solve(h, 1));
-            hip_check(lexls_lse_synchronize(h));
+            hip_check(lexls_lse_get_x(h, x_dl.data()));
+            hip_check(lexls_lse_get_ranks(h, NULL, NULL, tr_dl.data()));
+            hip_check(lexls_lse_synchronize(h)); // the ONE wait of this round: uploads, assembly, factorization and downloads were only enqueued
             const double t2 = now();
-            std::vector<double> xn((size_t)B * n);
-            std::vector<uint32_t> tr(B), rk((size_t)B * nObjL);
-            hip_check(lexls_lse_get_x(h, xn.data()));
-            hip_check(lexls_lse_get_ranks(h, rk.data(), NULL, tr.data()));
             for (uint32_t b = 0; b < B; b++)
                 if (!skip[b])
                 {
-                    std::copy(xn.begin() + (size_t)b * n, xn.begin() + (size_t)(b + 1) * n, x.begin() + (size_t)b * n);
-                    totalrank[b] = tr[b];
+                    std::copy(x_dl.begin() + (size_t)b * n, x_dl.begin() + (size_t)(b + 1) * n, x.begin() + (size_t)b * n);
+                    totalrank[b] = tr_dl[b];
                 }
             rounds_fs++;
             t_up += t1 - t0;
@@ -139,6 +168,7 @@ namespace
             const double t0 = now();
             hip_check(lexls_lse_sensitivity(h, objidx.data(), 0, tolW, tolC));
             hip_check(lexls_lse_get_sensitivity(h, sens.data(), maxabs.data()));
+            hip_check(lexls_lse_synchronize(h));
             rounds_sens++;
             t_sens += now() - t0;
         }
@@ -370,6 +400,7 @@ extern "C"
             BatchCtx ctx;
             ctx.create(device, batch, nVar, nObj - off, h_dims + off);
             hip_check(lexls_lse_set_tolerance(ctx.h, par.tol_linear_dependence));
+            hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between rounds
             if (per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING")) // (diagnostic switch: assemble on the host, stage over PCIe)
             {
                 hip_check(lexls_lse_set_constraint_data(ctx.h, h_data, per_data));
