@@ -141,6 +141,7 @@ namespace lexls_oracle
             LOD.resize(cap, nVar + 1);
             PROBLEM_DATA.resize(cap, nVar + 1);
             dWorkspace.resize(2 * std::max(cap, nVar) + nVar + 1);
+            null_space.resize(nVar, nVar + 1);
             column_permutations.resize(nVar);
             nCtr      = 0;
             TotalRank = 0;
@@ -223,7 +224,8 @@ namespace lexls_oracle
         /// lexlse.h:117-506
         void factorize()
         {
-            if (parameters.regularization_type != REGULARIZATION_NONE) throw Exception("oracle: only REGULARIZATION_NONE is restated");
+            const bool reg = parameters.regularization_type != REGULARIZATION_NONE;
+            if (reg) check_regularization_type();
 
             PROBLEM_DATA = LOD; // :119
             const Index M  = nCtr;
@@ -291,6 +293,8 @@ namespace lexls_oracle
                     {
                         swap_columns(ColIndex, piv, M);
                         std::swap(ColNorms[ColIndex], ColNorms[piv]);
+                        if (reg) // :229-231 (only the rows above this level's first column)
+                            for (Index i = 0; i < Fc; i++) std::swap(null_space(i, ColIndex), null_space(i, piv));
                     }
 
                     if (R > 1) // :239-248 (the RHS column is transformed too)
@@ -311,6 +315,8 @@ namespace lexls_oracle
                 }
 
                 const Index rank = obj_info[ObjIndex].rank = ColIndex - Fc; // :272
+
+                if (reg) regularize(ObjIndex, F, Fc, rank, RemainingColumns); // :277-411
 
                 // Gauss step (:431-471): L <- L R^-1, Trailing -= L * Up
                 if (ObjIndex < nObj - 1 && rank > 0)
@@ -528,6 +534,54 @@ namespace lexls_oracle
             apply_permutation();
         }
 
+        /// lexlse.h:1222-1277: least-norm solution from the null-space basis the Tikhonov family accumulates (regularization_type
+        /// TIKHONOV with all factors 0): null_space(0:nVarRank, nVarFixed:) = [inv(R) | -inv(R) [T | rhs]].
+        void solveLeastNorm_3()
+        {
+            Index nVarRank = 0;
+            for (Index k = 0; k < nObj; k++) nVarRank += obj_info[k].rank;
+            const Index nVarFree = nVar - (nVarRank + nVarFixed);
+            const Index c0       = nVarFixed + nVarRank; // first column of T inside null_space
+            Dense D(nVarFree, nVarFree);
+            std::vector<double> d(nVarFree, 0.0);
+            for (Index j = 0; j < nVarFree; j++)
+            {
+                for (Index i = j; i < nVarFree; i++)
+                {
+                    double acc = 0.0;
+                    for (Index k = 0; k < nVarRank; k++) acc = std::fma(null_space(k, c0 + i), null_space(k, c0 + j), acc);
+                    D(i, j) = acc;
+                }
+                D(j, j) += 1.0;
+                double acc = 0.0;
+                for (Index k = 0; k < nVarRank; k++) acc = std::fma(null_space(k, c0 + j), null_space(k, c0 + nVarFree), acc);
+                d[j] = acc;
+            }
+            cholesky_solve(D, d, nVarFree);
+            for (Index i = 0; i < nVarFree; i++) x(c0 + i) = d[i];
+            Index counter = 0;
+            for (Index k = 0; k < nObj; k++)
+            {
+                const Index F = obj_info[k].first_row_index, rank = obj_info[k].rank;
+                for (Index i = 0; i < rank; i++)
+                {
+                    double acc = 0.0;
+                    for (Index c = 0; c < nVarFree; c++) acc = std::fma(LOD(F + i, c0 + c), x(c0 + c), acc);
+                    x(nVarFixed + counter + i) = LOD(F + i, nVar) - acc;
+                }
+                counter += rank;
+            }
+            std::vector<double> out(nVarRank);
+            for (Index i = 0; i < nVarRank; i++) // x_rank <- triu(iR) * x_rank
+            {
+                double acc = 0.0;
+                for (Index j = i; j < nVarRank; j++) acc = std::fma(null_space(i, nVarFixed + j), x(nVarFixed + j), acc);
+                out[i] = acc;
+            }
+            for (Index i = 0; i < nVarRank; i++) x(nVarFixed + i) = out[i];
+            apply_permutation();
+        }
+
         /// lexlse.h:611-762.  On exit dWorkspace.head(nVarFixed+nLambda) = [lambda_fixed; lambda].
         bool ObjectiveSensitivity(Index ObjIndex, Index &CtrIndex2Remove, int &ObjIndex2Remove, RealScalar tol_wrong_sign_lambda,
                                   RealScalar tol_correct_sign_lambda, RealScalar &maxAbsValue)
@@ -653,7 +707,349 @@ namespace lexls_oracle
                 obj_info[k].first_col_index = 0;
             }
             hh_scalars.setZero();
+            null_space.setZero(); // :1686
             for (Index i = nVarFixed; i < nVar; i++) x(i) = 0.0;
+        }
+
+        // ------------------------------------------------------------------------------------------
+        // Regularization family (lexlse.h:277-411, :1700-2251, :2592-2625).  Restated: TIKHONOV (1), R (3), R_NO_Z (4),
+        // RT_NO_Z (5), TIKHONOV_2 (8), TEST (9); the CG variants (2, 6) and the experimental TIKHONOV_1 (7) are not.
+        // Arithmetic contract of what Eigen leaves open: every product entry is an ascending fma chain from 0 over the contraction
+        // index; "X += s * P" is fma(s, p, x) on the finished entry p; "X -= A*B" accumulates fma(-a, b, x) into x (as the Gauss
+        // update does); right-side triangular solves scale by the reciprocal of the diagonal (as the Gauss TRSM does); Cholesky and
+        // its two solves as in solveLeastNorm_2().
+        // ------------------------------------------------------------------------------------------
+        void check_regularization_type() const
+        {
+            switch (parameters.regularization_type)
+            {
+            case REGULARIZATION_TIKHONOV:
+            case REGULARIZATION_R:
+            case REGULARIZATION_R_NO_Z:
+            case REGULARIZATION_RT_NO_Z:
+            case REGULARIZATION_TIKHONOV_2:
+            case REGULARIZATION_TEST: return;
+            default: throw Exception("oracle: this regularization type is not restated (CG variants, TIKHONOV_1)");
+            }
+        }
+
+        struct Dense // small column-major scratch matrix
+        {
+            Index m;
+            std::vector<double> a;
+            Dense(Index m_, Index n_) : m(m_ ? m_ : 1), a(static_cast<size_t>(m_ ? m_ : 1) * (n_ ? n_ : 1), 0.0) {}
+            double &operator()(Index i, Index j) { return a[i + static_cast<size_t>(j) * m]; }
+            double operator()(Index i, Index j) const { return a[i + static_cast<size_t>(j) * m]; }
+        };
+
+        /// LLT of the lower triangle of D (N x N) in place, then D z = d in place
+        static void cholesky_solve(Dense &D, std::vector<double> &d, Index N)
+        {
+            for (Index j = 0; j < N; j++)
+            {
+                double sjj = D(j, j);
+                for (Index k = 0; k < j; k++) sjj = std::fma(-D(j, k), D(j, k), sjj);
+                D(j, j) = std::sqrt(sjj);
+                for (Index i = j + 1; i < N; i++)
+                {
+                    double v = D(i, j);
+                    for (Index k = 0; k < j; k++) v = std::fma(-D(i, k), D(j, k), v);
+                    D(i, j) = v / D(j, j);
+                }
+            }
+            for (Index j = 0; j < N; j++)
+            {
+                d[j] = d[j] / D(j, j);
+                for (Index i = j + 1; i < N; i++) d[i] = std::fma(-D(i, j), d[j], d[i]);
+            }
+            for (Index j = N; j--;)
+            {
+                d[j] = d[j] / D(j, j);
+                for (Index i = 0; i < j; i++) d[i] = std::fma(-D(j, i), d[j], d[i]);
+            }
+        }
+
+        // views of the level: R(i,j) = LOD(F+i, Fc+j) (upper part), T(i,c) = LOD(F+i, Fc+rank+c), rhs_i = LOD(F+i, nVar)
+        /// lower triangle of R^T R (only the upper triangle of the block is read, lexlse.h:2156)
+        void lower_RtR(Dense &D, Index F, Index Fc, Index rank) const
+        {
+            for (Index j = 0; j < rank; j++)
+                for (Index i = j; i < rank; i++)
+                {
+                    double acc = 0.0;
+                    for (Index k = 0; k <= j; k++) acc = std::fma(LOD(F + k, Fc + i), LOD(F + k, Fc + j), acc);
+                    D(i, j) = acc;
+                }
+        }
+        /// lower triangle of R R^T + T T^T (lexlse.h:2211-2212, :2098-2100)
+        void lower_RRt_TTt(Dense &D, Index F, Index Fc, Index rank, Index RC) const
+        {
+            for (Index j = 0; j < rank; j++)
+                for (Index i = j; i < rank; i++)
+                {
+                    double acc = 0.0;
+                    for (Index k = i; k < rank; k++) acc = std::fma(LOD(F + i, Fc + k), LOD(F + j, Fc + k), acc);
+                    double t = 0.0;
+                    for (Index c = 0; c < RC; c++) t = std::fma(LOD(F + i, Fc + rank + c), LOD(F + j, Fc + rank + c), t);
+                    D(i, j) = acc + t;
+                }
+        }
+        /// out_i = sum_{k <= i} R(k,i) rhs_k   (R^T rhs)
+        double Rt_rhs(Index F, Index Fc, Index i) const
+        {
+            double acc = 0.0;
+            for (Index k = 0; k <= i; k++) acc = std::fma(LOD(F + k, Fc + i), LOD(F + k, nVar), acc);
+            return acc;
+        }
+        /// out_i = sum_{j >= i} R(i,j) d_j      (R d)
+        double R_times(Index F, Index Fc, Index rank, Index i, const std::vector<double> &d) const
+        {
+            double acc = 0.0;
+            for (Index j = i; j < rank; j++) acc = std::fma(LOD(F + i, Fc + j), d[j], acc);
+            return acc;
+        }
+        /// d <- sym(D) d with only the lower triangle of D stored
+        static void symv_lower(const Dense &D, std::vector<double> &d, Index N)
+        {
+            std::vector<double> out(N, 0.0);
+            for (Index i = 0; i < N; i++)
+            {
+                double acc = 0.0;
+                for (Index j = 0; j < N; j++) acc = std::fma(i >= j ? D(i, j) : D(j, i), d[j], acc);
+                out[i] = acc;
+            }
+            d = out;
+        }
+
+        void regularize(Index ObjIndex, Index F, Index Fc, Index rank, Index RC)
+        {
+            // :277-311
+            if (parameters.variable_regularization_factor == 0.0)
+                aRegularizationFactor = obj_info[ObjIndex].regularization_factor;
+            else
+            {
+                aRegularizationFactor = 0.0;
+                if (rank > 0)
+                {
+                    std::vector<double> t(rank);
+                    for (Index i = 0; i < rank; i++) t[i] = LOD(F + i, nVar);
+                    double ce = sqnorm(t.data(), rank);
+                    back_substitute(F, Fc, rank, t.data());
+                    ce /= sqnorm(t.data(), rank);
+                    const double eps = parameters.variable_regularization_factor;
+                    if (ce < eps)
+                    {
+                        aRegularizationFactor = std::sqrt(1 - (ce * ce) / (eps * eps));
+                        aRegularizationFactor *= obj_info[ObjIndex].regularization_factor;
+                    }
+                }
+            }
+            const bool nonzero = !(std::abs(aRegularizationFactor - 0.0) < 1e-15); // utility.h:48-51
+            switch (parameters.regularization_type) // :314-395
+            {
+            case REGULARIZATION_TIKHONOV:
+                if (nonzero)
+                {
+                    if (Fc + rank <= RC)
+                        regularize_tikhonov_2(F, Fc, rank, RC);
+                    else
+                        regularize_tikhonov_1(F, Fc, rank, RC);
+                }
+                accumulate_nullspace_basis(F, Fc, rank, RC);
+                break;
+            case REGULARIZATION_TIKHONOV_2:
+                if (nonzero) regularize_tikhonov_2(F, Fc, rank, RC);
+                accumulate_nullspace_basis(F, Fc, rank, RC);
+                break;
+            case REGULARIZATION_R:
+                if (nonzero) regularize_R(F, Fc, rank);
+                accumulate_nullspace_basis(F, Fc, rank, RC);
+                break;
+            case REGULARIZATION_R_NO_Z:
+                if (nonzero) regularize_R_NO_Z(F, Fc, rank);
+                break;
+            case REGULARIZATION_RT_NO_Z:
+                if (nonzero) regularize_RT_NO_Z(F, Fc, rank, RC);
+                break;
+            case REGULARIZATION_TEST:
+                if (nonzero)
+                    for (Index i = 0; i < rank; i++) LOD(F + i, nVar) *= aRegularizationFactor; // :2244
+                break;
+            default: break;
+            }
+        }
+
+        /// lexlse.h:1700-1760
+        void regularize_tikhonov_1(Index F, Index Fc, Index rank, Index RC)
+        {
+            const double mu = aRegularizationFactor * aRegularizationFactor;
+            const Index m0 = Fc - nVarFixed, N = RC + rank;
+            Dense D(N, N);
+            std::vector<double> d(N, 0.0);
+            lower_RtR(D, F, Fc, rank);
+            for (Index b = 0; b < RC; b++) // Tk'*Tk (lower)
+                for (Index a = b; a < RC; a++)
+                {
+                    double acc = 0.0;
+                    for (Index k = 0; k < rank; k++) acc = std::fma(LOD(F + k, Fc + rank + a), LOD(F + k, Fc + rank + b), acc);
+                    D(rank + a, rank + b) = acc;
+                }
+            for (Index j = 0; j < rank; j++) // Tk'*triu(Rk)
+                for (Index a = 0; a < RC; a++)
+                {
+                    double acc = 0.0;
+                    for (Index k = 0; k <= j; k++) acc = std::fma(LOD(F + k, Fc + rank + a), LOD(F + k, Fc + j), acc);
+                    D(rank + a, j) = acc;
+                }
+            for (Index j = 0; j < N; j++) // += mu * up'*up, up = null_space(0:m0, Fc:Fc+N)
+                for (Index i = j; i < N; i++)
+                {
+                    double acc = 0.0;
+                    for (Index r = 0; r < m0; r++) acc = std::fma(null_space(r, Fc + i), null_space(r, Fc + j), acc);
+                    D(i, j) = std::fma(mu, acc, D(i, j));
+                }
+            for (Index i = 0; i < N; i++) D(i, i) += mu;
+            for (Index i = 0; i < rank; i++) d[i] = Rt_rhs(F, Fc, i);
+            for (Index a = 0; a < RC; a++)
+            {
+                double acc = 0.0;
+                for (Index k = 0; k < rank; k++) acc = std::fma(LOD(F + k, Fc + rank + a), LOD(F + k, nVar), acc);
+                d[rank + a] = acc;
+            }
+            for (Index i = 0; i < N; i++)
+            {
+                double acc = 0.0;
+                for (Index r = 0; r < m0; r++) acc = std::fma(null_space(r, Fc + i), null_space(r, nVar), acc);
+                d[i] = std::fma(mu, acc, d[i]);
+            }
+            cholesky_solve(D, d, N);
+            std::vector<double> out(rank);
+            for (Index i = 0; i < rank; i++)
+            {
+                double t = 0.0;
+                for (Index c = 0; c < RC; c++) t = std::fma(LOD(F + i, Fc + rank + c), d[rank + c], t);
+                out[i] = R_times(F, Fc, rank, i, d) + t;
+            }
+            for (Index i = 0; i < rank; i++) LOD(F + i, nVar) = out[i];
+        }
+
+        /// lexlse.h:2076-2133
+        void regularize_tikhonov_2(Index F, Index Fc, Index rank, Index RC)
+        {
+            const double f = aRegularizationFactor, mu = f * f;
+            const Index m0 = Fc - nVarFixed, N = m0 + rank, W = RC + rank;
+            Dense D(N, N);
+            std::vector<double> d(N, 0.0);
+            lower_RRt_TTt(D, F, Fc, rank, RC);
+            for (Index t = 0; t < m0; t++) // mu * up*up' (lower)
+                for (Index s2 = t; s2 < m0; s2++)
+                {
+                    double acc = 0.0;
+                    for (Index c = 0; c < W; c++) acc = std::fma(null_space(s2, Fc + c), null_space(t, Fc + c), acc);
+                    D(rank + s2, rank + t) = mu * acc;
+                }
+            for (Index i = 0; i < rank; i++) // f * (up.leftCols(rank)*triu(Rk)' + up.rightCols(RC)*Tk')
+                for (Index s2 = 0; s2 < m0; s2++)
+                {
+                    double a1 = 0.0;
+                    for (Index c = i; c < rank; c++) a1 = std::fma(null_space(s2, Fc + c), LOD(F + i, Fc + c), a1);
+                    double a2 = 0.0;
+                    for (Index c = 0; c < RC; c++) a2 = std::fma(null_space(s2, Fc + rank + c), LOD(F + i, Fc + rank + c), a2);
+                    D(rank + s2, i) = std::fma(f, a2, f * a1);
+                }
+            for (Index i = 0; i < N; i++) D(i, i) += mu;
+            for (Index i = 0; i < rank; i++) d[i] = LOD(F + i, nVar);
+            for (Index s2 = 0; s2 < m0; s2++) d[rank + s2] = f * null_space(s2, nVar);
+            Dense D0 = D; // Eigen::LLT works on a copy (:2121); the matrix itself is needed again below
+            cholesky_solve(D, d, N);
+            for (Index i = 0; i < N; i++) D0(i, i) -= mu;
+            symv_lower(D0, d, N);
+            for (Index i = 0; i < rank; i++) LOD(F + i, nVar) = d[i];
+        }
+
+        /// lexlse.h:2138-2170
+        void regularize_R(Index F, Index Fc, Index rank)
+        {
+            const double mu = aRegularizationFactor * aRegularizationFactor;
+            const Index m0 = Fc - nVarFixed;
+            Dense D(rank, rank);
+            std::vector<double> d(rank, 0.0);
+            lower_RtR(D, F, Fc, rank);
+            for (Index j = 0; j < rank; j++)
+                for (Index i = j; i < rank; i++)
+                {
+                    double acc = 0.0;
+                    for (Index r = 0; r < m0; r++) acc = std::fma(null_space(r, Fc + i), null_space(r, Fc + j), acc);
+                    D(i, j) = std::fma(mu, acc, D(i, j));
+                }
+            for (Index i = 0; i < rank; i++) D(i, i) += mu;
+            for (Index i = 0; i < rank; i++)
+            {
+                double acc = 0.0;
+                for (Index r = 0; r < m0; r++) acc = std::fma(null_space(r, Fc + i), null_space(r, nVar), acc);
+                d[i] = mu * acc + Rt_rhs(F, Fc, i);
+            }
+            cholesky_solve(D, d, rank);
+            std::vector<double> out(rank);
+            for (Index i = 0; i < rank; i++) out[i] = R_times(F, Fc, rank, i, d);
+            for (Index i = 0; i < rank; i++) LOD(F + i, nVar) = out[i];
+        }
+
+        /// lexlse.h:2175-2200
+        void regularize_R_NO_Z(Index F, Index Fc, Index rank)
+        {
+            const double mu = aRegularizationFactor * aRegularizationFactor;
+            Dense D(rank, rank);
+            std::vector<double> d(rank, 0.0);
+            lower_RtR(D, F, Fc, rank);
+            for (Index i = 0; i < rank; i++) D(i, i) += mu;
+            for (Index i = 0; i < rank; i++) d[i] = Rt_rhs(F, Fc, i);
+            cholesky_solve(D, d, rank);
+            std::vector<double> out(rank);
+            for (Index i = 0; i < rank; i++) out[i] = R_times(F, Fc, rank, i, d);
+            for (Index i = 0; i < rank; i++) LOD(F + i, nVar) = out[i];
+        }
+
+        /// lexlse.h:2205-2236
+        void regularize_RT_NO_Z(Index F, Index Fc, Index rank, Index RC)
+        {
+            const double mu = aRegularizationFactor * aRegularizationFactor;
+            Dense D(rank, rank);
+            std::vector<double> d(rank, 0.0);
+            lower_RRt_TTt(D, F, Fc, rank, RC);
+            for (Index i = 0; i < rank; i++) D(i, i) += mu;
+            for (Index i = 0; i < rank; i++) d[i] = LOD(F + i, nVar);
+            // the Cholesky factor overwrites D: keep the matrix for the product below
+            Dense D0 = D;
+            cholesky_solve(D, d, rank);
+            for (Index i = 0; i < rank; i++) D0(i, i) -= mu;
+            symv_lower(D0, d, rank);
+            for (Index i = 0; i < rank; i++) LOD(F + i, nVar) = d[i];
+        }
+
+        /// lexlse.h:2592-2625
+        void accumulate_nullspace_basis(Index F, Index Fc, Index rank, Index RC)
+        {
+            const Index m0 = Fc - nVarFixed, rows = m0 + rank;
+            for (Index i = 0; i < rank; i++) // LeftBlock.block(m0, 0, rank, rank).setIdentity()
+                for (Index j = 0; j < rank; j++) null_space(m0 + i, Fc + j) = (i == j) ? 1.0 : 0.0;
+            if (rank == 0) return;
+            std::vector<double> inv_diag(rank);
+            for (Index p = 0; p < rank; p++) inv_diag[p] = 1.0 / LOD(F + p, Fc + p);
+            for (Index i = 0; i < rows; i++) // LeftBlock <- LeftBlock * R^-1
+                for (Index p = 0; p < rank; p++)
+                {
+                    double sv = null_space(i, Fc + p);
+                    for (Index q = 0; q < p; q++) sv = std::fma(-null_space(i, Fc + q), LOD(F + q, Fc + p), sv);
+                    null_space(i, Fc + p) = sv * inv_diag[p];
+                }
+            for (Index i = 0; i < rows; i++) // TrailingBlock -= LeftBlock * UpBlock (RC + 1 columns: the RHS column too)
+                for (Index k = 0; k <= RC; k++)
+                {
+                    double t = null_space(i, Fc + rank + k);
+                    for (Index p = 0; p < rank; p++) t = std::fma(-null_space(i, Fc + p), LOD(F + p, Fc + rank + k), t);
+                    null_space(i, Fc + rank + k) = t;
+                }
         }
 
         void swap_columns(Index a, Index b, Index rows)
@@ -787,7 +1183,8 @@ namespace lexls_oracle
         Index nVar, nObj, nCtr, nVarFixed, nVarFixedInit, TotalRank;
         ParametersLexLSE parameters;
         std::vector<internal::ObjectiveInfo> obj_info;
-        dMatrixType LOD, PROBLEM_DATA;
+        dMatrixType LOD, PROBLEM_DATA, null_space; // null_space: nVar x (nVar+1), basis accumulated for the regularization (lexlse.h:93)
+        double aRegularizationFactor = 0.0;
         dVectorType x, hh_scalars, dWorkspace;
         iVectorType column_permutations, fixed_var_index;
         std::vector<ConstraintActivationType> ctr_type, fixed_var_type;

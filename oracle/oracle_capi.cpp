@@ -46,6 +46,14 @@ namespace
         uint8_t *ctr_type_out; // batch x cap
     };
 
+    /// regularization of the next oracle_lse_run calls (oracle_lse_set_regularization): type, per-level factors, variable factor
+    struct RegState
+    {
+        int type = 0;
+        std::vector<double> factors;
+        double variable = 0.0;
+    } g_reg;
+
     void run_one(const LseBatchArgs &a, uint32_t b, OLSE &lse, uint32_t cap)
     {
         const uint32_t n = a.nVar;
@@ -58,6 +66,7 @@ namespace
                 lse.fixVariable(a.fixed_idx[static_cast<size_t>(b) * n + k], a.fixed_val[static_cast<size_t>(b) * n + k],
                                 a.fixed_type ? static_cast<ConstraintActivationType>(a.fixed_type[static_cast<size_t>(b) * n + k]) : CTR_ACTIVE_UB);
         lse.setProblem(dMatrixConstRef(a.lod + static_cast<size_t>(b) * cap * (n + 1), cap, n + 1));
+        for (uint32_t k = 0; k < a.nObj; k++) lse.setRegularizationFactor(k, k < g_reg.factors.size() ? g_reg.factors[k] : 0.0);
         if (a.ctr_type)
         {
             uint32_t r = 0;
@@ -68,6 +77,7 @@ namespace
         if (a.solve_option == 0) lse.solve();
         else if (a.solve_option == 1) lse.solveLeastNorm_1();
         else if (a.solve_option == 2) lse.solveLeastNorm_2();
+        else if (a.solve_option == 3) lse.solveLeastNorm_3();
 
         if (a.x)
             for (uint32_t i = 0; i < n; i++) a.x[static_cast<size_t>(b) * n + i] = lse.get_x()(i);
@@ -127,6 +137,8 @@ namespace
         lse.resize(a.nVar, a.nObj, maxdim.data());
         ParametersLexLSE p;
         p.tol_linear_dependence = a.tol;
+        p.regularization_type            = static_cast<RegularizationType>(g_reg.type);
+        p.variable_regularization_factor = g_reg.variable;
         lse.setParameters(p);
         for (uint32_t b = b0; b < b1; b++) run_one(a, b, lse, cap);
         return 0;
@@ -136,6 +148,14 @@ namespace
 extern "C"
 {
     const char *oracle_last_error() { return g_err.c_str(); }
+
+    /// regularization used by the following oracle_lse_run calls: type = LexLS::RegularizationType, factors = one per level (or NULL)
+    void oracle_lse_set_regularization(int type, uint32_t nObj, const double *factors, double variable_factor)
+    {
+        g_reg.type = type;
+        g_reg.factors.assign(factors ? factors : NULL, factors ? factors + nObj : NULL);
+        g_reg.variable = variable_factor;
+    }
 
     /// factorize (+ solve, + residual, + sensitivity) of a batch of equality problems, `nthreads` host threads
     int oracle_lse_run(uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *maxdim, const uint32_t *dims, const double *lod, double tol,
