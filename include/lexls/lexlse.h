@@ -10,7 +10,7 @@
 //
 // Differences a caller can observe: Eigen types are replaced by the containers of typedefs.h
 // (dMatrixConstRef is a (ptr, rows, cols, ld) view); setCtr takes a pointer to nVar doubles;
-// regularization types other than REGULARIZATION_NONE, solveLeastNorm_3 and solveGeneralNorm throw.
+// the CG regularization variants, REGULARIZATION_TIKHONOV_1 and solveGeneralNorm throw.
 #pragma once
 
 #include <lexls/typedefs.h>
@@ -83,14 +83,30 @@ namespace LexLS
                 for (Index i = nVarFixed; i < nVar; i++) x(i) = 0.0;
             }
 
-            /// lexlse.h:1467 — only REGULARIZATION_NONE has a device path
+            /// lexlse.h:1467.  Regularization types with a device path: NONE, TIKHONOV, R, R_NO_Z, RT_NO_Z, TIKHONOV_2, TEST
+            /// (the CG variants and TIKHONOV_1 throw)
             void setParameters(const ParametersLexLSE &p)
             {
-                if (p.regularization_type != REGULARIZATION_NONE) throw Exception("lexls_hip: only REGULARIZATION_NONE is implemented on the device path");
+                switch (p.regularization_type)
+                {
+                case REGULARIZATION_NONE:
+                case REGULARIZATION_TIKHONOV:
+                case REGULARIZATION_R:
+                case REGULARIZATION_R_NO_Z:
+                case REGULARIZATION_RT_NO_Z:
+                case REGULARIZATION_TIKHONOV_2:
+                case REGULARIZATION_TEST: break;
+                default: throw Exception("lexls_hip: this regularization type has no device path (CG variants, TIKHONOV_1)");
+                }
                 parameters = p;
                 if (h) check(lexls_lse_set_tolerance(h, p.tol_linear_dependence));
             }
-            void setRegularizationFactor(Index, RealScalar) {} // lexlse.h:1477 (unused without regularization)
+            /// lexlse.h:1477
+            void setRegularizationFactor(Index ObjIndex, RealScalar factor)
+            {
+                if (reg_factor.size() < nObj) reg_factor.assign(nObj, 0.0);
+                reg_factor[ObjIndex] = factor;
+            }
 
             /// lexlse.h:1449-1462
             void setFixedVariablesCount(Index nVarFixed_)
@@ -165,7 +181,12 @@ namespace LexLS
                 check(lexls_lse_solve_least_norm_2(h));
                 check(lexls_lse_get_x(h, x.data()));
             }
-            void solveLeastNorm_3() { throw Exception("lexls_hip: solveLeastNorm_3 needs the Tikhonov null-space basis (regularization family: no device path); use solveLeastNorm_1 or _2"); }
+            /// lexlse.h:1222-1277 (needs regularization_type TIKHONOV / TIKHONOV_2 / R, normally with all factors 0)
+            void solveLeastNorm_3()
+            {
+                check(lexls_lse_solve_least_norm_3(h));
+                check(lexls_lse_get_x(h, x.data()));
+            }
 
             /// lexlse.h:611-762; on return getWorkspace().head(nVarFixed + nLambda) = [lambda_fixed; lambda]
             bool ObjectiveSensitivity(Index ObjIndex, Index &CtrIndex2Remove, int &ObjIndex2Remove, RealScalar tol_wrong_sign_lambda,
@@ -271,6 +292,9 @@ namespace LexLS
                 check(lexls_lse_set_fixed(h, nf ? &nf : NULL, fixed_idx.data(), fixed_val.data(), fixed_type.data()));
                 check(lexls_lse_set_ctr_type(h, ctr_type.data()));
                 check(lexls_lse_set_problem_host(h, LOD.data()));
+                if (reg_factor.size() < nObj) reg_factor.assign(nObj, 0.0);
+                check(lexls_lse_set_regularization(h, static_cast<int>(parameters.regularization_type), reg_factor.data(), 0,
+                                                   parameters.variable_regularization_factor));
             }
 
             lexls_lse_t h;
@@ -279,7 +303,7 @@ namespace LexLS
             bool factor_on_host = false;
             ParametersLexLSE parameters;
             std::vector<Index> dims, first_row, rank, first_col, fixed_idx;
-            std::vector<double> fixed_val;
+            std::vector<double> fixed_val, reg_factor;
             std::vector<uint8_t> fixed_type, ctr_type;
             dMatrixType LOD, PROBLEM_DATA, FACTOR;
             dVectorType x, dWorkspace;

@@ -5,3 +5,4 @@ include/lexls_hip.h), ``lexlse.BatchedLexLSE`` (host-side mirror of the referenc
 interface over that ABI) and ``problems`` (deterministic synthetic inputs, flop/byte model).
 """
 from .lexlse import BatchedLexLSE  # noqa: F401
+from .capi import LexlsError  # noqa: F401

@@ -4,6 +4,7 @@
 #include "../../include/lexls_hip.h"
 #include "lexls_kernels.h"
 #include "lexls_launch.h"
+#include "lexls_regularize.h"
 
 #include <cstdio>
 #include <cstring>
@@ -61,6 +62,9 @@ struct lexls_lse_s
     uint8_t *d_fixed_type, *d_ctr_type, *d_skip;
     bool has_skip;
     int32_t *d_sens, *d_objidx;
+    uint32_t reg_type;    // LexLS::RegularizationType, 0 = none
+    double reg_variable;
+    double *d_reg_factor, *d_reg_scratch;
 
     LseArgs args() const
     {
@@ -91,6 +95,10 @@ struct lexls_lse_s
         a.maxabs     = d_maxabs;
         a.scratch    = d_scratch;
         a.skip       = has_skip ? d_skip : nullptr;
+        a.reg_type     = reg_type;
+        a.reg_variable = reg_variable;
+        a.reg_factor   = d_reg_factor;
+        a.reg_scratch  = d_reg_scratch;
         return a;
     }
     size_t problem_elems() const { return (size_t)cap * (nVar + 1); }
@@ -145,6 +153,9 @@ extern "C"
         h->last_kernel = "";
         h->d_in_owned  = nullptr;
         h->d_cdata     = nullptr;
+        h->reg_type    = 0;
+        h->reg_variable = 0.0;
+        h->d_reg_factor = h->d_reg_scratch = nullptr;
         h->deferred_sync = false;
         h->h_dims_pinned = nullptr;
         h->dims_event = nullptr;
@@ -197,7 +208,7 @@ extern "C"
         (void)hipSetDevice(h->device);
         void *ptrs[] = {h->d_in_owned, h->d_fac,     h->d_x,      h->d_hh,        h->d_v,        h->d_lambda,     h->d_maxabs,
                         h->d_scratch,  h->d_fixed_val, h->d_perm,   h->d_rank,      h->d_fcol,     h->d_totalrank,  h->d_dims,
-                        h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx,      h->d_skip,       h->d_large_state, h->d_norms, h->d_cdata, h->d_row_src, h->d_row_ld};
+                        h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx,      h->d_skip,       h->d_large_state, h->d_norms, h->d_cdata, h->d_row_src, h->d_row_ld, h->d_reg_factor, h->d_reg_scratch};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (h->h_dims_pinned) (void)hipHostFree(h->h_dims_pinned);
@@ -218,6 +229,36 @@ extern "C"
         CHECK_HANDLE(h);
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_regularization(lexls_lse_t h, int type, const double *h_factors, int per_problem, double variable_factor)
+    {
+        CHECK_HANDLE(h);
+        switch (type)
+        {
+        case 0: case 1: case 3: case 4: case 5: case 8: case 9: break;
+        default: return fail(LEXLS_ERR_UNSUPPORTED, "set_regularization: the CG variants (2, 6) and TIKHONOV_1 (7) have no device path");
+        }
+        HIP_TRY(hipSetDevice(h->device));
+        h->factor_valid = false;
+        h->reg_type     = (uint32_t)type;
+        h->reg_variable = variable_factor;
+        if (type == 0) return LEXLS_OK;
+        const size_t B = h->batch, nObj = h->nObj;
+        std::vector<double> f(B * nObj, 0.0);
+        if (h_factors)
+            for (size_t b = 0; b < B; b++)
+                for (size_t k = 0; k < nObj; k++) f[b * nObj + k] = per_problem ? h_factors[b * nObj + k] : h_factors[k];
+        if (!h->d_reg_factor) HIP_TRY(hipMalloc((void **)&h->d_reg_factor, 8 * B * nObj));
+        if (!h->d_reg_scratch)
+        {
+            const size_t bytes = 8 * B * reg_scratch_doubles(h->nVar);
+            HIP_TRY(hipMalloc((void **)&h->d_reg_scratch, bytes));
+            HIP_TRY(hipMemsetAsync(h->d_reg_scratch, 0, bytes, h->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(h->d_reg_factor, f.data(), 8 * B * nObj, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream)); // f is a temporary
         return LEXLS_OK;
     }
 
@@ -437,11 +478,12 @@ extern "C"
         HIP_TRY(hipSetDevice(h->device));
         const char *variant = "";
         const LseArgs a     = h->args();
-        if (h->force_generic != 1 && wave_kernel_supports(a, h->max_rows, h->max_level_dim, h->has_fixed))
+        const bool shape_kernels = h->force_generic != 1 && h->reg_type == 0; // the regularization family lives in the generic kernel only
+        if (shape_kernels && wave_kernel_supports(a, h->max_rows, h->max_level_dim, h->has_fixed))
         {
             HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, h->force_generic != 2, h->stream, &variant)); // always solves as well
         }
-        else if (h->force_generic != 1 && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
+        else if (shape_kernels && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
         {
             if (!h->d_large_state) HIP_TRY(hipMalloc(&h->d_large_state, large_state_bytes(h->batch)));
             if (!h->d_norms) HIP_TRY(hipMalloc((void **)&h->d_norms, 8 * (size_t)h->batch * h->nVar));
@@ -493,6 +535,17 @@ extern "C"
         HIP_TRY(hipSetDevice(h->device));
         if (!h->d_scratch) HIP_TRY(hipMalloc((void **)&h->d_scratch, 8 * (size_t)h->batch * 2 * h->nVar * h->nVar));
         HIP_TRY(launch_leastnorm2(h->args(), h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_solve_least_norm_3(lexls_lse_t h)
+    {
+        if (int rc = need_factor(h, "lexls_lse_solve_least_norm_3")) return rc;
+        if (h->reg_type != 1 && h->reg_type != 8 && h->reg_type != 3)
+            return fail(LEXLS_ERR_INVALID, "lexls_lse_solve_least_norm_3: needs a factorization with a regularization type that accumulates the null-space basis (lexlse.h:1217-1221)");
+        HIP_TRY(hipSetDevice(h->device));
+        if (!h->d_scratch) HIP_TRY(hipMalloc((void **)&h->d_scratch, 8 * (size_t)h->batch * 2 * h->nVar * h->nVar));
+        HIP_TRY(launch_leastnorm3(h->args(), h->stream));
         return LEXLS_OK;
     }
 

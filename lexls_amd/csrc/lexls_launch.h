@@ -17,6 +17,7 @@ namespace lexls
     hipError_t launch_sensitivity(const LseArgs &a, const int32_t *d_obj_index, int32_t obj_all, double tolW, double tolC, hipStream_t s);
     hipError_t launch_leastnorm(const LseArgs &a, hipStream_t s);
     hipError_t launch_leastnorm2(const LseArgs &a, hipStream_t s);
+    hipError_t launch_leastnorm3(const LseArgs &a, hipStream_t s);
     hipError_t launch_gather_rows(const LseArgs &a, const double *d_cdata, uint64_t per_problem, const uint32_t *d_row_src, const uint32_t *d_row_ld,
                                   double *d_dst, hipStream_t s);
 

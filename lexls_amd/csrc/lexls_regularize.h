@@ -1,0 +1,425 @@
+// Regularization family of LexLSE::factorize (lexlse.h:277-411, :1700-2251, :2592-2625) for the generic kernel: executed by the
+// whole workgroup right after a level's QR, before its Gauss step.  Implemented: TIKHONOV (1), R (3), R_NO_Z (4), RT_NO_Z (5),
+// TIKHONOV_2 (8), TEST (9) and the variable factor; not: the CG variants (2, 6) and the experimental TIKHONOV_1 (7).
+// Arithmetic order = oracle/lexlse_oracle.h (regularize_* there), so the results are bit-identical to the oracle's.
+//
+// Per problem the scratch holds (doubles): NS n x (n+1) [the accumulated null-space basis, lexlse.h:93; it survives the
+// factorization because solveLeastNorm_3 reads it], D n x n, D0 n x n, d n, out n, 8 scalars.
+#pragma once
+#include "lexls_kernels.h"
+
+namespace lexls
+{
+    namespace
+    {
+        __device__ __forceinline__ double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+        __host__ __device__ inline size_t reg_scratch_doubles(uint32_t n) { return (size_t)n * (n + 1) + 2 * (size_t)n * n + 2 * (size_t)n + 8; }
+
+        struct RegView
+        {
+            double *W;   // the problem matrix (LDS or HBM), column-major
+            size_t ld;
+            uint32_t n, nf;
+            double *NS;  // n x (n+1), ld = n
+            double *D, *D0, *d, *out, *scal;
+            __device__ double &ns(uint32_t i, uint32_t j) const { return NS[i + (size_t)j * n]; }
+            __device__ double &w(uint32_t i, uint32_t j) const { return W[i + j * ld]; }
+            __device__ double &dd(uint32_t i, uint32_t j) const { return D[i + (size_t)j * n]; }
+            __device__ double &d0(uint32_t i, uint32_t j) const { return D0[i + (size_t)j * n]; }
+        };
+
+        __device__ inline RegView reg_view(const LseArgs &a, uint32_t b, double *W, size_t ld, uint32_t nf)
+        {
+            RegView v;
+            const uint32_t n = a.nVar;
+            double *base     = a.reg_scratch + (size_t)b * reg_scratch_doubles(n);
+            v.W    = W;
+            v.ld   = ld;
+            v.n    = n;
+            v.nf   = nf;
+            v.NS   = base;
+            v.D    = base + (size_t)n * (n + 1);
+            v.D0   = v.D + (size_t)n * n;
+            v.d    = v.D0 + (size_t)n * n;
+            v.out  = v.d + n;
+            v.scal = v.out + n;
+            return v;
+        }
+
+        /// LLT of the lower triangle of D (N x N) in place, then D z = d in place (oracle: cholesky_solve)
+        template <int NT>
+        __device__ void reg_cholesky_solve(const RegView &v, uint32_t N, uint32_t tid)
+        {
+            for (uint32_t j = 0; j < N; j++)
+            {
+                if (tid == 0)
+                {
+                    double sjj = v.dd(j, j);
+                    for (uint32_t k = 0; k < j; k++) sjj = rfma(-v.dd(j, k), v.dd(j, k), sjj);
+                    v.dd(j, j) = sqrt(sjj);
+                }
+                __syncthreads();
+                const double ljj = v.dd(j, j);
+                for (uint32_t i = j + 1 + tid; i < N; i += NT)
+                {
+                    double t = v.dd(i, j);
+                    for (uint32_t k = 0; k < j; k++) t = rfma(-v.dd(i, k), v.dd(j, k), t);
+                    v.dd(i, j) = t / ljj;
+                }
+                __syncthreads();
+            }
+            for (uint32_t j = 0; j < N; j++)
+            {
+                if (tid == 0) v.d[j] = v.d[j] / v.dd(j, j);
+                __syncthreads();
+                const double yj = v.d[j];
+                for (uint32_t i = j + 1 + tid; i < N; i += NT) v.d[i] = rfma(-v.dd(i, j), yj, v.d[i]);
+                __syncthreads();
+            }
+            for (uint32_t j = N; j--;)
+            {
+                if (tid == 0) v.d[j] = v.d[j] / v.dd(j, j);
+                __syncthreads();
+                const double zj = v.d[j];
+                for (uint32_t i = tid; i < j; i += NT) v.d[i] = rfma(-v.dd(j, i), zj, v.d[i]);
+                __syncthreads();
+            }
+        }
+
+        /// d <- sym(D0) d (lower triangle stored)
+        template <int NT>
+        __device__ void reg_symv_lower_d0(const RegView &v, uint32_t N, uint32_t tid)
+        {
+            for (uint32_t i = tid; i < N; i += NT)
+            {
+                double acc = 0.0;
+                for (uint32_t j = 0; j < N; j++) acc = rfma(i >= j ? v.d0(i, j) : v.d0(j, i), v.d[j], acc);
+                v.out[i] = acc;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < N; i += NT) v.d[i] = v.out[i];
+            __syncthreads();
+        }
+
+        /// lower triangle of R^T R into D
+        template <int NT>
+        __device__ void reg_lower_RtR(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t tid)
+        {
+            for (uint32_t e = tid; e < rank * rank; e += NT)
+            {
+                const uint32_t i = e % rank, j = e / rank;
+                if (i < j) continue;
+                double acc = 0.0;
+                for (uint32_t k = 0; k <= j; k++) acc = rfma(v.w(F + k, Fc + i), v.w(F + k, Fc + j), acc);
+                v.dd(i, j) = acc;
+            }
+        }
+        /// lower triangle of R R^T + T T^T into D
+        template <int NT>
+        __device__ void reg_lower_RRt_TTt(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, uint32_t tid)
+        {
+            for (uint32_t e = tid; e < rank * rank; e += NT)
+            {
+                const uint32_t i = e % rank, j = e / rank;
+                if (i < j) continue;
+                double acc = 0.0;
+                for (uint32_t k = i; k < rank; k++) acc = rfma(v.w(F + i, Fc + k), v.w(F + j, Fc + k), acc);
+                double t = 0.0;
+                for (uint32_t c = 0; c < RC; c++) t = rfma(v.w(F + i, Fc + rank + c), v.w(F + j, Fc + rank + c), t);
+                v.dd(i, j) = acc + t;
+            }
+        }
+        __device__ inline double reg_Rt_rhs(const RegView &v, uint32_t F, uint32_t Fc, uint32_t i)
+        {
+            double acc = 0.0;
+            for (uint32_t k = 0; k <= i; k++) acc = rfma(v.w(F + k, Fc + i), v.w(F + k, v.n), acc);
+            return acc;
+        }
+        __device__ inline double reg_R_times_d(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t i)
+        {
+            double acc = 0.0;
+            for (uint32_t j = i; j < rank; j++) acc = rfma(v.w(F + i, Fc + j), v.d[j], acc);
+            return acc;
+        }
+        template <int NT>
+        __device__ void reg_copy_D_to_D0(const RegView &v, uint32_t N, uint32_t tid)
+        {
+            for (uint32_t e = tid; e < N * N; e += NT)
+            {
+                const uint32_t i = e % N, j = e / N;
+                v.d0(i, j) = v.dd(i, j);
+            }
+            __syncthreads();
+        }
+        /// rhs of the level <- out[0..rank)
+        template <int NT>
+        __device__ void reg_store_rhs(const RegView &v, uint32_t F, uint32_t rank, const double *src, uint32_t tid)
+        {
+            __syncthreads();
+            for (uint32_t i = tid; i < rank; i += NT) v.w(F + i, v.n) = src[i];
+            __syncthreads();
+        }
+
+        template <int NT>
+        __device__ void reg_tikhonov_1(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, double f, uint32_t tid)
+        {
+            const double mu   = f * f;
+            const uint32_t m0 = Fc - v.nf, N = RC + rank;
+            reg_lower_RtR<NT>(v, F, Fc, rank, tid);
+            for (uint32_t e = tid; e < RC * RC; e += NT) // Tk'*Tk (lower)
+            {
+                const uint32_t a = e % RC, b2 = e / RC;
+                if (a < b2) continue;
+                double acc = 0.0;
+                for (uint32_t k = 0; k < rank; k++) acc = rfma(v.w(F + k, Fc + rank + a), v.w(F + k, Fc + rank + b2), acc);
+                v.dd(rank + a, rank + b2) = acc;
+            }
+            for (uint32_t e = tid; e < RC * rank; e += NT) // Tk'*triu(Rk)
+            {
+                const uint32_t a = e % RC, j = e / RC;
+                double acc = 0.0;
+                for (uint32_t k = 0; k <= j; k++) acc = rfma(v.w(F + k, Fc + rank + a), v.w(F + k, Fc + j), acc);
+                v.dd(rank + a, j) = acc;
+            }
+            __syncthreads();
+            for (uint32_t e = tid; e < N * N; e += NT) // += mu * up'*up ; + mu on the diagonal
+            {
+                const uint32_t i = e % N, j = e / N;
+                if (i < j) continue;
+                double acc = 0.0;
+                for (uint32_t r = 0; r < m0; r++) acc = rfma(v.ns(r, Fc + i), v.ns(r, Fc + j), acc);
+                double t = rfma(mu, acc, v.dd(i, j));
+                if (i == j) t += mu;
+                v.dd(i, j) = t;
+            }
+            for (uint32_t i = tid; i < N; i += NT)
+            {
+                double base;
+                if (i < rank)
+                    base = reg_Rt_rhs(v, F, Fc, i);
+                else
+                {
+                    double acc = 0.0;
+                    for (uint32_t k = 0; k < rank; k++) acc = rfma(v.w(F + k, Fc + i), v.w(F + k, v.n), acc);
+                    base = acc;
+                }
+                double acc = 0.0;
+                for (uint32_t r = 0; r < m0; r++) acc = rfma(v.ns(r, Fc + i), v.ns(r, v.n), acc);
+                v.d[i] = rfma(mu, acc, base);
+            }
+            __syncthreads();
+            reg_cholesky_solve<NT>(v, N, tid);
+            for (uint32_t i = tid; i < rank; i += NT)
+            {
+                double t = 0.0;
+                for (uint32_t c = 0; c < RC; c++) t = rfma(v.w(F + i, Fc + rank + c), v.d[rank + c], t);
+                v.out[i] = reg_R_times_d(v, F, Fc, rank, i) + t;
+            }
+            reg_store_rhs<NT>(v, F, rank, v.out, tid);
+        }
+
+        template <int NT>
+        __device__ void reg_tikhonov_2(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, double f, uint32_t tid)
+        {
+            const double mu   = f * f;
+            const uint32_t m0 = Fc - v.nf, N = m0 + rank, Wd = RC + rank;
+            reg_lower_RRt_TTt<NT>(v, F, Fc, rank, RC, tid);
+            for (uint32_t e = tid; e < m0 * m0; e += NT) // mu * up*up' (lower)
+            {
+                const uint32_t s2 = e % m0, t = e / m0;
+                if (s2 < t) continue;
+                double acc = 0.0;
+                for (uint32_t c = 0; c < Wd; c++) acc = rfma(v.ns(s2, Fc + c), v.ns(t, Fc + c), acc);
+                v.dd(rank + s2, rank + t) = mu * acc;
+            }
+            for (uint32_t e = tid; e < m0 * rank; e += NT) // f * (up.leftCols(rank)*triu(Rk)' + up.rightCols(RC)*Tk')
+            {
+                const uint32_t s2 = e % m0, i = e / m0;
+                double a1 = 0.0;
+                for (uint32_t c = i; c < rank; c++) a1 = rfma(v.ns(s2, Fc + c), v.w(F + i, Fc + c), a1);
+                double a2 = 0.0;
+                for (uint32_t c = 0; c < RC; c++) a2 = rfma(v.ns(s2, Fc + rank + c), v.w(F + i, Fc + rank + c), a2);
+                v.dd(rank + s2, i) = rfma(f, a2, f * a1);
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < N; i += NT)
+            {
+                v.dd(i, i) += mu;
+                v.d[i] = (i < rank) ? v.w(F + i, v.n) : f * v.ns(i - rank, v.n);
+            }
+            __syncthreads();
+            reg_copy_D_to_D0<NT>(v, N, tid);
+            reg_cholesky_solve<NT>(v, N, tid);
+            for (uint32_t i = tid; i < N; i += NT) v.d0(i, i) -= mu;
+            __syncthreads();
+            reg_symv_lower_d0<NT>(v, N, tid);
+            reg_store_rhs<NT>(v, F, rank, v.d, tid);
+        }
+
+        template <int NT>
+        __device__ void reg_R(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, double f, bool with_z, uint32_t tid)
+        {
+            const double mu   = f * f;
+            const uint32_t m0 = with_z ? Fc - v.nf : 0;
+            reg_lower_RtR<NT>(v, F, Fc, rank, tid);
+            __syncthreads();
+            for (uint32_t e = tid; e < rank * rank; e += NT)
+            {
+                const uint32_t i = e % rank, j = e / rank;
+                if (i < j) continue;
+                double t = v.dd(i, j);
+                if (with_z)
+                {
+                    double acc = 0.0;
+                    for (uint32_t r = 0; r < m0; r++) acc = rfma(v.ns(r, Fc + i), v.ns(r, Fc + j), acc);
+                    t = rfma(mu, acc, t);
+                }
+                if (i == j) t += mu;
+                v.dd(i, j) = t;
+            }
+            for (uint32_t i = tid; i < rank; i += NT)
+            {
+                if (with_z)
+                {
+                    double acc = 0.0;
+                    for (uint32_t r = 0; r < m0; r++) acc = rfma(v.ns(r, Fc + i), v.ns(r, v.n), acc);
+                    v.d[i] = mu * acc + reg_Rt_rhs(v, F, Fc, i);
+                }
+                else
+                    v.d[i] = reg_Rt_rhs(v, F, Fc, i);
+            }
+            __syncthreads();
+            reg_cholesky_solve<NT>(v, rank, tid);
+            for (uint32_t i = tid; i < rank; i += NT) v.out[i] = reg_R_times_d(v, F, Fc, rank, i);
+            reg_store_rhs<NT>(v, F, rank, v.out, tid);
+        }
+
+        template <int NT>
+        __device__ void reg_RT_NO_Z(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, double f, uint32_t tid)
+        {
+            const double mu = f * f;
+            reg_lower_RRt_TTt<NT>(v, F, Fc, rank, RC, tid);
+            __syncthreads();
+            for (uint32_t i = tid; i < rank; i += NT)
+            {
+                v.dd(i, i) += mu;
+                v.d[i] = v.w(F + i, v.n);
+            }
+            __syncthreads();
+            reg_copy_D_to_D0<NT>(v, rank, tid);
+            reg_cholesky_solve<NT>(v, rank, tid);
+            for (uint32_t i = tid; i < rank; i += NT) v.d0(i, i) -= mu;
+            __syncthreads();
+            reg_symv_lower_d0<NT>(v, rank, tid);
+            reg_store_rhs<NT>(v, F, rank, v.d, tid);
+        }
+
+        /// lexlse.h:2592-2625
+        template <int NT>
+        __device__ void reg_accumulate_nullspace(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, uint32_t tid)
+        {
+            const uint32_t m0 = Fc - v.nf, rows = m0 + rank;
+            for (uint32_t e = tid; e < rank * rank; e += NT)
+            {
+                const uint32_t i = e % rank, j = e / rank;
+                v.ns(m0 + i, Fc + j) = (i == j) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            if (rank == 0) return;
+            for (uint32_t i = tid; i < rows; i += NT) // LeftBlock <- LeftBlock * R^-1 (row by row, reciprocal of the diagonal)
+                for (uint32_t p = 0; p < rank; p++)
+                {
+                    double sv = v.ns(i, Fc + p);
+                    for (uint32_t q = 0; q < p; q++) sv = rfma(-v.ns(i, Fc + q), v.w(F + q, Fc + p), sv);
+                    v.ns(i, Fc + p) = sv * (1.0 / v.w(F + p, Fc + p));
+                }
+            __syncthreads();
+            for (uint32_t e = tid; e < rows * (RC + 1); e += NT) // TrailingBlock -= LeftBlock * UpBlock (RHS column included)
+            {
+                const uint32_t i = e % rows, k = e / rows;
+                double t = v.ns(i, Fc + rank + k);
+                for (uint32_t p = 0; p < rank; p++) t = rfma(-v.ns(i, Fc + p), v.w(F + p, Fc + rank + k), t);
+                v.ns(i, Fc + rank + k) = t;
+            }
+            __syncthreads();
+        }
+
+        /// dispatch of lexlse.h:277-395 for one level; called by every thread of the workgroup (uniform arguments)
+        template <int NT>
+        __device__ void regularize_level(const LseArgs &a, uint32_t b, double *W, size_t ld, uint32_t nf, uint32_t ObjIndex, uint32_t F, uint32_t Fc,
+                                         uint32_t rank, uint32_t RC, uint32_t tid)
+        {
+            const RegView v = reg_view(a, b, W, ld, nf);
+            if (tid == 0) // lexlse.h:277-311: constant or conditioning-dependent factor
+            {
+                const double fk = a.reg_factor[(size_t)b * a.nObj + ObjIndex];
+                double f        = fk;
+                if (a.reg_variable != 0.0)
+                {
+                    f = 0.0;
+                    if (rank > 0)
+                    {
+                        double ce = 0.0;
+                        for (uint32_t i = 0; i < rank; i++)
+                        {
+                            v.out[i] = v.w(F + i, v.n);
+                            ce       = rfma(v.out[i], v.out[i], ce);
+                        }
+                        for (uint32_t j = rank; j--;)
+                        {
+                            v.out[j] = v.out[j] / v.w(F + j, Fc + j);
+                            for (uint32_t i = 0; i < j; i++) v.out[i] = rfma(-v.w(F + i, Fc + j), v.out[j], v.out[i]);
+                        }
+                        double q = 0.0;
+                        for (uint32_t i = 0; i < rank; i++) q = rfma(v.out[i], v.out[i], q);
+                        ce /= q;
+                        const double eps = a.reg_variable;
+                        if (ce < eps)
+                        {
+                            f = sqrt(1 - (ce * ce) / (eps * eps));
+                            f *= fk;
+                        }
+                    }
+                }
+                v.scal[0] = f;
+            }
+            __syncthreads();
+            const double f     = v.scal[0];
+            const bool nonzero = !(fabs(f - 0.0) < 1e-15);
+            switch (a.reg_type)
+            {
+            case 1: // REGULARIZATION_TIKHONOV
+                if (nonzero)
+                {
+                    if (Fc + rank <= RC)
+                        reg_tikhonov_2<NT>(v, F, Fc, rank, RC, f, tid);
+                    else
+                        reg_tikhonov_1<NT>(v, F, Fc, rank, RC, f, tid);
+                }
+                reg_accumulate_nullspace<NT>(v, F, Fc, rank, RC, tid);
+                break;
+            case 8: // REGULARIZATION_TIKHONOV_2
+                if (nonzero) reg_tikhonov_2<NT>(v, F, Fc, rank, RC, f, tid);
+                reg_accumulate_nullspace<NT>(v, F, Fc, rank, RC, tid);
+                break;
+            case 3: // REGULARIZATION_R
+                if (nonzero) reg_R<NT>(v, F, Fc, rank, f, true, tid);
+                reg_accumulate_nullspace<NT>(v, F, Fc, rank, RC, tid);
+                break;
+            case 4: // REGULARIZATION_R_NO_Z
+                if (nonzero) reg_R<NT>(v, F, Fc, rank, f, false, tid);
+                break;
+            case 5: // REGULARIZATION_RT_NO_Z
+                if (nonzero) reg_RT_NO_Z<NT>(v, F, Fc, rank, RC, f, tid);
+                break;
+            case 9: // REGULARIZATION_TEST (lexlse.h:2244)
+                if (nonzero)
+                    for (uint32_t i = tid; i < rank; i += NT) v.w(F + i, v.n) *= f;
+                __syncthreads();
+                break;
+            default: break;
+            }
+        }
+    } // namespace
+} // namespace lexls

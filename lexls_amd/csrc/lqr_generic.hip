@@ -15,6 +15,7 @@
 // distinct 8-byte bank pairs (ds_read_b64: bank = (addr/4) % 64, stride 2*ldp dwords).
 #include "lexls_kernels.h"
 #include "lexls_launch.h"
+#include "lexls_regularize.h"
 
 #include <cfloat>
 
@@ -157,6 +158,11 @@ namespace lexls
             for (uint32_t i = tid; i < n; i += NT) perm_s[i] = i;
             const uint32_t nf = a.nfixed ? a.nfixed[b] : 0;
             for (uint32_t i = tid; i < n; i += NT) xs[i] = (i < nf) ? a.fixed_val[(size_t)b * n + i] : 0.0;
+            if (a.reg_type) // initialize(): null_space.setZero() (lexlse.h:1686)
+            {
+                double *NS = a.reg_scratch + (size_t)b * reg_scratch_doubles(n);
+                for (uint32_t e = tid; e < n * (n + 1); e += NT) NS[e] = 0.0;
+            }
             __syncthreads();
 
             // ---- fixed variables: their columns go first, their contribution goes to the RHS (lexlse.h:132-156) ----
@@ -296,6 +302,16 @@ namespace lexls
                                 W[i + ColIndex * ld] = newc;
                                 if (piv != ColIndex) W[i + piv * ld] = a1;
                             }
+                            if (a.reg_type && piv != ColIndex) // lexlse.h:229-231: the rows of the basis above this level's first column
+                            {
+                                double *NS = a.reg_scratch + (size_t)b * reg_scratch_doubles(n);
+                                for (uint32_t i = tid; i < Fc; i += NT)
+                                {
+                                    const double t               = NS[i + (size_t)ColIndex * n];
+                                    NS[i + (size_t)ColIndex * n] = NS[i + (size_t)piv * n];
+                                    NS[i + (size_t)piv * n]      = t;
+                                }
+                            }
                         }
                         __syncthreads();
 
@@ -326,6 +342,12 @@ namespace lexls
                     const uint32_t rank = ColIndex - Fc;
                     if (tid == 0) rk_s[ObjIndex] = rank;
                     TotalRank += rank;
+
+                    if (a.reg_type) // lexlse.h:277-411: the level's transformed right-hand side is damped before the Gauss step
+                    {
+                        __syncthreads();
+                        regularize_level<NT>(a, b, W, ld, nf, ObjIndex, F, Fc, rank, n - ColIndex, tid);
+                    }
 
                     // Gauss step (lexlse.h:431-471)
                     if (ObjIndex + 1 < nObj && rank > 0)
@@ -946,6 +968,119 @@ namespace lexls
             __syncthreads();
             for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
         }
+        /// solveLeastNorm_3 (lexlse.h:1222-1277): least-norm solution from the null-space basis of the Tikhonov family,
+        /// null_space(0:nVarRank, nVarFixed:) = [inv(R) | -inv(R) [T | rhs]].  Arithmetic order as the oracle's solveLeastNorm_3.
+        template <int NT>
+        __global__ __launch_bounds__(NT) void leastnorm3_kernel(LseArgs a)
+        {
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.x, tid = threadIdx.x;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const double *W  = a.fac + (size_t)b * cap * (n + 1);
+            const size_t ld  = cap;
+            const double *NS = a.reg_scratch + (size_t)b * reg_scratch_doubles(n); // n x (n+1), ld = n
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            const uint32_t *rk   = a.rank + (size_t)b * nObj;
+            const uint32_t *perm = a.perm + (size_t)b * n;
+            const uint32_t nf    = a.nfixed ? a.nfixed[b] : 0;
+            uint32_t nVarRank    = 0;
+            for (uint32_t k = 0; k < nObj; k++) nVarRank += rk[k];
+            const uint32_t nVarFree = n - (nVarRank + nf);
+            const uint32_t c0       = nf + nVarRank;
+            double *D               = a.scratch + (size_t)b * 2 * n * n; // nVarFree x nVarFree (lower), column-major
+            const size_t ldd        = nVarFree ? nVarFree : 1;
+            double *d               = smem;     // n
+            double *xs              = smem + n; // n
+            double *out             = smem + 2 * n; // n
+
+            for (uint32_t i = tid; i < n; i += NT) xs[i] = (i < nf) ? a.fixed_val[(size_t)b * n + i] : 0.0;
+            for (uint32_t e = tid; e < nVarFree * nVarFree; e += NT)
+            {
+                const uint32_t i = e % nVarFree, j = e / nVarFree;
+                if (i < j) continue;
+                double acc = 0.0;
+                for (uint32_t k = 0; k < nVarRank; k++) acc = dfma(NS[k + (size_t)(c0 + i) * n], NS[k + (size_t)(c0 + j) * n], acc);
+                D[i + j * ldd] = (i == j) ? acc + 1.0 : acc;
+            }
+            for (uint32_t j = tid; j < nVarFree; j += NT)
+            {
+                double acc = 0.0;
+                for (uint32_t k = 0; k < nVarRank; k++) acc = dfma(NS[k + (size_t)(c0 + j) * n], NS[k + (size_t)(c0 + nVarFree) * n], acc);
+                d[j] = acc;
+            }
+            __syncthreads();
+            for (uint32_t j = 0; j < nVarFree; j++) // Cholesky
+            {
+                if (tid == 0)
+                {
+                    double sjj = D[j + j * ldd];
+                    for (uint32_t k = 0; k < j; k++) sjj = dfma(-D[j + k * ldd], D[j + k * ldd], sjj);
+                    D[j + j * ldd] = sqrt(sjj);
+                }
+                __syncthreads();
+                const double ljj = D[j + j * ldd];
+                for (uint32_t i = j + 1 + tid; i < nVarFree; i += NT)
+                {
+                    double v = D[i + j * ldd];
+                    for (uint32_t k = 0; k < j; k++) v = dfma(-D[i + k * ldd], D[j + k * ldd], v);
+                    D[i + j * ldd] = v / ljj;
+                }
+                __syncthreads();
+            }
+            for (uint32_t j = 0; j < nVarFree; j++)
+            {
+                if (tid == 0) d[j] = d[j] / D[j + j * ldd];
+                __syncthreads();
+                const double yj = d[j];
+                for (uint32_t i = j + 1 + tid; i < nVarFree; i += NT) d[i] = dfma(-D[i + j * ldd], yj, d[i]);
+                __syncthreads();
+            }
+            for (uint32_t j = nVarFree; j--;)
+            {
+                if (tid == 0) d[j] = d[j] / D[j + j * ldd];
+                __syncthreads();
+                const double zj = d[j];
+                for (uint32_t i = tid; i < j; i += NT) d[i] = dfma(-D[j + i * ldd], zj, d[i]);
+                __syncthreads();
+            }
+            for (uint32_t i = tid; i < nVarFree; i += NT) xs[c0 + i] = d[i];
+            __syncthreads();
+            {
+                uint32_t counter = 0, F = 0;
+                for (uint32_t k = 0; k < nObj; k++)
+                {
+                    const uint32_t rank = rk[k];
+                    for (uint32_t i = tid; i < rank; i += NT)
+                    {
+                        double acc = 0.0;
+                        for (uint32_t c = 0; c < nVarFree; c++) acc = dfma(W[F + i + (size_t)(c0 + c) * ld], xs[c0 + c], acc);
+                        xs[nf + counter + i] = W[F + i + n * ld] - acc;
+                    }
+                    counter += rank;
+                    F += dims[k];
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < nVarRank; i += NT) // x_rank <- triu(inv(R)) * x_rank
+            {
+                double acc = 0.0;
+                for (uint32_t j = i; j < nVarRank; j++) acc = dfma(NS[i + (size_t)(nf + j) * n], xs[nf + j], acc);
+                out[i] = acc;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < nVarRank; i += NT) xs[nf + i] = out[i];
+            __syncthreads();
+            if (tid == 0)
+                for (uint32_t k = a.totalrank[b]; k--;)
+                {
+                    const uint32_t pk = perm[k];
+                    const double t    = xs[k];
+                    xs[k]             = xs[pk];
+                    xs[pk]            = t;
+                }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
+        }
     } // namespace
 
     // ---------------------------------------------------------------------------------------------
@@ -1097,6 +1232,16 @@ namespace lexls
         hipError_t e = set_lds(leastnorm2_kernel<64>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((leastnorm2_kernel<64>), dim3(a.batch), dim3(64), lds, s, a);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_leastnorm3(const LseArgs &a, hipStream_t s)
+    {
+        const size_t lds = 8 * (3 * (size_t)a.nVar + 4);
+        if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
+        hipError_t e = set_lds(leastnorm3_kernel<64>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((leastnorm3_kernel<64>), dim3(a.batch), dim3(64), lds, s, a);
         return hipGetLastError();
     }
 } // namespace lexls

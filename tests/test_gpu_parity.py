@@ -316,6 +316,68 @@ def test_least_norm_normal_equations(hip, oracle):
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
+@pytest.mark.parametrize("reg_type", [1, 3, 4, 5, 8, 9])
+def test_regularization_family_bit_exact(hip, oracle, reg_type):
+    """lexlse.h:277-411 on the device (generic kernel): bit-identical to the oracle for every implemented type, on a hierarchy that
+    takes both Tikhonov branches (tikhonov_1 and tikhonov_2), with fixed variables, per-problem factors and a rank-deficient level."""
+    n, dims, batch = 12, [3, 4, 2], 6
+    lod = P.lse_batch(7, batch, n, dims)
+    lod[3:, :, 5] = lod[3:, :, 4]  # duplicated row in level 1 of half of the problems
+    fac = np.abs(P.normal(88, batch * 3)).reshape(batch, 3) * 0.5 + 0.05
+    fac[1, 1] = 0.0
+    nfixed = np.array([0, 0, 2, 2, 1, 0], np.uint32)
+    idx = np.zeros((batch, n), np.uint32)
+    idx[:, :2] = [7, 2]
+    val = np.zeros((batch, n))
+    val[:, :2] = P.normal(89, 2)
+    for b in range(batch):  # the oracle binding takes one factor vector per call
+        ref = oracle.lse_run(lod[b:b + 1], dims, n, reg_type=reg_type, reg_factors=fac[b], nfixed=nfixed[b:b + 1], fixed_idx=idx[b:b + 1],
+                             fixed_val=val[b:b + 1])
+        s = hip.BatchedLexLSE(1, n, dims)
+        s.setRegularization(reg_type, fac[b])
+        s.fixVariables(nfixed[b:b + 1], idx[b:b + 1], val[b:b + 1])
+        s.setProblem(lod[b:b + 1])
+        s.factorize_solve()
+        assert s.last_kernel().startswith("lqr_generic")
+        assert_factor_equal(s, ref, dims, n)
+        np.testing.assert_array_equal(s.get_x(), ref["x"])
+    # the whole batch at once with per-problem factors gives the same solutions
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.setRegularization(reg_type, fac)
+    s.fixVariables(nfixed, idx, val)
+    s.setProblem(lod)
+    s.factorize_solve()
+    for b in range(batch):
+        ref = oracle.lse_run(lod[b:b + 1], dims, n, reg_type=reg_type, reg_factors=fac[b], nfixed=nfixed[b:b + 1], fixed_idx=idx[b:b + 1],
+                             fixed_val=val[b:b + 1])
+        np.testing.assert_array_equal(s.get_x()[b], ref["x"][0])
+
+
+def test_regularization_variable_factor_and_least_norm_3(hip, oracle):
+    n, dims, batch = 40, [6] * 5, 4
+    lod = P.lse_batch(61, batch, n, dims)
+    ref = oracle.lse_run(lod, dims, n, reg_type=1, reg_factors=[0.4] * 5, var_reg=1e3)
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.setRegularization(1, [0.4] * 5, variable_factor=1e3)
+    s.setProblem(lod)
+    s.factorize_solve()
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    # solveLeastNorm_3: null-space basis of the Tikhonov family with zero factors (lexlse.h:1217-1221)
+    ref3 = oracle.lse_run(lod, dims, n, solve_option=3, reg_type=1, reg_factors=[0.0] * 5)
+    s.setRegularization(1, [0.0] * 5)
+    s.factorize()
+    s.solveLeastNorm_3()
+    np.testing.assert_array_equal(s.get_x(), ref3["x"])
+    s.solveLeastNorm_1()
+    assert np.abs(s.get_x() - ref3["x"]).max() < 1e-10
+    s.setRegularization(0)
+    s.factorize()
+    with pytest.raises(hip.LexlsError):
+        s.solveLeastNorm_3()
+    with pytest.raises(hip.LexlsError):
+        s.setRegularization(2)
+
+
 def test_full_size_batch_4096(hip, oracle):
     """BASELINE.json configs[2]: batch 4096 x (n=40, 5x12) against the oracle on all problems."""
     n, dims, batch = 40, [12] * 5, 4096

@@ -172,3 +172,37 @@ def test_least_norm_normal_equations_equals_givens_and_pinv(oracle):
     for b in range(3):
         A, rhs = lod[b, :n, :].T, lod[b, n, :]
         assert np.abs(np.linalg.pinv(A) @ rhs - x2[b]).max() < 1e-10
+
+
+@pytest.mark.parametrize("reg_type", [1, 3, 4, 5, 8])
+def test_regularization_single_level_is_damped_least_squares(oracle, reg_type):
+    """One full-column-rank level: every regularization type of the family reduces to (A'A + mu^2 I)^-1 A'b
+    (lexlse.h:1700-2236 with an empty null-space basis); tolerance of the reference's MATLAB suites."""
+    n, dims, f = 6, [9], 0.7
+    lod = P.lse_batch(11, 3, n, dims)
+    x = oracle.lse_run(lod, dims, n, reg_type=reg_type, reg_factors=[f])["x"]
+    for b in range(3):
+        A, rhs = lod[b, :n, :].T, lod[b, n, :]
+        assert np.abs(np.linalg.solve(A.T @ A + f * f * np.eye(n), A.T @ rhs) - x[b]).max() < 1e-10
+
+
+def test_regularization_consistency_properties(oracle):
+    """zero factors == no regularization (bitwise, utility.h:48-51 skips the damping); the two Tikhonov formulations
+    (regularize_tikhonov_1 :1700 / _2 :2076, chosen by size for type 1, always _2 for type 8) agree; the variable factor
+    (lexlse.h:281-311) with a huge threshold damps every level; solveLeastNorm_3 == solveLeastNorm_1."""
+    n, dims = 12, [3, 4, 2]
+    lod = P.lse_batch(7, 3, n, dims)
+    x0 = oracle.lse_run(lod, dims, n)["x"]
+    for t in (1, 3, 4, 5, 8, 9):
+        np.testing.assert_array_equal(oracle.lse_run(lod, dims, n, reg_type=t, reg_factors=[0, 0, 0])["x"], x0)
+    fac = [0.3, 0.5, 0.2]
+    x1 = oracle.lse_run(lod, dims, n, reg_type=1, reg_factors=fac)["x"]
+    x8 = oracle.lse_run(lod, dims, n, reg_type=8, reg_factors=fac)["x"]
+    assert np.abs(x1 - x8).max() < 1e-10 and np.abs(x1 - x0).max() > 1e-3
+    xv = oracle.lse_run(lod, dims, n, reg_type=1, reg_factors=fac, var_reg=1e6)["x"]
+    assert np.abs(xv - x0).max() > 1e-3
+    n, dims = 40, [6] * 5
+    lod = P.lse_batch(61, 2, n, dims)
+    a = oracle.lse_run(lod, dims, n, solve_option=1)["x"]
+    c = oracle.lse_run(lod, dims, n, solve_option=3, reg_type=1, reg_factors=[0] * 5)["x"]
+    assert np.abs(a - c).max() < 1e-10
