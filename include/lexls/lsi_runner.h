@@ -23,6 +23,8 @@ namespace LexLS
             const Index *var_index;      // dims[0] 0-based indices when objective 0 is simple bounds, else unused
             const uint8_t *active_guess; // sum(dims) activation flags (0..3) or NULL
             const double *x0;            // nVar or NULL
+            const double *v0          = NULL; // sum(dims) initial residuals (lexlsi.cpp:573-587, set_v0 per objective) or NULL
+            const double *reg_factors = NULL; // nObj regularization factors (lexlsi.cpp:539, setRegularizationFactor) or NULL
         };
 
         struct LsiInfo
@@ -56,7 +58,20 @@ namespace LexLS
                 }
                 off += objective_size(p, k);
             }
+            if (p.reg_factors)
+                for (Index k = 0; k < p.nObj; k++)
+                    if (!(types[k] == SIMPLE_BOUNDS_OBJECTIVE && p.reg_factors[k] == 0.0)) lsi.setRegularizationFactor(k, p.reg_factors[k]); // (objective.h:820 warns for simple bounds)
             if (p.x0) lsi.set_x0(dVectorType(p.x0, p.nVar));
+            if (p.v0)
+            {
+                size_t r = 0;
+                for (Index k = 0; k < p.nObj; k++)
+                {
+                    dVectorType vk(p.v0 + r, dims[k]);
+                    lsi.set_v0(k, vk);
+                    r += dims[k];
+                }
+            }
             if (p.active_guess)
             {
                 size_t r = 0;

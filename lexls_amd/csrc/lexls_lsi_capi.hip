@@ -20,7 +20,9 @@ using namespace LexLS;
 namespace
 {
 
-    ParametersLexLSI unpack(const double *p)
+    /// p[0..9): see lexls_lsi_solve; p[9..12) (only read when nparams >= 12): regularization_type, variable_regularization_factor,
+    /// max_number_of_CG_iterations (typedefs.h:185-187)
+    ParametersLexLSI unpack(const double *p, uint32_t nparams = 9)
     {
         ParametersLexLSI par;
         if (p)
@@ -34,6 +36,12 @@ namespace
             par.cycling_max_counter          = static_cast<Index>(p[6]);
             par.cycling_relax_step           = p[7];
             par.deactivate_first_wrong_sign  = p[8] != 0;
+            if (nparams >= 12)
+            {
+                par.regularization_type            = static_cast<RegularizationType>(static_cast<int>(p[9]));
+                par.variable_regularization_factor = p[10];
+                par.max_number_of_CG_iterations    = static_cast<Index>(p[11]);
+            }
         }
         return par;
     }
@@ -497,6 +505,31 @@ extern "C"
             internal::LexLSI lsi;
             lsi.getLexLSE().setDevice(device);
             runner::setup(lsi, p, unpack(h_params9));
+            lsi.solve();
+            runner::LsiInfo info;
+            runner::collect(lsi, p, h_x, &info, h_active, h_v);
+            if (h_info6) std::memcpy(h_info6, &info, sizeof(info));
+            return LEXLS_OK;
+        }
+        catch (const std::exception &e)
+        {
+            lexls_internal_set_error(e.what());
+            return LEXLS_ERR_INVALID;
+        }
+    }
+
+    int lexls_lsi_solve_ex(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types, const double *h_data,
+                           const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_v0,
+                           const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
+                           double *h_v)
+    {
+        try
+        {
+            if (h_params && nparams != 9 && nparams != 12) throw Exception("lexls_lsi_solve_ex: 9 or 12 parameters expected");
+            runner::LsiProblem p = {nVar, nObj, h_dims, h_types, h_data, h_var_index, h_active_guess, h_x0, h_v0, h_reg_factors};
+            internal::LexLSI lsi;
+            lsi.getLexLSE().setDevice(device);
+            runner::setup(lsi, p, unpack(h_params, nparams));
             lsi.solve();
             runner::LsiInfo info;
             runner::collect(lsi, p, h_x, &info, h_active, h_v);

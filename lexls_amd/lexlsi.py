@@ -14,6 +14,9 @@ from . import capi
 PARAM_KEYS = ["max_number_of_factorizations", "tol_linear_dependence", "tol_wrong_sign_lambda", "tol_correct_sign_lambda",
               "tol_feasibility", "cycling_handling_enabled", "cycling_max_counter", "cycling_relax_step", "deactivate_first_wrong_sign"]
 PARAM_DEFAULTS = [200, 1e-12, 1e-8, 1e-12, 1e-13, 0, 50, 1e-8, 0]  # typedefs.h:268-294
+# the three regularization parameters of ParametersLexLSI (typedefs.h:185-187) travel only through the *_ex entry points
+REG_PARAM_KEYS = ["regularization_type", "variable_regularization_factor", "max_number_of_CG_iterations"]
+REG_PARAM_DEFAULTS = [0, 0.0, 10]
 INFO_KEYS = ["status", "iterations", "activations", "deactivations", "factorizations", "total_rank"]
 
 
@@ -21,6 +24,14 @@ def pack_params(**kw) -> np.ndarray:
     vals = list(PARAM_DEFAULTS)
     for k, v in kw.items():
         vals[PARAM_KEYS.index(k)] = float(v)
+    return np.array(vals, dtype=np.float64)
+
+
+def pack_params_ex(**kw) -> np.ndarray:
+    """the 9 parameters of pack_params followed by regularization_type, variable_regularization_factor, max_number_of_CG_iterations"""
+    keys, vals = PARAM_KEYS + REG_PARAM_KEYS, list(PARAM_DEFAULTS) + list(REG_PARAM_DEFAULTS)
+    for k, v in kw.items():
+        vals[keys.index(k)] = float(v)
     return np.array(vals, dtype=np.float64)
 
 
@@ -48,18 +59,31 @@ def _p(a, t):
     return None if a is None else a.ctypes.data_as(C.POINTER(t))
 
 
-def lsi_solve(nvar: int, objectives, active_guess=None, x0=None, device: int = 0, **params):
+def lsi_solve(nvar: int, objectives, active_guess=None, x0=None, device: int = 0, v0=None, regularization_factors=None, **params):
+    """One LexLSI problem through the C ABI.  `v0`: per-objective initial residuals (list of arrays) or None; `regularization_factors`:
+    one per objective or None; `params`: ParametersLexLSI fields (PARAM_KEYS + REG_PARAM_KEYS)."""
     dims, types, data, var_index = flatten(nvar, objectives)
     total = int(dims.sum())
     x, info = np.zeros(nvar), np.zeros(6, np.int32)
     active, v = np.zeros(total, np.uint8), np.zeros(total)
     guess = None if active_guess is None else np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint8) for g in active_guess]))
     x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
-    par = pack_params(**params)
-    capi.check(capi.lib().lexls_lsi_solve(
-        C.c_int(device), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32), _p(data, C.c_double),
-        _p(var_index if var_index.size else None, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(par, C.c_double),
-        _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8), _p(v, C.c_double)))
+    extended = v0 is not None or regularization_factors is not None or any(k in REG_PARAM_KEYS for k in params)
+    if extended:
+        v0a = None if v0 is None else np.ascontiguousarray(np.concatenate([np.asarray(a, np.float64) for a in v0]))
+        rfa = None if regularization_factors is None else np.ascontiguousarray(regularization_factors, np.float64)
+        par = pack_params_ex(**params)
+        capi.check(capi.lib().lexls_lsi_solve_ex(
+            C.c_int(device), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32), _p(data, C.c_double),
+            _p(var_index if var_index.size else None, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(v0a, C.c_double),
+            _p(rfa, C.c_double), _p(par, C.c_double), C.c_uint32(len(par)), _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8),
+            _p(v, C.c_double)))
+    else:
+        par = pack_params(**params)
+        capi.check(capi.lib().lexls_lsi_solve(
+            C.c_int(device), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32), _p(data, C.c_double),
+            _p(var_index if var_index.size else None, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(par, C.c_double),
+            _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8), _p(v, C.c_double)))
     cuts = np.cumsum(dims)[:-1]
     return dict(x=x, info=dict(zip(INFO_KEYS, info.tolist())), active=np.split(active, cuts), v=np.split(v, cuts))
 

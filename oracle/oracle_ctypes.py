@@ -100,10 +100,10 @@ def hardware_threads():
     return int(lib().oracle_hardware_threads())
 
 
-from lexls_amd.lexlsi import flatten as flatten_lsi, pack_params  # noqa: E402  (flat problem layout shared with the product binding)
+from lexls_amd.lexlsi import flatten as flatten_lsi, pack_params, pack_params_ex, REG_PARAM_KEYS  # noqa: E402  (flat problem layout shared with the product binding)
 
 
-def lsi_run(nvar, objectives, active_guess=None, x0=None, **params):
+def lsi_run(nvar, objectives, active_guess=None, x0=None, v0=None, regularization_factors=None, **params):
     dims, types, data, var_index = flatten_lsi(nvar, objectives)
     total = int(dims.sum())
     x = np.zeros(nvar)
@@ -112,6 +112,17 @@ def lsi_run(nvar, objectives, active_guess=None, x0=None, **params):
     v = np.zeros(total)
     guess = None if active_guess is None else np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint8) for g in active_guess]))
     x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
+    keys = ["status", "iterations", "activations", "deactivations", "factorizations", "total_rank"]
+    if v0 is not None or regularization_factors is not None or any(k in REG_PARAM_KEYS for k in params):
+        v0a = None if v0 is None else np.ascontiguousarray(np.concatenate([np.asarray(a, np.float64) for a in v0]))
+        rfa = None if regularization_factors is None else np.ascontiguousarray(regularization_factors, np.float64)
+        par = pack_params_ex(**params)
+        rc = lib().oracle_lsi_run_ex(C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, _u32p), _p(types, _i32p), _p(data, _dp),
+                                     _p(var_index if var_index.size else None, _u32p), _p(guess, _u8p), _p(x0a, _dp), _p(v0a, _dp), _p(rfa, _dp),
+                                     _p(par, _dp), _p(x, _dp), _p(info, _i32p), _p(active, _u8p), _p(v, _dp))
+        if rc:
+            raise RuntimeError(lib().oracle_last_error().decode())
+        return dict(x=x, info=dict(zip(keys, info.tolist())), active=np.split(active, np.cumsum(dims)[:-1]), v=np.split(v, np.cumsum(dims)[:-1]))
     resumable = float(bool(params.pop("resumable", False)))
     par = np.append(pack_params(**params), resumable)
     rc = lib().oracle_lsi_run(C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, _u32p), _p(types, _i32p), _p(data, _dp),

@@ -144,3 +144,61 @@ def test_deactivate_first_wrong_sign_matches_oracle_driver(hip, oracle, seed):
     for a, b in zip(d["active"], o["active"]):
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(d["x"], o["x"])
+
+
+@pytest.mark.parametrize("reg_type,factors", [(1, [0, 0.3, 0.2, 0.4]), (4, [0, 0.5, 0.5, 0.5]), (8, [0, 0.1, 0.3, 0.2])])
+def test_lsi_with_regularization_matches_oracle_driver(hip, oracle, reg_type, factors):
+    """lexlsi.cpp:527-625 also passes regularization factors / types and initial residuals: lexls_lsi_solve_ex.  The damped problems
+    run on the device (generic kernel); trajectories and results equal the oracle-backed driver bit for bit."""
+    n, dims = 20, [6, 5, 5, 6]
+    objs = P.lsi_problem(410, n, dims)
+    d = lexlsi.lsi_solve(n, objs, regularization_type=reg_type, regularization_factors=factors)
+    o = oracle.lsi_run(n, objs, regularization_type=reg_type, regularization_factors=factors)
+    assert d["info"] == o["info"] and d["info"]["status"] == 0
+    np.testing.assert_array_equal(d["x"], o["x"])
+    for a, b in zip(d["active"], o["active"]):
+        np.testing.assert_array_equal(a, b)
+    plain = lexlsi.lsi_solve(n, objs)
+    assert np.abs(plain["x"] - d["x"]).max() > 1e-6  # the damping changed the solution
+
+
+def test_lsi_initial_residuals_v0(hip, oracle):
+    n, dims = 20, [6, 5, 5, 6]
+    objs = P.lsi_problem(411, n, dims)
+    base = oracle.lsi_run(n, objs)
+    v0 = [0.5 * v for v in base["v"]]
+    d = lexlsi.lsi_solve(n, objs, x0=0.5 * base["x"], v0=v0)
+    o = oracle.lsi_run(n, objs, x0=0.5 * base["x"], v0=v0)
+    assert d["info"] == o["info"]
+    np.testing.assert_array_equal(d["x"], o["x"])
+
+
+def test_matlab_style_front_end(hip, oracle):
+    """lexls_amd.frontend mirrors the MEX call shapes lexlse(obj, options) / lexlsi(obj, options, active_set, x0, v0)."""
+    from lexls_amd import frontend
+    n, dims = 12, [3, 4, 2]
+    lod = P.lse_batch(7, 1, n, dims)
+    objs, r = [], 0
+    for m in dims:
+        objs.append(dict(A=lod[0, :n, r:r + m].T.copy(), b=lod[0, n, r:r + m].copy()))
+        r += m
+    x, info, v = frontend.lexlse(objs)
+    ref = oracle.lse_run(lod, dims, n)
+    np.testing.assert_array_equal(x, ref["x"][0])
+    np.testing.assert_array_equal(np.concatenate(v), ref["v"][0])
+    assert info["status"] == 0
+    x1, _, _ = frontend.lexlse(objs, dict(get_least_norm_solution=1))
+    x2, _, _ = frontend.lexlse(objs, dict(get_least_norm_solution=2))
+    x3, _, _ = frontend.lexlse(objs, dict(get_least_norm_solution=3, regularization_type=1))
+    assert np.abs(x1 - x2).max() < 1e-10 and np.abs(x1 - x3).max() < 1e-10
+    xr, _, _ = frontend.lexlse(objs, dict(regularization_type=1, regularization_factors=[0.3, 0.5, 0.2]))
+    np.testing.assert_array_equal(xr, oracle.lse_run(lod, dims, n, reg_type=1, reg_factors=[0.3, 0.5, 0.2])["x"][0])
+    # fixed variables as the first "objective" (lexlse.cpp:148-164)
+    xf, _, _ = frontend.lexlse([dict(var=[5, 1], b=[0.25, -0.5])] + objs)
+    assert xf[5] == 0.25 and xf[1] == -0.5
+    # lexlsi
+    lobjs = P.lsi_problem(412, 20, [6, 5, 5, 6])
+    x, info, v, active = frontend.lexlsi(lobjs, dict(tol_feasibility=1e-13))
+    o = oracle.lsi_run(20, lobjs)
+    np.testing.assert_array_equal(x, o["x"])
+    assert info["number_of_factorizations"] == o["info"]["factorizations"] and len(active) == 4
