@@ -110,6 +110,40 @@ def main():
     if not all_ok:
         raise SystemExit("bench: wrong ranks / non-finite solution — refusing to report a number")
 
+    # ---- outside the timed region: the one place RCCL carries data (north_star: "used only to scatter problem blocks and gather
+    #      solutions").  Rank 0 builds the whole batch, scatters the blocks, every rank checks its block against the shard it generated
+    #      itself, the solutions are gathered on rank 0.  Reported separately; never part of `value`.  A failure here is
+    #      reported, it does not take the benchmark down.
+    scatter_gather = None
+    if world > 1:
+        try:
+            from lexls_amd import sharding
+            cdev = torch.device("cuda", device_index) if args.dist_backend == "nccl" else torch.device("cpu")
+            cap = lod_host.shape[2]
+            root = None
+            if rank == 0:
+                root = torch.from_numpy(np.concatenate([lod_host] + [P.lse_batch(SEED0 + r * batch, batch, NVAR, DIMS) for r in range(1, world)])).to(cdev)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mine = sharding.scatter_problems(root, batch * world, NVAR, cap, device=cdev)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_scatter = time.perf_counter() - t0
+            same = bool(torch.equal(mine.cpu(), torch.from_numpy(lod_host)))  # the block that arrived == the shard this rank generated itself
+            t0 = time.perf_counter()
+            xg = sharding.gather_solutions(torch.from_numpy(x).to(cdev), batch * world, NVAR)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_gather = time.perf_counter() - t0
+            flags = torch.tensor([float(same)], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+            scatter_gather = {"scatter_ms": 1e3 * t_scatter, "gather_ms": 1e3 * t_gather, "bytes_scattered": int(8 * batch * world * (NVAR + 1) * cap),
+                              "blocks_verified": bool(flags.item()), "gathered_shape": list(xg.shape) if rank == 0 else None,
+                              "backend": args.dist_backend}
+        except Exception as exc:  # noqa: BLE001
+            scatter_gather = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
         total = batch * world * args.steps
         value = total / elapsed
@@ -137,6 +171,8 @@ def main():
                          "traffic": _committed_traffic(args.keep_factor), "algorithmic_bytes_per_launch": bytes_per * batch,
                          "kernel_ms": kernel_ms},
         }
+        if scatter_gather is not None:
+            line["scatter_gather"] = scatter_gather
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(lod_host, args.cpu_seconds)
         print(json.dumps(line), flush=True)
