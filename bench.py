@@ -12,6 +12,7 @@ and a final all-gather of per-shard solution checksums.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -55,9 +56,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(minutes=5))
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=5))
 
     import lexls_amd
     from lexls_amd import problems as P
@@ -115,7 +116,7 @@ def main():
     #      itself, the solutions are gathered on rank 0.  Reported separately; never part of `value`.  A failure here is
     #      reported, it does not take the benchmark down.
     scatter_gather = None
-    if world > 1:
+    if world > 1 and not os.environ.get("LEXLS_BENCH_SKIP_SCATTER"):
         try:
             from lexls_amd import sharding
             cdev = torch.device("cuda", device_index) if args.dist_backend == "nccl" else torch.device("cpu")
