@@ -15,7 +15,7 @@
 //          level q (conflict-free), the back-substitution reads rows.  <= 1064 doubles for n = 40, level dims <= 12.
 //
 // ~10 KB of LDS and <= 128 VGPRs per wave -> 4 waves per SIMD (the register-resident kernel: 2), and the level blocks
-// are pulled into L2 while the previous level is being factorised.
+// stream in when their level starts (an L2 warm-up by extra touch loads was measured: 4 % slower).
 // Fixed variables are not handled here (the dispatcher keeps such batches on the register-resident kernel).
 #pragma once
 #include "lqr_wave_common.h"
@@ -119,16 +119,6 @@ namespace lexls
                 }
             };
 
-            // L2 warm-up of a level block: one dword per 64-byte piece of every column segment (the block itself is loaded when
-            // its level starts; a register-resident prefetch would cost MD more doubles per lane for a whole level)
-            auto touch_level = [&](int Frow, int dim) {
-                const char *src = reinterpret_cast<const char *>(in + Frow + (size_t)(lane <= n ? lane : 0) * cap);
-                int t = 0;
-                for (int o = 0; o < dim * 8; o += 64) t += *reinterpret_cast<const volatile int *>(src + o);
-                t += *reinterpret_cast<const volatile int *>(src + dim * 8 - 4);
-                return t; // consumed (by an empty asm) only when the next level starts, so nothing waits for these loads
-            };
-            int warm = 0;
             STAMP(0)
 
             for (int k = 0; k < nObj; k++)
@@ -139,7 +129,6 @@ namespace lexls
                 const bool work  = dim_rt > 0 && (!exhausted || write_factor);
 
                 double hh[MD];
-                asm volatile("" ::"v"(warm));
                 if (work)
                     load_level(hh, F, dim_rt);
                 else
@@ -261,9 +250,6 @@ namespace lexls
                     double nrm = 0.0;
 #pragma unroll
                     for (int r = 0; r < MD; r++) nrm = dfma(hh[r], hh[r], nrm);
-                    // the next level's block starts its way into L2 now (after the first use of hh, so that the wait for hh does
-                    // not also wait for these)
-                    if (k + 1 < nObj && dims[k + 1] > 0) warm = touch_level(F + dim_rt, (int)dims[k + 1]);
 
                     double mytau = 0.0; // lane r: tau of the level's row r (0 where no reflector was made, lexlse.h:239,1683)
                     bool go      = true; // wave-uniform: false once the level hit its rank / the columns ran out
