@@ -92,6 +92,7 @@ namespace lexls
             uint32_t imgp = 0; // bump pointer into IMG
             bool exhausted = false;
             int F          = 0;
+            unsigned parked_levels = 0u; // (factor output) bit k: level k was written by physical column and still has to be re-ordered
 
             // column-per-lane load of one level block; 16-byte loads when the block starts on an even element
             auto load_level = [&](double (&dst)[MD], int Frow, int dim) {
@@ -453,11 +454,23 @@ namespace lexls
                     imgp += (uint32_t)(w * rank);
                 }
                 slots |= (unsigned long long)((lane < n) ? pos : n) << (8 * k);
-                if (write_factor && dim > 0 && lane <= n) // factor rows of this level, still by PHYSICAL column (re-ordered at the end)
+                if (write_factor && dim > 0)
                 {
+                    // Factor rows of this level.  A column that has been pivoted (and the RHS) already sits at its final position and
+                    // goes there directly.  The still-free columns of a full-rank level hold nothing but T entries, which are in the LDS
+                    // image: they are written from there once their final positions are known (end of the kernel).  Only a
+                    // rank-deficient level (free columns then also carry rows below the rank) is parked by PHYSICAL column and
+                    // re-ordered at the end.
+                    const bool parked = rank != dim && ColIndex < n; // wave-uniform; once the columns are exhausted every position is final
+                    if (parked) parked_levels |= 1u << k;
+                    const bool placed = (lane < n && pos < ColIndex) || lane == n;
+                    if (lane <= n && (parked || placed))
+                    {
+                        const size_t col = parked ? (size_t)lane : (size_t)((lane < n) ? pos : n);
 #pragma unroll
-                    for (int r = 0; r < MD; r++)
-                        if (r < dim) out[F + r + (size_t)lane * cap] = hh[r];
+                        for (int r = 0; r < MD; r++)
+                            if (r < dim) out[F + r + col * cap] = hh[r];
+                    }
                 }
                 wave_lds_fence();
                 STAMP(6)
@@ -521,16 +534,34 @@ namespace lexls
                 for (int k = 0; k < nObj; k++)
                 {
                     const int dim = (int)dims[k];
-                    double blk[MD];
-#pragma unroll
-                    for (int r = 0; r < MD; r++) blk[r] = (lane <= n && r < dim) ? out[Fr + r + (size_t)lane * cap] : 0.0;
-                    __syncthreads(); // every column of the block is in registers before any is overwritten
-                    const int slot = (lane < n) ? pos : n;
-                    if (lane <= n && slot != lane)
+                    if ((parked_levels >> k) & 1u)
                     {
+                        double blk[MD];
 #pragma unroll
-                        for (int r = 0; r < MD; r++)
-                            if (r < dim) out[Fr + r + (size_t)slot * cap] = blk[r];
+                        for (int r = 0; r < MD; r++) blk[r] = (lane <= n && r < dim) ? out[Fr + r + (size_t)lane * cap] : 0.0;
+                        // (row r of every column is loaded by ONE instruction and the stores below wait for their data: no column is
+                        //  overwritten before it has been read)
+                        const int slot = (lane < n) ? pos : n;
+                        if (lane <= n && slot != lane)
+                        {
+#pragma unroll
+                            for (int r = 0; r < MD; r++)
+                                if (r < dim) out[Fr + r + (size_t)slot * cap] = blk[r];
+                        }
+                    }
+                    else if (dim > 0) // full-rank level: the columns that were still free take their T entries from the image
+                    {
+                        const int rank    = uni((int)meta[4 * k + 1]);
+                        const int Fc      = uni((int)meta[4 * k + 0]);
+                        const double *img = IMG + uni((int)meta[4 * k + 2]);
+                        const int w       = n + 1 - Fc;
+                        const int myslot  = (int)((slots >> (8 * k)) & 0xffull);
+                        if (lane < n && myslot >= Fc + rank)
+                        {
+#pragma unroll
+                            for (int r = 0; r < MD; r++)
+                                if (r < rank) out[Fr + r + (size_t)pos * cap] = img[r * w + (myslot - Fc)];
+                        }
                     }
                     Fr += dim;
                 }
