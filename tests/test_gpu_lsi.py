@@ -202,3 +202,18 @@ def test_matlab_style_front_end(hip, oracle):
     o = oracle.lsi_run(20, lobjs)
     np.testing.assert_array_equal(x, o["x"])
     assert info["number_of_factorizations"] == o["info"]["factorizations"] and len(active) == 4
+
+
+def test_cpp_drop_in_example(hip, tmp_path):
+    """examples/drop_in.cpp is what a user of the reference writes (LexLSI / LexLSE classes, .dat reader), compiled with plain g++
+    against include/ and linked with liblexls_hip.so: it must reproduce the #Solution block of the reference's own fixture."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "lexls_amd", "csrc")
+    exe = str(tmp_path / "drop_in")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "drop_in.cpp"),
+                           "-L" + libdir, "-llexls_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    r = subprocess.run([exe, os.path.join(GOLDEN, "test_01.dat")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "LexLSI: status 0" in r.stdout and "LexLSE: ranks 3 1" in r.stdout, r.stdout
