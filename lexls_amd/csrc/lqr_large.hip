@@ -239,7 +239,8 @@ namespace lexls
             const double tau  = s->tau;
             const uint32_t ld = R | 1u; // odd: lane t walks column t of the tile without bank conflicts
             double *tile      = smem;   // TC * ld
-            double *es        = tile + (size_t)TC * ld; // R - 1
+            double *es        = tile + (size_t)TC * ld; // R - 1 (+1 pad)
+            double *tmps      = es + R;                 // TC: the dot products of the tile's columns
 
 #ifdef LEXLS_LARGE_STAMPS
             long long t0 = clock64(), t1 = t0, t2 = t0, t3 = t0;
@@ -261,41 +262,28 @@ namespace lexls
 #endif
                 if (tid < nc)
                 {
-                    // restrict: the essential part and the column never overlap, so the LDS reads may run ahead of the stores
-                    double *__restrict__ col      = tile + tid * ld;
-                    const double *__restrict__ ev = es;
-                    double tmp                    = 0.0;
+                    // the ordered dot product of lexlse.h:243-246 (applyHouseholderOnTheLeft): one chain per column, the only serial part
+                    const double *__restrict__ col = tile + tid * ld;
+                    const double *__restrict__ ev  = es;
+                    double tmp                     = 0.0;
 #pragma unroll 16
                     for (uint32_t i = 1; i < R; i++) tmp = dfma(ev[i - 1], col[i], tmp);
                     tmp += col[0];
-                    col[0] = dfma(-tau, tmp, col[0]);
-                    // chunks of 16: all LDS reads of a chunk are issued before its first store (the compiler will not
-                    // move a read above a store to the same LDS array on its own)
-                    uint32_t i = 1;
-                    for (; i + 16 <= R; i += 16)
-                    {
-                        double e16[16], c16[16];
-#pragma unroll
-                        for (int k = 0; k < 16; k++)
-                        {
-                            e16[k] = ev[i - 1 + k];
-                            c16[k] = col[i + k];
-                        }
-#pragma unroll
-                        for (int k = 0; k < 16; k++) col[i + k] = dfma(-(tau * e16[k]), tmp, c16[k]);
-                    }
-                    for (; i < R; i++) col[i] = dfma(-(tau * ev[i - 1]), tmp, col[i]);
-                    if (j0 + tid < n && c + 1 < n) norms[j0 + tid] = dfma(-col[0], col[0], norms[j0 + tid]);
+                    tmps[tid]       = tmp;
+                    const double c0 = dfma(-tau, tmp, col[0]);
+                    if (j0 + tid < n && c + 1 < n) norms[j0 + tid] = dfma(-c0, c0, norms[j0 + tid]);
                 }
                 __syncthreads();
 #ifdef LEXLS_LARGE_STAMPS
                 t2 = clock64();
 #endif
+                // the update itself is independent per element: all threads, fused with the store of the tile
                 for (uint32_t i = tid; i < R; i += 256)
                 {
+                    const double f = (i == 0) ? -tau : -(tau * es[i - 1]);
                     double v[TC];
 #pragma unroll
-                    for (int t = 0; t < TC; t++) v[t] = tile[t * ld + i];
+                    for (int t = 0; t < TC; t++) v[t] = dfma(f, tmps[t], tile[t * ld + i]);
 #pragma unroll
                     for (int t = 0; t < TC; t++)
                         if ((uint32_t)t < nc) W[row + i + (size_t)(j0 + t) * cap] = v[t];
@@ -378,6 +366,72 @@ namespace lexls
                 for (uint32_t q = 0; q < rank; q++) W[gi + (size_t)(Fc + q) * cap] = L[q * 64 + lane];
         }
 
+        /// L <- A_left R^-1, column per thread (level dims <= 1024): thread q owns column q of the block for TRB rows held in registers.
+        /// Step p: thread p finalises L_.p = acc * (1/R_pp) and posts it in LDS; every thread q > p absorbs -L_.p * R[p][q].  Each element
+        /// sees the same ordered chain as in the row-per-lane form above (p ascending, then the product with the reciprocal), so the result
+        /// is bit-identical — but the chain of one row is spread over `rank` threads instead of being walked by one, and a thread streams
+        /// its own (contiguous) column of R in chunks of TCH.
+        constexpr int TRB = 8, TCH = 16;
+        __global__ __launch_bounds__(1024) void large_trsm_cols(LseArgs a, const LargeState *st, uint32_t level)
+        {
+            __shared__ double Lb[2][TRB];
+            const uint32_t b = blockIdx.y, tid = threadIdx.x;
+            if (skipped(a, b)) return;
+            const LargeState *s = st + b;
+            const uint32_t rank = s->rank;
+            if (rank == 0 || level + 1 >= a.nObj) return;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            uint32_t M           = 0;
+            for (uint32_t k = 0; k < nObj; k++) M += dims[k];
+            const uint32_t F = s->F, Fc = s->Fc, Fn = F + s->dim;
+            const uint32_t r0 = Fn + blockIdx.x * TRB;
+            if (r0 >= M) return; // uniform per workgroup
+            double *W         = a.fac + (size_t)b * cap * (n + 1);
+            const bool mine   = tid < rank;
+            double *col       = W + (size_t)(Fc + (mine ? tid : 0)) * cap;
+            double acc[TRB];
+#pragma unroll
+            for (int i = 0; i < TRB; i++) acc[i] = (mine && r0 + i < M) ? col[r0 + i] : 0.0;
+            for (uint32_t p0 = 0; p0 < rank; p0 += TCH)
+            {
+                double rbuf[TCH]; // R[p0 .. p0+TCH)[tid]: this thread's column of R, contiguous in memory
+#pragma unroll
+                for (int j = 0; j < TCH; j++) rbuf[j] = (mine && p0 + j < rank && p0 + j <= tid) ? col[F + p0 + j] : 0.0;
+#pragma unroll
+                for (int j = 0; j < TCH; j++)
+                {
+                    const uint32_t p = p0 + j;
+                    if (p < rank) // uniform
+                    {
+                        const int buf = (int)(p & 1u);
+                        if (tid == p)
+                        {
+                            const double inv = 1.0 / rbuf[j];
+#pragma unroll
+                            for (int i = 0; i < TRB; i++)
+                            {
+                                acc[i]     = acc[i] * inv;
+                                Lb[buf][i] = acc[i];
+                            }
+                        }
+                        __syncthreads();
+                        if (mine && tid > p)
+                        {
+#pragma unroll
+                            for (int i = 0; i < TRB; i++) acc[i] = dfma(-Lb[buf][i], rbuf[j], acc[i]);
+                        }
+                    }
+                }
+            }
+            if (mine)
+            {
+#pragma unroll
+                for (int i = 0; i < TRB; i++)
+                    if (r0 + i < M) col[r0 + i] = acc[i];
+            }
+        }
+
         /// Trailing -= L * Up (lexlse.h:454-469): one row per lane, TJ trailing columns per lane in registers
         __global__ __launch_bounds__(64) void large_gemm(LseArgs a, const LargeState *st, uint32_t level)
         {
@@ -446,7 +500,7 @@ namespace lexls
         uint32_t maxdim = 0;
         for (uint32_t k = 0; k < a.nObj; k++) maxdim = h_level_max[k] > maxdim ? h_level_max[k] : maxdim;
         const size_t piv_lds  = 8 * ((size_t)((maxdim + 1) & ~1u) + 1024 + 16) + 4 * 1024;
-        const size_t app_lds  = 8 * ((size_t)TC * (maxdim | 1u) + maxdim);
+        const size_t app_lds  = 8 * ((size_t)TC * (maxdim | 1u) + maxdim + TC + 2);
         const size_t trsm_lds = 8 * (size_t)((n < maxdim) ? n : maxdim) * 65;
         set_lds(reinterpret_cast<const void *>(large_pivot), piv_lds);
         set_lds(reinterpret_cast<const void *>(large_apply), app_lds);
@@ -471,7 +525,10 @@ namespace lexls
             const uint32_t below = h_rows_max > rows_seen ? h_rows_max - rows_seen : 0;
             if (level + 1 < a.nObj && below > 0)
             {
-                hipLaunchKernelGGL(large_trsm, dim3((below + 63) / 64, B), dim3(64), trsm_lds, s, a, st, level);
+                if (h_level_max[level] <= 1024)
+                    hipLaunchKernelGGL(large_trsm_cols, dim3((below + TRB - 1) / TRB, B), dim3(((h_level_max[level] + 63) / 64) * 64), 0, s, a, st, level);
+                else
+                    hipLaunchKernelGGL(large_trsm, dim3((below + 63) / 64, B), dim3(64), trsm_lds, s, a, st, level);
                 hipLaunchKernelGGL(large_gemm, dim3((below + 63) / 64, (n + TJ) / TJ, B), dim3(64), 0, s, a, st, level);
             }
             e = hipGetLastError();
