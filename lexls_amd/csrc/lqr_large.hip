@@ -14,6 +14,7 @@
 // the device from a small per-problem state record; the host only reads `exhausted` back once per level to stop launching.
 #include "lexls_kernels.h"
 #include "lexls_launch.h"
+#include "lqr_wave_common.h"
 
 #include <cfloat>
 #include <vector>
@@ -28,7 +29,6 @@ namespace lexls
 
     namespace
     {
-        __device__ __forceinline__ double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #ifndef LEXLS_LARGE_TC
 #define LEXLS_LARGE_TC 8
 #endif
@@ -118,23 +118,42 @@ namespace lexls
                     bv = norms[k];
                     bi = k;
                 }
-            red_v[tid] = bv;
-            red_i[tid] = bi;
-            __syncthreads();
-            for (int h = 512; h > 0; h >>= 1)
+            // wave-level first maximum (DPP butterfly + ballot; ties go to the lowest column index), then 16 wave results through LDS
             {
-                if (tid < (uint32_t)h)
+                const double wm          = wave_max(bv);
+                unsigned long long tied  = __ballot(bv == wm && bi != 0xffffffffu);
+                uint32_t best            = 0xffffffffu;
+                while (tied) // more than one lane only on exact ties
                 {
-                    const double v2   = red_v[tid + h];
-                    const uint32_t i2 = red_i[tid + h];
-                    if (v2 > red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid]))
+                    const int l = (int)__builtin_ctzll(tied);
+                    tied &= tied - 1;
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)bi, l);
+                    best               = idx < best ? idx : best;
+                }
+                if ((tid & 63u) == 0)
+                {
+                    red_v[tid >> 6] = wm;
+                    red_i[tid >> 6] = best;
+                }
+            }
+            __syncthreads();
+            if (tid == 0)
+            {
+                double v0   = red_v[0];
+                uint32_t i0 = red_i[0];
+                for (int w = 1; w < 16; w++)
+                {
+                    const double v2   = red_v[w];
+                    const uint32_t i2 = red_i[w];
+                    if (i2 != 0xffffffffu && (i0 == 0xffffffffu || v2 > v0 || (v2 == v0 && i2 < i0)))
                     {
-                        red_v[tid] = v2;
-                        red_i[tid] = i2;
+                        v0 = v2;
+                        i0 = i2;
                     }
                 }
-                __syncthreads();
+                red_i[0] = i0;
             }
+            __syncthreads();
             const uint32_t piv = red_i[0];
 
             // stage the pivot column (coalesced) and run the two ordered chains on two different waves
