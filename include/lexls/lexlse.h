@@ -260,6 +260,20 @@ namespace LexLS
             Index get_nVar() const { return nVar; }
             Index getTotalRank() const { return TotalRank; }
             Index getFixedVariablesCount() const { return nVarFixed; }
+            /// lexlse.h:1495.  The indices as given to fixVariable(); the reference hands out its working copy, which factorize()
+            /// rewrites by the chained-index rule (:146-153) — nothing in the reference reads it afterwards.
+            iVectorType getFixedVarIndex() const
+            {
+                iVectorType v(nVarFixed);
+                for (Index i = 0; i < nVarFixed; i++) v(i) = fixed_idx[i];
+                return v;
+            }
+            /// lexlse.h:1636-1650: filled only by REGULARIZATION_TIKHONOV_1 (regularize_tikhonov_1_test), which has no device path
+            const dMatrixType &get_X_mu() const { throw Exception("lexls_hip: X_mu is produced by REGULARIZATION_TIKHONOV_1 only, which has no device path"); }
+            const dMatrixType &get_X_mu_rhs() const { throw Exception("lexls_hip: X_mu_rhs is produced by REGULARIZATION_TIKHONOV_1 only, which has no device path"); }
+            const dVectorType &get_residual_mu() const { throw Exception("lexls_hip: residual_mu is produced by REGULARIZATION_TIKHONOV_1 only, which has no device path"); }
+            /// lexlse.h:770-861: the debug overload that prints every multiplier; use getWorkspace() after the overloads above
+            void ObjectiveSensitivity(Index) { throw Exception("lexls_hip: the printing overload of ObjectiveSensitivity is not provided"); }
             const dVectorType &getWorkspace() const { return dWorkspace; }
             const dMatrixType &get_data() const { return PROBLEM_DATA; }
             const dMatrixType &get_lexqr()
