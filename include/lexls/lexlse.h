@@ -10,7 +10,7 @@
 //
 // Differences a caller can observe: Eigen types are replaced by the containers of typedefs.h
 // (dMatrixConstRef is a (ptr, rows, cols, ld) view); setCtr takes a pointer to nVar doubles;
-// the CG regularization variants, REGULARIZATION_TIKHONOV_1 and solveGeneralNorm throw.
+// REGULARIZATION_TIKHONOV_1 and solveGeneralNorm throw.
 #pragma once
 
 #include <lexls/typedefs.h>
@@ -83,20 +83,21 @@ namespace LexLS
                 for (Index i = nVarFixed; i < nVar; i++) x(i) = 0.0;
             }
 
-            /// lexlse.h:1467.  Regularization types with a device path: NONE, TIKHONOV, R, R_NO_Z, RT_NO_Z, TIKHONOV_2, TEST
-            /// (the CG variants and TIKHONOV_1 throw)
+            /// lexlse.h:1467.  Every regularization type has a device path except the experimental TIKHONOV_1 (throws)
             void setParameters(const ParametersLexLSE &p)
             {
                 switch (p.regularization_type)
                 {
                 case REGULARIZATION_NONE:
                 case REGULARIZATION_TIKHONOV:
+                case REGULARIZATION_TIKHONOV_CG:
                 case REGULARIZATION_R:
                 case REGULARIZATION_R_NO_Z:
                 case REGULARIZATION_RT_NO_Z:
+                case REGULARIZATION_RT_NO_Z_CG:
                 case REGULARIZATION_TIKHONOV_2:
                 case REGULARIZATION_TEST: break;
-                default: throw Exception("lexls_hip: this regularization type has no device path (CG variants, TIKHONOV_1)");
+                default: throw Exception("lexls_hip: REGULARIZATION_TIKHONOV_1 (experimental) has no device path");
                 }
                 parameters = p;
                 if (h) check(lexls_lse_set_tolerance(h, p.tol_linear_dependence));
@@ -307,6 +308,7 @@ namespace LexLS
                 check(lexls_lse_set_ctr_type(h, ctr_type.data()));
                 check(lexls_lse_set_problem_host(h, LOD.data()));
                 if (reg_factor.size() < nObj) reg_factor.assign(nObj, 0.0);
+                check(lexls_lse_set_cg_iterations(h, parameters.max_number_of_CG_iterations));
                 check(lexls_lse_set_regularization(h, static_cast<int>(parameters.regularization_type), reg_factor.data(), 0,
                                                    parameters.variable_regularization_factor));
             }

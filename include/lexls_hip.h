@@ -116,11 +116,13 @@ int lexls_lse_factorize_solve(lexls_lse_t h, int keep_factor);
 int lexls_lse_solve_least_norm(lexls_lse_t h);
 /* replaces setParameters(regularization_type, variable_regularization_factor) + setRegularizationFactor (lexlse.h:1467, :1477;
  * dispatch lexlse.h:277-411).  type: LexLS::RegularizationType — NONE 0, TIKHONOV 1, R 3, R_NO_Z 4, RT_NO_Z 5, TIKHONOV_2 8, TEST 9
- * (the CG variants 2, 6 and the experimental TIKHONOV_1 7 return LEXLS_ERR_UNSUPPORTED).  h_factors: one factor per level
+ * and the CGLS variants TIKHONOV_CG 2, RT_NO_Z_CG 6 (the experimental TIKHONOV_1 7 returns LEXLS_ERR_UNSUPPORTED).  h_factors: one factor per level
  * (per_problem == 0) or batch x nObj (per_problem != 0); NULL = all zero.  With a type != 0 the factorization runs on the generic kernel. */
 int lexls_lse_set_regularization(lexls_lse_t h, int type, const double *h_factors, int per_problem, double variable_factor);
+/* max_number_of_CG_iterations (typedefs.h:111, default 10): iteration cap of the two CGLS variants */
+int lexls_lse_set_cg_iterations(lexls_lse_t h, uint32_t max_iterations);
 /* replaces solveLeastNorm_3() (lexlse.h:1222-1277): least-norm solution from the null-space basis accumulated by the Tikhonov family
- * (regularization type 1, 3 or 8, normally with all factors zero) */
+ * (regularization type 1, 2, 3 or 8, normally with all factors zero) */
 int lexls_lse_solve_least_norm_3(lexls_lse_t h);
 /* replaces solveLeastNorm_2() (lexlse.h:1138-1213, normal equations of the free variables + Cholesky); needs a factorization */
 int lexls_lse_solve_least_norm_2(lexls_lse_t h);

@@ -63,6 +63,7 @@ struct lexls_lse_s
     bool has_skip;
     int32_t *d_sens, *d_objidx;
     uint32_t reg_type;    // LexLS::RegularizationType, 0 = none
+    uint32_t reg_cg_iters;
     double reg_variable;
     double *d_reg_factor, *d_reg_scratch;
 
@@ -96,6 +97,7 @@ struct lexls_lse_s
         a.scratch    = d_scratch;
         a.skip       = has_skip ? d_skip : nullptr;
         a.reg_type     = reg_type;
+        a.reg_cg_iters = reg_cg_iters;
         a.reg_variable = reg_variable;
         a.reg_factor   = d_reg_factor;
         a.reg_scratch  = d_reg_scratch;
@@ -154,6 +156,7 @@ extern "C"
         h->d_in_owned  = nullptr;
         h->d_cdata     = nullptr;
         h->reg_type    = 0;
+        h->reg_cg_iters = 10; // typedefs.h:170
         h->reg_variable = 0.0;
         h->d_reg_factor = h->d_reg_scratch = nullptr;
         h->deferred_sync = false;
@@ -237,8 +240,8 @@ extern "C"
         CHECK_HANDLE(h);
         switch (type)
         {
-        case 0: case 1: case 3: case 4: case 5: case 8: case 9: break;
-        default: return fail(LEXLS_ERR_UNSUPPORTED, "set_regularization: the CG variants (2, 6) and TIKHONOV_1 (7) have no device path");
+        case 0: case 1: case 2: case 3: case 4: case 5: case 6: case 8: case 9: break;
+        default: return fail(LEXLS_ERR_UNSUPPORTED, "set_regularization: REGULARIZATION_TIKHONOV_1 (7, experimental) has no device path");
         }
         HIP_TRY(hipSetDevice(h->device));
         h->factor_valid = false;
@@ -259,6 +262,14 @@ extern "C"
         }
         HIP_TRY(hipMemcpyAsync(h->d_reg_factor, f.data(), 8 * B * nObj, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream)); // f is a temporary
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_cg_iterations(lexls_lse_t h, uint32_t max_iterations)
+    {
+        CHECK_HANDLE(h);
+        h->reg_cg_iters = max_iterations;
+        h->factor_valid = false;
         return LEXLS_OK;
     }
 
@@ -541,7 +552,7 @@ extern "C"
     int lexls_lse_solve_least_norm_3(lexls_lse_t h)
     {
         if (int rc = need_factor(h, "lexls_lse_solve_least_norm_3")) return rc;
-        if (h->reg_type != 1 && h->reg_type != 8 && h->reg_type != 3)
+        if (h->reg_type != 1 && h->reg_type != 2 && h->reg_type != 8 && h->reg_type != 3)
             return fail(LEXLS_ERR_INVALID, "lexls_lse_solve_least_norm_3: needs a factorization with a regularization type that accumulates the null-space basis (lexlse.h:1217-1221)");
         HIP_TRY(hipSetDevice(h->device));
         if (!h->d_scratch) HIP_TRY(hipMalloc((void **)&h->d_scratch, 8 * (size_t)h->batch * 2 * h->nVar * h->nVar));

@@ -41,6 +41,7 @@ namespace lexls
         double *maxabs;                  // batch
         double *scratch;                 // batch x 2 x nVar x nVar (least-norm only, may be NULL)
         uint32_t reg_type;               // LexLS::RegularizationType (0 = none); != 0 is served by the generic kernel only
+        uint32_t reg_cg_iters;           // max_number_of_CG_iterations (typedefs.h:111), CG variants only
         double reg_variable;             // variable_regularization_factor (typedefs.h:116), 0 = constant factors
         const double *reg_factor;        // batch x nObj regularization factors (lexlse.h:1477)
         double *reg_scratch;             // batch x reg_scratch_doubles(nVar): null-space basis + work matrices (lexls_regularize.h)

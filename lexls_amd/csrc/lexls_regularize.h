@@ -1,6 +1,6 @@
 // Regularization family of LexLSE::factorize (lexlse.h:277-411, :1700-2251, :2592-2625) for the generic kernel: executed by the
-// whole workgroup right after a level's QR, before its Gauss step.  Implemented: TIKHONOV (1), R (3), R_NO_Z (4), RT_NO_Z (5),
-// TIKHONOV_2 (8), TEST (9) and the variable factor; not: the CG variants (2, 6) and the experimental TIKHONOV_1 (7).
+// whole workgroup right after a level's QR, before its Gauss step.  Implemented: TIKHONOV (1), TIKHONOV_CG (2), R (3), R_NO_Z (4),
+// RT_NO_Z (5), RT_NO_Z_CG (6), TIKHONOV_2 (8), TEST (9) and the variable factor; not: the experimental TIKHONOV_1 (7).
 // Arithmetic order = oracle/lexlse_oracle.h (regularize_* there), so the results are bit-identical to the oracle's.
 //
 // Per problem the scratch holds (doubles): NS n x (n+1) [the accumulated null-space basis, lexlse.h:93; it survives the
@@ -14,7 +14,7 @@ namespace lexls
     {
         __device__ __forceinline__ double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-        __host__ __device__ inline size_t reg_scratch_doubles(uint32_t n) { return (size_t)n * (n + 1) + 2 * (size_t)n * n + 2 * (size_t)n + 8; }
+        __host__ __device__ inline size_t reg_scratch_doubles(uint32_t n) { return (size_t)n * (n + 1) + 2 * (size_t)n * n + 2 * (size_t)n + 8 + 10 * (size_t)n; }
 
         struct RegView
         {
@@ -22,7 +22,7 @@ namespace lexls
             size_t ld;
             uint32_t n, nf;
             double *NS;  // n x (n+1), ld = n
-            double *D, *D0, *d, *out, *scal;
+            double *D, *D0, *d, *out, *scal, *cg; // cg: 10 n doubles for the CGLS vectors
             __device__ double &ns(uint32_t i, uint32_t j) const { return NS[i + (size_t)j * n]; }
             __device__ double &w(uint32_t i, uint32_t j) const { return W[i + j * ld]; }
             __device__ double &dd(uint32_t i, uint32_t j) const { return D[i + (size_t)j * n]; }
@@ -44,6 +44,7 @@ namespace lexls
             v.d    = v.D0 + (size_t)n * n;
             v.out  = v.d + n;
             v.scal = v.out + n;
+            v.cg   = v.scal + 8;
             return v;
         }
 
@@ -315,6 +316,118 @@ namespace lexls
             reg_store_rhs<NT>(v, F, rank, v.d, tid);
         }
 
+        /// regularize_tikhonov_CG / regularize_RT_NO_Z_CG (lexlse.h:2256-2279, :2325-2347) with cg_tikhonov / cg_RT (:2370-2554): CGLS on
+        /// [Rk Tk; f Sk; f I] x = [y; f s; 0] from x = 0; arithmetic order of the oracle's regularize_cg
+        template <int NT>
+        __device__ void reg_cg(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, double f, bool with_z, uint32_t max_iter, uint32_t tid)
+        {
+            const uint32_t m0 = with_z ? Fc - v.nf : 0, N = rank + RC, n = v.n;
+            double *x = v.cg, *r1 = x + n, *r2 = r1 + n, *r3 = r2 + n, *q1 = r3 + n, *q2 = q1 + n, *q3 = q2 + n, *sv = q3 + n, *pv = sv + n;
+            auto T_times = [&](const double *vec, uint32_t i) {
+                double t = 0.0;
+                for (uint32_t c = 0; c < RC; c++) t = rfma(v.w(F + i, Fc + rank + c), vec[rank + c], t);
+                return t;
+            };
+            auto R_times = [&](const double *vec, uint32_t i) {
+                double rr = 0.0;
+                for (uint32_t j = i; j < rank; j++) rr = rfma(v.w(F + i, Fc + j), vec[j], rr);
+                return rr;
+            };
+            auto compute_s = [&]() {
+                for (uint32_t i = tid; i < N; i += NT)
+                {
+                    double acc = 0.0;
+                    for (uint32_t k = 0; k < m0; k++) acc = rfma(v.ns(k, Fc + i), r2[k], acc);
+                    double sval = with_z ? (acc + r3[i]) * f : f * r3[i];
+                    double add  = 0.0;
+                    if (i < rank)
+                        for (uint32_t k = 0; k <= i; k++) add = rfma(v.w(F + k, Fc + i), r1[k], add);
+                    else
+                        for (uint32_t k = 0; k < rank; k++) add = rfma(v.w(F + k, Fc + i), r1[k], add);
+                    sv[i] = sval + add;
+                }
+                __syncthreads();
+            };
+            for (uint32_t i = tid; i < N; i += NT) x[i] = 0.0;
+            __syncthreads();
+            for (uint32_t i = tid; i < rank; i += NT)
+            {
+                double t = v.w(F + i, n) - T_times(x, i);
+                t -= R_times(x, i);
+                r1[i] = t;
+            }
+            for (uint32_t k = tid; k < m0; k += NT)
+            {
+                double acc = 0.0;
+                for (uint32_t i = 0; i < N; i++) acc = rfma(v.ns(k, Fc + i), x[i], acc);
+                r2[k] = (v.ns(k, n) - acc) * f;
+            }
+            for (uint32_t i = tid; i < N; i += NT) r3[i] = -f * x[i];
+            __syncthreads();
+            compute_s();
+            for (uint32_t i = tid; i < N; i += NT) pv[i] = sv[i];
+            if (tid == 0)
+            {
+                double g = 0.0;
+                for (uint32_t i = 0; i < N; i++) g = rfma(sv[i], sv[i], g);
+                v.scal[1] = g;
+            }
+            __syncthreads();
+            double gamma = v.scal[1];
+            uint32_t iter = 0;
+            while (sqrt(gamma) > 1e-12 && iter < max_iter) // uniform: gamma is read from memory by every thread
+            {
+                for (uint32_t i = tid; i < rank; i += NT)
+                {
+                    double t = T_times(pv, i);
+                    t += R_times(pv, i);
+                    q1[i] = t;
+                }
+                for (uint32_t k = tid; k < m0; k += NT)
+                {
+                    double acc = 0.0;
+                    for (uint32_t i = 0; i < N; i++) acc = rfma(v.ns(k, Fc + i), pv[i], acc);
+                    q2[k] = acc * f;
+                }
+                for (uint32_t i = tid; i < N; i += NT) q3[i] = f * pv[i];
+                __syncthreads();
+                if (tid == 0)
+                {
+                    double qq = 0.0;
+                    for (uint32_t i = 0; i < rank; i++) qq = rfma(q1[i], q1[i], qq);
+                    for (uint32_t k = 0; k < m0; k++) qq = rfma(q2[k], q2[k], qq);
+                    for (uint32_t i = 0; i < N; i++) qq = rfma(q3[i], q3[i], qq);
+                    v.scal[2] = gamma / qq;
+                }
+                __syncthreads();
+                const double alpha = v.scal[2];
+                for (uint32_t i = tid; i < N; i += NT)
+                {
+                    x[i]  = rfma(alpha, pv[i], x[i]);
+                    r3[i] = rfma(-alpha, q3[i], r3[i]);
+                }
+                for (uint32_t i = tid; i < rank; i += NT) r1[i] = rfma(-alpha, q1[i], r1[i]);
+                for (uint32_t k = tid; k < m0; k += NT) r2[k] = rfma(-alpha, q2[k], r2[k]);
+                __syncthreads();
+                compute_s();
+                if (tid == 0)
+                {
+                    double g = 0.0;
+                    for (uint32_t i = 0; i < N; i++) g = rfma(sv[i], sv[i], g);
+                    v.scal[1] = g;
+                }
+                __syncthreads();
+                const double gamma_previous = gamma;
+                gamma                       = v.scal[1];
+                const double beta           = gamma / gamma_previous;
+                for (uint32_t i = tid; i < N; i += NT) pv[i] = rfma(beta, pv[i], sv[i]);
+                __syncthreads();
+                iter++;
+            }
+            for (uint32_t i = tid; i < rank; i += NT) v.out[i] = R_times(x, i) + T_times(x, i);
+            reg_store_rhs<NT>(v, F, rank, v.out, tid);
+        }
+
         /// lexlse.h:2592-2625
         template <int NT>
         __device__ void reg_accumulate_nullspace(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, uint32_t tid)
@@ -402,6 +515,13 @@ namespace lexls
             case 8: // REGULARIZATION_TIKHONOV_2
                 if (nonzero) reg_tikhonov_2<NT>(v, F, Fc, rank, RC, f, tid);
                 reg_accumulate_nullspace<NT>(v, F, Fc, rank, RC, tid);
+                break;
+            case 2: // REGULARIZATION_TIKHONOV_CG
+                if (nonzero) reg_cg<NT>(v, F, Fc, rank, RC, f, true, a.reg_cg_iters, tid);
+                reg_accumulate_nullspace<NT>(v, F, Fc, rank, RC, tid);
+                break;
+            case 6: // REGULARIZATION_RT_NO_Z_CG
+                if (nonzero) reg_cg<NT>(v, F, Fc, rank, RC, f, false, a.reg_cg_iters, tid);
                 break;
             case 3: // REGULARIZATION_R
                 if (nonzero) reg_R<NT>(v, F, Fc, rank, f, true, tid);

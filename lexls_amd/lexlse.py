@@ -55,13 +55,14 @@ class BatchedLexLSE:
     def setParameters(self, tol_linear_dependence: float = 1e-12):
         capi.check(capi.lib().lexls_lse_set_tolerance(self._h, C.c_double(tol_linear_dependence)))
 
-    def setRegularization(self, regularization_type: int, factors=None, variable_factor: float = 0.0):
-        """lexlse.h:1467/:1477: LexLS::RegularizationType (0 none, 1 Tikhonov, 3 R, 4 R_NO_Z, 5 RT_NO_Z, 8 Tikhonov_2, 9 test) and
+    def setRegularization(self, regularization_type: int, factors=None, variable_factor: float = 0.0, cg_iterations: int = 10):
+        """lexlse.h:1467/:1477: LexLS::RegularizationType (0 none, 1 Tikhonov, 2 Tikhonov by CGLS, 3 R, 4 R_NO_Z, 5 RT_NO_Z, 6 RT_NO_Z by CGLS, 8 Tikhonov_2, 9 test) and
         one factor per level ((nObj,)) or per problem and level ((batch, nObj))"""
         f = None if factors is None else np.ascontiguousarray(factors, dtype=np.float64)
         per = 1 if (f is not None and f.ndim == 2) else 0
         if f is not None and f.shape not in ((self.nObj,), (self.batch, self.nObj)):
             raise ValueError("factors must be (nObj,) or (batch, nObj)")
+        capi.check(capi.lib().lexls_lse_set_cg_iterations(self._h, C.c_uint32(int(cg_iterations))))
         capi.check(capi.lib().lexls_lse_set_regularization(self._h, C.c_int(int(regularization_type)), _ptr(f, C.c_double) if f is not None else None,
                                                            C.c_int(per), C.c_double(variable_factor)))
 

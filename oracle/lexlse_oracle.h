@@ -712,8 +712,8 @@ namespace lexls_oracle
         }
 
         // ------------------------------------------------------------------------------------------
-        // Regularization family (lexlse.h:277-411, :1700-2251, :2592-2625).  Restated: TIKHONOV (1), R (3), R_NO_Z (4),
-        // RT_NO_Z (5), TIKHONOV_2 (8), TEST (9); the CG variants (2, 6) and the experimental TIKHONOV_1 (7) are not.
+        // Regularization family (lexlse.h:277-411, :1700-2554, :2592-2625).  Restated: TIKHONOV (1), TIKHONOV_CG (2), R (3), R_NO_Z (4),
+        // RT_NO_Z (5), RT_NO_Z_CG (6), TIKHONOV_2 (8), TEST (9); the experimental TIKHONOV_1 (7) is not.
         // Arithmetic contract of what Eigen leaves open: every product entry is an ascending fma chain from 0 over the contraction
         // index; "X += s * P" is fma(s, p, x) on the finished entry p; "X -= A*B" accumulates fma(-a, b, x) into x (as the Gauss
         // update does); right-side triangular solves scale by the reciprocal of the diagonal (as the Gauss TRSM does); Cholesky and
@@ -724,12 +724,14 @@ namespace lexls_oracle
             switch (parameters.regularization_type)
             {
             case REGULARIZATION_TIKHONOV:
+            case REGULARIZATION_TIKHONOV_CG:
             case REGULARIZATION_R:
             case REGULARIZATION_R_NO_Z:
             case REGULARIZATION_RT_NO_Z:
+            case REGULARIZATION_RT_NO_Z_CG:
             case REGULARIZATION_TIKHONOV_2:
             case REGULARIZATION_TEST: return;
-            default: throw Exception("oracle: this regularization type is not restated (CG variants, TIKHONOV_1)");
+            default: throw Exception("oracle: REGULARIZATION_TIKHONOV_1 (experimental) is not restated");
             }
         }
 
@@ -860,6 +862,13 @@ namespace lexls_oracle
             case REGULARIZATION_TIKHONOV_2:
                 if (nonzero) regularize_tikhonov_2(F, Fc, rank, RC);
                 accumulate_nullspace_basis(F, Fc, rank, RC);
+                break;
+            case REGULARIZATION_TIKHONOV_CG: // :337-345
+                if (nonzero) regularize_cg(F, Fc, rank, RC, true);
+                accumulate_nullspace_basis(F, Fc, rank, RC);
+                break;
+            case REGULARIZATION_RT_NO_Z_CG: // :371-377
+                if (nonzero) regularize_cg(F, Fc, rank, RC, false);
                 break;
             case REGULARIZATION_R:
                 if (nonzero) regularize_R(F, Fc, rank);
@@ -1025,6 +1034,104 @@ namespace lexls_oracle
             for (Index i = 0; i < rank; i++) D0(i, i) -= mu;
             symv_lower(D0, d, rank);
             for (Index i = 0; i < rank; i++) LOD(F + i, nVar) = d[i];
+        }
+
+        /// regularize_tikhonov_CG (lexlse.h:2256-2279, cg_tikhonov :2370-2461) with with_z, regularize_RT_NO_Z_CG (:2325-2347, cg_RT
+        /// :2472-2554) without: CGLS on  [Rk Tk; f Sk; f I] x = [y; f s; 0]  (the Sk rows only with_z), started from x = 0, at most
+        /// max_number_of_CG_iterations steps, tolerance 1e-12 on ||s||; then rhs <- [Rk Tk] x.
+        /// Contract: every matrix-vector entry is an ascending fma chain from 0 that is then added / subtracted as the reference's
+        /// statement reads; "v += a*w" is fma(a, w, v); squared norms are ascending chains.
+        void regularize_cg(Index F, Index Fc, Index rank, Index RC, bool with_z)
+        {
+            const double f  = aRegularizationFactor;
+            const Index m0  = with_z ? Fc - nVarFixed : 0, N = rank + RC;
+            std::vector<double> x(N, 0.0), r1(rank), r2(m0), r3(N), q1(rank), q2(m0), q3(N), sv(N), pv(N);
+            auto RTx = [&](const std::vector<double> &v, Index i, double &t_out, double &r_out) { // (Tk v_tail)_i and (triu(Rk) v_head)_i
+                double t = 0.0;
+                for (Index c = 0; c < RC; c++) t = std::fma(LOD(F + i, Fc + rank + c), v[rank + c], t);
+                double rr = 0.0;
+                for (Index j = i; j < rank; j++) rr = std::fma(LOD(F + i, Fc + j), v[j], rr);
+                t_out = t;
+                r_out = rr;
+            };
+            auto compute_s = [&]() { // s = [Rk Tk; f Sk; f I]' r
+                for (Index i = 0; i < N; i++)
+                {
+                    double acc = 0.0;
+                    for (Index k = 0; k < m0; k++) acc = std::fma(null_space(k, Fc + i), r2[k], acc);
+                    sv[i] = with_z ? (acc + r3[i]) * f : f * r3[i];
+                }
+                for (Index i = 0; i < rank; i++)
+                {
+                    double acc = 0.0;
+                    for (Index k = 0; k <= i; k++) acc = std::fma(LOD(F + k, Fc + i), r1[k], acc);
+                    sv[i] += acc;
+                }
+                for (Index c = 0; c < RC; c++)
+                {
+                    double acc = 0.0;
+                    for (Index k = 0; k < rank; k++) acc = std::fma(LOD(F + k, Fc + rank + c), r1[k], acc);
+                    sv[rank + c] += acc;
+                }
+            };
+            for (Index i = 0; i < rank; i++) // r = [y; f s; 0] - [Rk Tk; f Sk; f I] x   (x = 0)
+            {
+                double t, rr;
+                RTx(x, i, t, rr);
+                r1[i] = LOD(F + i, nVar) - t;
+                r1[i] -= rr;
+            }
+            for (Index k = 0; k < m0; k++)
+            {
+                double acc = 0.0;
+                for (Index i = 0; i < N; i++) acc = std::fma(null_space(k, Fc + i), x[i], acc);
+                r2[k] = (null_space(k, nVar) - acc) * f;
+            }
+            for (Index i = 0; i < N; i++) r3[i] = -f * x[i];
+            compute_s();
+            pv           = sv;
+            double gamma = sqnorm(sv.data(), N);
+            Index iter   = 0;
+            while (std::sqrt(gamma) > 1e-12 && iter < parameters.max_number_of_CG_iterations)
+            {
+                for (Index i = 0; i < rank; i++)
+                {
+                    double t, rr;
+                    RTx(pv, i, t, rr);
+                    q1[i] = t;
+                    q1[i] += rr;
+                }
+                for (Index k = 0; k < m0; k++)
+                {
+                    double acc = 0.0;
+                    for (Index i = 0; i < N; i++) acc = std::fma(null_space(k, Fc + i), pv[i], acc);
+                    q2[k] = acc * f;
+                }
+                for (Index i = 0; i < N; i++) q3[i] = f * pv[i];
+                double qq = 0.0; // q.squaredNorm(): one chain over [q1; q2; q3]
+                for (Index i = 0; i < rank; i++) qq = std::fma(q1[i], q1[i], qq);
+                for (Index k = 0; k < m0; k++) qq = std::fma(q2[k], q2[k], qq);
+                for (Index i = 0; i < N; i++) qq = std::fma(q3[i], q3[i], qq);
+                const double alpha = gamma / qq;
+                for (Index i = 0; i < N; i++) x[i] = std::fma(alpha, pv[i], x[i]);
+                for (Index i = 0; i < rank; i++) r1[i] = std::fma(-alpha, q1[i], r1[i]);
+                for (Index k = 0; k < m0; k++) r2[k] = std::fma(-alpha, q2[k], r2[k]);
+                for (Index i = 0; i < N; i++) r3[i] = std::fma(-alpha, q3[i], r3[i]);
+                compute_s();
+                const double gamma_previous = gamma;
+                gamma                       = sqnorm(sv.data(), N);
+                const double beta           = gamma / gamma_previous;
+                for (Index i = 0; i < N; i++) pv[i] = std::fma(beta, pv[i], sv[i]);
+                iter++;
+            }
+            std::vector<double> out(rank);
+            for (Index i = 0; i < rank; i++)
+            {
+                double t, rr;
+                RTx(x, i, t, rr);
+                out[i] = rr + t;
+            }
+            for (Index i = 0; i < rank; i++) LOD(F + i, nVar) = out[i];
         }
 
         /// lexlse.h:2592-2625

@@ -52,6 +52,7 @@ namespace
         int type = 0;
         std::vector<double> factors;
         double variable = 0.0;
+        unsigned cg_iterations = 10; // typedefs.h:170
     } g_reg;
 
     void run_one(const LseBatchArgs &a, uint32_t b, OLSE &lse, uint32_t cap)
@@ -139,6 +140,7 @@ namespace
         p.tol_linear_dependence = a.tol;
         p.regularization_type            = static_cast<RegularizationType>(g_reg.type);
         p.variable_regularization_factor = g_reg.variable;
+        p.max_number_of_CG_iterations    = g_reg.cg_iterations;
         lse.setParameters(p);
         for (uint32_t b = b0; b < b1; b++) run_one(a, b, lse, cap);
         return 0;
@@ -150,8 +152,9 @@ extern "C"
     const char *oracle_last_error() { return g_err.c_str(); }
 
     /// regularization used by the following oracle_lse_run calls: type = LexLS::RegularizationType, factors = one per level (or NULL)
-    void oracle_lse_set_regularization(int type, uint32_t nObj, const double *factors, double variable_factor)
+    void oracle_lse_set_regularization(int type, uint32_t nObj, const double *factors, double variable_factor, uint32_t cg_iterations)
     {
+        g_reg.cg_iterations = cg_iterations ? cg_iterations : 10;
         g_reg.type = type;
         g_reg.factors.assign(factors ? factors : NULL, factors ? factors + nObj : NULL);
         g_reg.variable = variable_factor;

@@ -38,7 +38,7 @@ def _p(a, typ):
 
 def lse_run(lod, dims, nvar, maxdim=None, tol=1e-12, nfixed=None, fixed_idx=None, fixed_val=None, fixed_type=None,
             ctr_type=None, solve_option=0, sens_obj=-1, tol_wrong=1e-8, tol_correct=1e-12, nthreads=1,
-            reg_type=0, reg_factors=None, var_reg=0.0):
+            reg_type=0, reg_factors=None, var_reg=0.0, cg_iters=10):
     """lod: (batch, nVar+1, cap) C array; dims: (batch, nObj) or (nObj,). Returns dict of numpy outputs."""
     lod = np.ascontiguousarray(lod, dtype=np.float64)
     batch, ncol, cap = lod.shape
@@ -69,7 +69,7 @@ def lse_run(lod, dims, nvar, maxdim=None, tol=1e-12, nfixed=None, fixed_idx=None
     if ctr_type is not None:
         ctr_type = np.ascontiguousarray(ctr_type, np.uint8)
     rf = None if reg_factors is None else np.ascontiguousarray(reg_factors, np.float64)
-    lib().oracle_lse_set_regularization(C.c_int(int(reg_type)), C.c_uint32(nobj), _p(rf, _dp), C.c_double(var_reg))
+    lib().oracle_lse_set_regularization(C.c_int(int(reg_type)), C.c_uint32(nobj), _p(rf, _dp), C.c_double(var_reg), C.c_uint32(int(cg_iters)))
     rc = lib().oracle_lse_run(
         C.c_uint32(batch), C.c_uint32(nvar), C.c_uint32(nobj), _p(maxdim, _u32p), _p(dims, _u32p), _p(lod, _dp), C.c_double(tol),
         _p(nfixed, _u32p), _p(fixed_idx, _u32p), _p(fixed_val, _dp), _p(fixed_type, _u8p), _p(ctr_type, _u8p),
@@ -77,7 +77,7 @@ def lse_run(lod, dims, nvar, maxdim=None, tol=1e-12, nfixed=None, fixed_idx=None
         _p(out["x"], _dp), _p(out["factor"], _dp), _p(out["hh"], _dp), _p(out["perm"], _u32p), _p(out["rank"], _u32p),
         _p(out["fcol"], _u32p), _p(out["totalrank"], _u32p), _p(out["v"], _dp), _p(out["lam"], _dp), _p(out["sens"], _i32p),
         _p(out["maxabs"], _dp), _p(out["ctr_type_out"], _u8p), C.c_int(nthreads))
-    lib().oracle_lse_set_regularization(C.c_int(0), C.c_uint32(0), None, C.c_double(0.0))
+    lib().oracle_lse_set_regularization(C.c_int(0), C.c_uint32(0), None, C.c_double(0.0), C.c_uint32(10))
     if rc:
         raise RuntimeError(lib().oracle_last_error().decode())
     return out

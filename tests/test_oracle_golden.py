@@ -206,3 +206,16 @@ def test_regularization_consistency_properties(oracle):
     a = oracle.lse_run(lod, dims, n, solve_option=1)["x"]
     c = oracle.lse_run(lod, dims, n, solve_option=3, reg_type=1, reg_factors=[0] * 5)["x"]
     assert np.abs(a - c).max() < 1e-10
+
+
+def test_regularization_cg_variants_converge_to_the_direct_ones(oracle):
+    """REGULARIZATION_TIKHONOV_CG / RT_NO_Z_CG (lexlse.h:2256-2554) run CGLS on the same stacked system the direct variants solve
+    through the normal equations: with enough iterations they must agree (and the default 10 iterations stay close)."""
+    n, dims, fac = 12, [3, 4, 2], [0.3, 0.5, 0.2]
+    lod = P.lse_batch(7, 3, n, dims)
+    x1 = oracle.lse_run(lod, dims, n, reg_type=1, reg_factors=fac)["x"]
+    x2 = oracle.lse_run(lod, dims, n, reg_type=2, reg_factors=fac, cg_iters=300)["x"]
+    x5 = oracle.lse_run(lod, dims, n, reg_type=5, reg_factors=fac)["x"]
+    x6 = oracle.lse_run(lod, dims, n, reg_type=6, reg_factors=fac, cg_iters=300)["x"]
+    assert np.abs(x1 - x2).max() < 1e-9 and np.abs(x5 - x6).max() < 1e-9
+    assert np.abs(oracle.lse_run(lod, dims, n, reg_type=2, reg_factors=fac)["x"] - x1).max() < 1e-6
