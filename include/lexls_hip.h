@@ -178,6 +178,13 @@ int lexls_lsi_solve(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_
 int lexls_lsi_batch_solve(int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types,
                           const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
                           const double *h_params9, double *h_x, int32_t *h_info6, uint8_t *h_active, double *h_v, int32_t *h_rounds2);
+/* lexls_lsi_batch_solve with the regularization inputs of lexls_lsi_solve_ex: h_reg_factors = one factor per objective, shared by the batch,
+ * or NULL; h_params with nparams == 9 or 12 (+ regularization_type, variable_regularization_factor, max_number_of_CG_iterations).
+ * Regularized batches run their factorizations on the generic kernel. */
+int lexls_lsi_batch_solve_ex(int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types,
+                             const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
+                             const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6,
+                             uint8_t *h_active, double *h_v, int32_t *h_rounds2);
 /* lexls_lsi_solve plus what the MEX front end also passes (interfaces/matlab-octave/lexlsi.cpp:527-625): h_v0 = initial residuals,
  * sum(dims) doubles (set_v0 per objective) or NULL; h_reg_factors = one regularization factor per objective or NULL; h_params with
  * nparams == 9 (as lexls_lsi_solve) or 12: + regularization_type, variable_regularization_factor, max_number_of_CG_iterations. */

@@ -99,6 +99,11 @@ namespace
         double *lod = NULL; // B x cap x (n+1), PINNED: host-staging fallback, uploaded every active-set round
         Pinned<uint8_t> fixed_type, ctr_type, skip;
         Pinned<int32_t> sens, objidx;
+        std::vector<double> reg_factor;        // B x nObjL regularization factors (host copy; uploaded when they change)
+        int reg_type = 0;                      // LexLS::RegularizationType shared by the batch
+        double reg_variable = 0.0;
+        uint32_t reg_cg_iters = 10;
+        std::atomic<bool> reg_dirty{false};
         bool gather = false;                   // constraint data resident on the device: only row references travel per round
         int rounds_fs = 0, rounds_sens = 0;
         double t_up = 0, t_kern = 0, t_down = 0, t_sens = 0; // seconds, reported when LEXLS_LSI_TIMING is set
@@ -131,6 +136,7 @@ namespace
             sens.assign((size_t)B * 3, 0);
             objidx.assign(B, -1);
             maxabs.assign(B, 0.0);
+            reg_factor.assign((size_t)B * nObjL, 0.0);
             row_src.assign((size_t)B * cap, 0);
             row_ld.assign((size_t)B * cap, 0);
         }
@@ -148,6 +154,11 @@ namespace
             hip_check(lexls_lse_set_fixed(h, nfixed.data(), fixed_idx.data(), fixed_val.data(), fixed_type.data()));
             hip_check(lexls_lse_set_ctr_type(h, ctr_type.data()));
             hip_check(lexls_lse_set_skip(h, skip.data()));
+            if (reg_type != 0 && reg_dirty.exchange(false)) // the factors are the same every round: uploaded once (this call synchronises)
+            {
+                hip_check(lexls_lse_set_cg_iterations(h, reg_cg_iters));
+                hip_check(lexls_lse_set_regularization(h, reg_type, reg_factor.data(), 1, reg_variable));
+            }
             if (gather)
                 hip_check(lexls_lse_gather_problem(h, row_src.data(), row_ld.data()));
             else
@@ -202,10 +213,18 @@ namespace
         }
         void setParameters(const ParametersLexLSE &p)
         {
-            if (p.regularization_type != REGULARIZATION_NONE) throw Exception("lexls_hip: only REGULARIZATION_NONE is implemented on the device path");
-            tol = p.tol_linear_dependence; // the batch handle's tolerance is set once by the batch driver
+            if (p.regularization_type == REGULARIZATION_TIKHONOV_1) throw Exception("lexls_hip: REGULARIZATION_TIKHONOV_1 (experimental) has no device path");
+            tol = p.tol_linear_dependence; // tolerance and regularization type of the batch handle are set once by the batch driver
         }
-        void setRegularizationFactor(Index, RealScalar) {}
+        void setRegularizationFactor(Index ObjIndex, RealScalar factor)
+        {
+            double &f = c->reg_factor[(size_t)b * c->nObjL + ObjIndex];
+            if (f != factor)
+            {
+                f = factor;
+                c->reg_dirty.store(true);
+            }
+        }
         void setObjDim(Index *ObjDim_)
         {
             Index r = 0;
@@ -391,10 +410,20 @@ extern "C"
                               const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
                               const double *h_params9, double *h_x, int32_t *h_info6, uint8_t *h_active, double *h_v, int32_t *h_rounds2)
     {
+        return lexls_lsi_batch_solve_ex(device, batch, nVar, nObj, h_dims, h_types, h_data, h_var_index, h_active_guess, h_x0, NULL, h_params9, 9, h_x,
+                                        h_info6, h_active, h_v, h_rounds2);
+    }
+
+    int lexls_lsi_batch_solve_ex(int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types,
+                                 const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
+                                 const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6,
+                                 uint8_t *h_active, double *h_v, int32_t *h_rounds2)
+    {
         try
         {
             if (batch == 0 || nObj == 0) throw Exception("lexls_lsi_batch_solve: empty batch");
-            const ParametersLexLSI par = unpack(h_params9);
+            if (h_params && nparams != 9 && nparams != 12) throw Exception("lexls_lsi_batch_solve_ex: 9 or 12 parameters expected");
+            const ParametersLexLSI par = unpack(h_params, nparams);
             if (par.deactivate_first_wrong_sign) throw Exception("lexls_lsi_batch_solve: deactivate_first_wrong_sign has no device path");
             const uint32_t off = (h_types[0] == 1) ? 1 : 0;
             if (nObj - off == 0) throw Exception("Problems consisting of one level of simple bounds are not supported."); // lexlsi.cpp:417
@@ -408,6 +437,10 @@ extern "C"
             BatchCtx ctx;
             ctx.create(device, batch, nVar, nObj - off, h_dims + off);
             hip_check(lexls_lse_set_tolerance(ctx.h, par.tol_linear_dependence));
+            ctx.reg_type     = static_cast<int>(par.regularization_type);
+            ctx.reg_variable = par.variable_regularization_factor;
+            ctx.reg_cg_iters = par.max_number_of_CG_iterations;
+            ctx.reg_dirty.store(ctx.reg_type != 0);
             hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between rounds
             if (per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING")) // (diagnostic switch: assemble on the host, stage over PCIe)
             {
@@ -428,7 +461,9 @@ extern "C"
                            h_data + (size_t)b * per_data,
                            h_var_index ? h_var_index + (size_t)b * h_dims[0] : NULL,
                            h_active_guess ? h_active_guess + (size_t)b * total : NULL,
-                           h_x0 ? h_x0 + (size_t)b * nVar : NULL};
+                           h_x0 ? h_x0 + (size_t)b * nVar : NULL,
+                           NULL,
+                           h_reg_factors};
                 runner::setup(*lsi[b], prob[b], par);
                 lsi[b]->begin();
             });

@@ -116,7 +116,7 @@ def pack_batch(nvar: int, problems) -> PackedBatch:
     return PackedBatch(nvar, dims, types, data, var_index)
 
 
-def lsi_batch_solve(nvar: int, problems, active_guess=None, x0=None, device: int = 0, **params):
+def lsi_batch_solve(nvar: int, problems, active_guess=None, x0=None, device: int = 0, regularization_factors=None, **params):
     """Lock-step batch of LexLSI problems of one structure (BASELINE configs[4]).  `problems`: list of objective lists
     (same dims / types) or a PackedBatch; `active_guess`: per problem list of per-objective flag arrays, a (batch, total) uint8
     array, or None; `x0`: (batch, nvar) or None."""
@@ -130,10 +130,18 @@ def lsi_batch_solve(nvar: int, problems, active_guess=None, x0=None, device: int
     x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
     x, info = np.zeros((batch, nvar)), np.zeros((batch, 6), np.int32)
     active, v, rounds = np.zeros((batch, total), np.uint8), np.zeros((batch, total)), np.zeros(2, np.int32)
-    par = pack_params(**params)
-    capi.check(capi.lib().lexls_lsi_batch_solve(
-        C.c_int(device), C.c_uint32(batch), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32), _p(data, C.c_double),
-        _p(var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(par, C.c_double), _p(x, C.c_double), _p(info, C.c_int32),
-        _p(active, C.c_uint8), _p(v, C.c_double), _p(rounds, C.c_int32)))
+    if regularization_factors is not None or any(k in REG_PARAM_KEYS for k in params):
+        par = pack_params_ex(**params)
+        rfa = None if regularization_factors is None else np.ascontiguousarray(regularization_factors, np.float64)
+        capi.check(capi.lib().lexls_lsi_batch_solve_ex(
+            C.c_int(device), C.c_uint32(batch), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32),
+            _p(data, C.c_double), _p(var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(rfa, C.c_double), _p(par, C.c_double),
+            C.c_uint32(len(par)), _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8), _p(v, C.c_double), _p(rounds, C.c_int32)))
+    else:
+        par = pack_params(**params)
+        capi.check(capi.lib().lexls_lsi_batch_solve(
+            C.c_int(device), C.c_uint32(batch), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32), _p(data, C.c_double),
+            _p(var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(par, C.c_double), _p(x, C.c_double), _p(info, C.c_int32),
+            _p(active, C.c_uint8), _p(v, C.c_double), _p(rounds, C.c_int32)))
     return dict(x=x, info=[dict(zip(INFO_KEYS, row.tolist())) for row in info], active=active, v=v,
                 rounds=dict(factorize_solve=int(rounds[0]), sensitivity=int(rounds[1])), dims=dims)

@@ -217,3 +217,19 @@ def test_cpp_drop_in_example(hip, tmp_path):
     r = subprocess.run([exe, os.path.join(GOLDEN, "test_01.dat")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "LexLSI: status 0" in r.stdout and "LexLSE: ranks 3 1" in r.stdout, r.stdout
+
+
+def test_lock_step_batch_with_regularization(hip, oracle):
+    """lexls_lsi_batch_solve_ex: the damped hierarchies of a batch run lock-step on the generic kernel; every instance ends exactly where
+    its stand-alone oracle-backed solve with the same regularization ends."""
+    n, dims, batch = 20, [6, 5, 5, 6], 12
+    factors = [0, 0.3, 0.2, 0.4]
+    problems = [P.lsi_problem(700 + b, n, dims) for b in range(batch)]
+    r = lexlsi.lsi_batch_solve(n, problems, regularization_type=1, regularization_factors=factors)
+    plain = lexlsi.lsi_batch_solve(n, problems)
+    assert np.abs(plain["x"] - r["x"]).max() > 1e-6
+    for b in range(batch):
+        o = oracle.lsi_run(n, problems[b], regularization_type=1, regularization_factors=factors)
+        assert r["info"][b] == o["info"], b
+        np.testing.assert_array_equal(r["x"][b], o["x"])
+        np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
