@@ -1,0 +1,70 @@
+"""Seeded random sweep: shapes, ragged level dimensions, rank deficiencies, fixed variables, kernel policies and both output
+variants — every case bit-identical to the oracle (pivots, ranks, Householder scalars, factor, x).  Complements the targeted
+cases of test_gpu_parity.py: the dispatcher picks lqr_lwave / lqr_wave / lqr_generic depending on the draw."""
+import numpy as np
+import pytest
+
+from lexls_amd import problems as P
+from test_gpu_parity import assert_factor_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(rng):
+    n = int(rng.integers(1, 64))
+    nobj = int(rng.integers(1, 7))
+    md = int(rng.choice([4, 8, 12, 16]))
+    cap_dims = rng.integers(1, md + 1, nobj)
+    while cap_dims.sum() > 64:  # stay inside the wave kernels' row budget most of the time, not always
+        cap_dims[int(rng.integers(0, nobj))] = 1
+        if cap_dims.sum() <= 64 or rng.random() < 0.1:
+            break
+    batch = int(rng.integers(1, 5))
+    dims = np.stack([np.minimum(cap_dims, rng.integers(0, md + 1, nobj)) if rng.random() < 0.5 else cap_dims for _ in range(batch)]).astype(np.uint32)
+    return n, cap_dims.astype(np.uint32), dims, batch
+
+
+@pytest.mark.parametrize("chunk", range(6))
+def test_random_sweep(hip, oracle, chunk):
+    rng = np.random.default_rng(20260700 + chunk)
+    kernels = set()
+    for case in range(25):
+        n, cap_dims, dims, batch = _draw(rng)
+        cap = int(cap_dims.sum())
+        lod = np.zeros((batch, n + 1, cap))
+        for b in range(batch):
+            m = int(dims[b].sum())
+            lod[b, :, :m] = P.normal(int(rng.integers(1, 2**31)), (n + 1) * m).reshape(n + 1, m)
+            if m > 2 and rng.random() < 0.4:  # duplicated / zero rows: rank deficiency inside and across levels
+                i, j = rng.integers(0, m, 2)
+                lod[b, :, i] = lod[b, :, j] if rng.random() < 0.7 else 0.0
+            if n > 2 and rng.random() < 0.3:  # duplicated column: exact ties in the pivot search
+                i, j = rng.integers(0, n, 2)
+                lod[b, i, :] = lod[b, j, :]
+        fixed = {}
+        if rng.random() < 0.35:
+            nf = rng.integers(0, min(n, 4) + 1, batch).astype(np.uint32)
+            idx = np.zeros((batch, n), np.uint32)
+            val = np.zeros((batch, n))
+            for b in range(batch):
+                idx[b, :nf[b]] = rng.choice(n, int(nf[b]), replace=False)
+                val[b, :nf[b]] = rng.normal(size=int(nf[b]))
+            fixed = dict(nfixed=nf, fixed_idx=idx, fixed_val=val)
+        policy = int(rng.choice([0, 0, 1, 2]))
+        keep = bool(rng.random() < 0.6)
+        ref = oracle.lse_run(lod, dims, n, maxdim=cap_dims, **fixed)
+        s = hip.BatchedLexLSE(batch, n, cap_dims)
+        s.set_kernel_policy(policy)
+        s.setObjDim(dims)
+        if fixed:
+            s.fixVariables(fixed["nfixed"], fixed["fixed_idx"], fixed["fixed_val"])
+        s.setProblem(lod)
+        s.factorize_solve(keep_factor=keep)
+        kernels.add(s.last_kernel().split("<")[0])
+        ctx = f"chunk {chunk} case {case}: n={n} cap={cap_dims.tolist()} dims={dims.tolist()} policy={policy} keep={keep} fixed={bool(fixed)} kernel={s.last_kernel()}"
+        np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
+        np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"], err_msg=ctx)
+        np.testing.assert_array_equal(s.getRanks()[0], ref["rank"], err_msg=ctx)
+        if keep:
+            assert_factor_equal(s, ref, dims, n)
+    assert len(kernels) >= 2, kernels
