@@ -145,6 +145,7 @@ int lexls_lse_get_lambda(lexls_lse_t h, double *h_lambda);          /* getWorksp
 /* h_found_ctr_obj: batch x 3 int32 {found, CtrIndex2Remove, ObjIndex2Remove}; h_max_abs: batch */
 int lexls_lse_get_sensitivity(lexls_lse_t h, int32_t *h_found_ctr_obj, double *h_max_abs);
 int lexls_lse_get_ctr_type(lexls_lse_t h, uint8_t *h_types);
+int lexls_lse_get_fixed_type(lexls_lse_t h, uint8_t *h_types);   /* batch x nVar: activation types of the fixed variables incl. the CORRECT_SIGN_OF_LAMBDA marks (lexlse.h:866-987) */
 /* raw device pointer of one of the handle's arrays (enum lexls_array), for zero-copy consumers */
 int lexls_lse_device_ptr(lexls_lse_t h, int which, void **d_ptr);
 

@@ -7,6 +7,7 @@
 #include "lexls_regularize.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -148,6 +149,7 @@ extern "C"
         h->max_rows    = h->cap;
         h->max_level_dim = 0;
         h->force_generic = 0;
+        if (const char *e = std::getenv("LEXLS_KERNEL_POLICY")) h->force_generic = std::atoi(e); // diagnostic default of lexls_lse_set_kernel_policy
         h->tol         = 1e-12; // typedefs.h:120
         h->dims_set    = false;
         h->has_fixed   = false;
@@ -630,6 +632,7 @@ extern "C"
         if (!rc && h_max_abs) rc = download(h, h_max_abs, h->d_maxabs, 8 * (size_t)h->batch);
         return rc;
     }
+    int lexls_lse_get_fixed_type(lexls_lse_t h, uint8_t *h_types) { return h ? download(h, h_types, h->d_fixed_type, (size_t)h->batch * h->nVar) : fail(LEXLS_ERR_INVALID, "null handle"); }
     int lexls_lse_get_ctr_type(lexls_lse_t h, uint8_t *h_types) { return h ? download(h, h_types, h->d_ctr_type, (size_t)h->batch * h->cap) : fail(LEXLS_ERR_INVALID, "null handle"); }
 
     int lexls_lse_device_ptr(lexls_lse_t h, int which, void **d_ptr)

@@ -97,7 +97,7 @@ namespace
         Pinned<uint32_t> dims, nfixed, fixed_idx, row_src, row_ld, tr_dl; // row_src/row_ld: B x cap, where each LOD row comes from (device gather)
         Pinned<double> fixed_val, maxabs, x_dl;
         double *lod = NULL; // B x cap x (n+1), PINNED: host-staging fallback, uploaded every active-set round
-        Pinned<uint8_t> fixed_type, ctr_type, skip;
+        Pinned<uint8_t> fixed_type, ctr_type, skip, ctr_dl, fixed_dl;
         Pinned<int32_t> sens, objidx;
         std::vector<double> reg_factor;        // B x nObjL regularization factors (host copy; uploaded when they change)
         int reg_type = 0;                      // LexLS::RegularizationType shared by the batch
@@ -129,6 +129,8 @@ namespace
             std::memset(lod, 0, 8 * (size_t)B * pstride);
             x.assign((size_t)B * n, 0.0);
             x_dl.assign((size_t)B * n, 0.0);
+            ctr_dl.assign((size_t)B * cap, 0);
+            fixed_dl.assign((size_t)B * n, 0);
             tr_dl.assign(B, 0);
             rank.assign((size_t)B * nObjL, 0);
             totalrank.assign(B, 0);
@@ -187,7 +189,18 @@ namespace
             const double t0 = now();
             hip_check(lexls_lse_sensitivity(h, objidx.data(), 0, tolW, tolC));
             hip_check(lexls_lse_get_sensitivity(h, sens.data(), maxabs.data()));
+            // ObjectiveSensitivity marks constraints CORRECT_SIGN_OF_LAMBDA on the device (lexlse.h:866-987) and the marks must survive
+            // until the instance re-forms its problem: the next factorize round uploads the host arrays for EVERY instance, also for the
+            // ones that are still in the middle of their sensitivity sequence — so the host copy takes the marks over
+            hip_check(lexls_lse_get_ctr_type(h, ctr_dl.data()));
+            hip_check(lexls_lse_get_fixed_type(h, fixed_dl.data()));
             hip_check(lexls_lse_synchronize(h));
+            for (uint32_t b = 0; b < B; b++)
+                if (objidx[b] >= 0)
+                {
+                    std::copy(ctr_dl.begin() + (size_t)b * cap, ctr_dl.begin() + (size_t)(b + 1) * cap, ctr_type.begin() + (size_t)b * cap);
+                    std::copy(fixed_dl.begin() + (size_t)b * n, fixed_dl.begin() + (size_t)(b + 1) * n, fixed_type.begin() + (size_t)b * n);
+                }
             rounds_sens++;
             t_sens += now() - t0;
         }

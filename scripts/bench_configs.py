@@ -80,9 +80,16 @@ t0 = time.perf_counter()
 warm30 = lexlsi.lsi_batch_solve(n, pert30, active_guess=guess, x0=cold["x"])
 t_warm30 = time.perf_counter() - t0
 f30 = np.array([i["factorizations"] for i in warm30["info"]])
+# spot check against the oracle-backed stand-alone driver (first 24 instances of the cold batch): same counters, same x
+from oracle import oracle_ctypes as _O
+_chk = 0
+for b in range(min(24, batch)):
+    o = _O.lsi_run(n, P.lsi_problem(20260500 + b, n, dims))
+    assert cold["info"][b] == o["info"] and np.array_equal(cold["x"][b], o["x"]), f"lock-step instance {b} differs from its stand-alone solve"
+    _chk += 1
 fc = np.array([i["factorizations"] for i in cold["info"]])
 fw = np.array([i["factorizations"] for i in warm["info"]])
-out["config4_lsi_lockstep"] = dict(batch=batch, cold=dict(seconds=t_cold, mean_factorizations=float(fc.mean()), max=int(fc.max()), rounds=cold["rounds"],
+out["config4_lsi_lockstep"] = dict(batch=batch, instances_checked_against_oracle=_chk, cold=dict(seconds=t_cold, mean_factorizations=float(fc.mean()), max=int(fc.max()), rounds=cold["rounds"],
                                                          solved=int(sum(i["status"] == 0 for i in cold["info"]))),
                                    warm=dict(seconds=t_warm, mean_factorizations=float(fw.mean()), max=int(fw.max()), rounds=warm["rounds"],
                                              solved=int(sum(i["status"] == 0 for i in warm["info"])), factorizations_per_s=float(fw.sum() / t_warm)),

@@ -68,3 +68,31 @@ def test_random_sweep(hip, oracle, chunk):
         if keep:
             assert_factor_equal(s, ref, dims, n)
     assert len(kernels) >= 2, kernels
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_random_lsi_sweep(hip, oracle, chunk):
+    """random inequality hierarchies (with / without a simple-bounds level, different sizes) through the single-problem driver and the
+    lock-step batch driver: trajectories (counters, working sets) and x identical to the oracle-backed driver"""
+    from lexls_amd import lexlsi
+    rng = np.random.default_rng(20260800 + chunk)
+    for case in range(5):
+        n = int(rng.integers(6, 30))
+        nobj = int(rng.integers(2, 6))
+        dims = [int(rng.integers(2, 9)) for _ in range(nobj)]
+        simple = bool(rng.random() < 0.6)
+        if simple:
+            dims[0] = min(dims[0], n)
+        batch = int(rng.integers(2, 7))
+        problems = [P.lsi_problem(int(rng.integers(1, 2**30)), n, dims, simple_bounds=simple) for _ in range(batch)]
+        rb = lexlsi.lsi_batch_solve(n, problems)
+        for b in range(batch):
+            o = oracle.lsi_run(n, problems[b])
+            ctx = f"chunk {chunk} case {case} instance {b}: n={n} dims={dims} simple={simple}"
+            assert rb["info"][b] == o["info"], ctx
+            np.testing.assert_array_equal(rb["x"][b], o["x"], err_msg=ctx)
+            np.testing.assert_array_equal(rb["active"][b], np.concatenate(o["active"]), err_msg=ctx)
+        d = lexlsi.lsi_solve(n, problems[0])
+        o = oracle.lsi_run(n, problems[0])
+        assert d["info"] == o["info"]
+        np.testing.assert_array_equal(d["x"], o["x"])
