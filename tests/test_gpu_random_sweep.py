@@ -96,3 +96,85 @@ def test_random_lsi_sweep(hip, oracle, chunk):
         o = oracle.lsi_run(n, problems[0])
         assert d["info"] == o["info"]
         np.testing.assert_array_equal(d["x"], o["x"])
+        # warm start of the whole batch from its own solution's working set (equalities are re-detected, so their flag is dropped)
+        guess = np.where(rb["active"] == 3, 0, rb["active"]).astype(np.uint8)
+        rw = lexlsi.lsi_batch_solve(n, problems, active_guess=guess, x0=rb["x"])
+        cuts = np.cumsum(dims)[:-1]
+        for b in range(batch):
+            o = oracle.lsi_run(n, problems[b], active_guess=np.split(guess[b], cuts), x0=rb["x"][b])
+            assert rw["info"][b] == o["info"], f"warm start, chunk {chunk} case {case} instance {b}"
+            np.testing.assert_array_equal(rw["x"][b], o["x"])
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_random_dual_residual_leastnorm_sweep(hip, oracle, chunk):
+    """ObjectiveSensitivity (multipliers, removal candidate, CORRECT_SIGN marks), get_v and the three least-norm solutions from factors
+    produced by whichever kernel the dispatcher picks — random shapes, activation types, fixed variables, rank deficiencies"""
+    rng = np.random.default_rng(20260900 + chunk)
+    for case in range(15):
+        n = int(rng.integers(3, 45))
+        nobj = int(rng.integers(1, 6))
+        dims = rng.integers(1, 9, nobj).astype(np.uint32)
+        cap, batch = int(dims.sum()), int(rng.integers(1, 4))
+        lod = np.stack([P.normal(int(rng.integers(1, 2**31)), (n + 1) * cap).reshape(n + 1, cap) for _ in range(batch)])
+        if cap > 2 and rng.random() < 0.4:
+            i, j = rng.integers(0, cap, 2)
+            lod[:, :, i] = lod[:, :, j]
+        types = rng.integers(1, 4, (batch, cap)).astype(np.uint8)
+        fixed = {}
+        if rng.random() < 0.4:
+            nf = rng.integers(0, min(n, 3) + 1, batch).astype(np.uint32)
+            idx = np.zeros((batch, n), np.uint32)
+            val = np.zeros((batch, n))
+            typ = np.full((batch, n), 2, np.uint8)
+            for b in range(batch):
+                idx[b, :nf[b]] = rng.choice(n, int(nf[b]), replace=False)
+                val[b, :nf[b]] = rng.normal(size=int(nf[b]))
+                typ[b, :nf[b]] = rng.integers(1, 3, int(nf[b]))
+            fixed = dict(nfixed=nf, fixed_idx=idx, fixed_val=val, fixed_type=typ)
+        level = int(rng.integers(0, nobj))
+        policy = int(rng.choice([0, 1, 2]))
+        ctx = f"chunk {chunk} case {case}: n={n} dims={dims.tolist()} level={level} policy={policy} fixed={bool(fixed)}"
+        ref = oracle.lse_run(lod, dims, n, ctr_type=types, sens_obj=level, **fixed)
+        s = hip.BatchedLexLSE(batch, n, dims)
+        s.set_kernel_policy(policy)
+        if fixed:
+            s.fixVariables(fixed["nfixed"], fixed["fixed_idx"], fixed["fixed_val"], fixed["fixed_type"])
+        s.setProblem(lod)
+        s.setCtrType(types)
+        s.factorize_solve()
+        np.testing.assert_array_equal(s.get_v()[:, :cap], ref["v"][:, :cap], err_msg=ctx)
+        found, ctr, obj, maxabs = s.ObjectiveSensitivity(level)
+        np.testing.assert_array_equal(found.astype(np.int32), ref["sens"][:, 0], err_msg=ctx)
+        np.testing.assert_array_equal(np.where(found, ctr, 0), np.where(found, ref["sens"][:, 1], 0), err_msg=ctx)
+        np.testing.assert_array_equal(np.where(found, obj, 0), np.where(found, ref["sens"][:, 2], 0), err_msg=ctx)
+        np.testing.assert_array_equal(maxabs, ref["maxabs"], err_msg=ctx)
+        np.testing.assert_array_equal(s.getCtrType(), ref["ctr_type_out"], err_msg=ctx)
+        for opt, fn in ((1, s.solveLeastNorm_1), (2, s.solveLeastNorm_2)):
+            fn()
+            np.testing.assert_array_equal(s.get_x(), oracle.lse_run(lod, dims, n, solve_option=opt, **fixed)["x"], err_msg=ctx + f" least-norm {opt}")
+
+
+@pytest.mark.parametrize("chunk", range(2))
+def test_random_regularization_sweep(hip, oracle, chunk):
+    rng = np.random.default_rng(20261000 + chunk)
+    for case in range(16):
+        n = int(rng.integers(2, 30))
+        nobj = int(rng.integers(1, 5))
+        dims = rng.integers(1, 8, nobj).astype(np.uint32)
+        cap = int(dims.sum())
+        lod = P.normal(int(rng.integers(1, 2**31)), (n + 1) * cap).reshape(1, n + 1, cap)
+        if cap > 2 and rng.random() < 0.3:
+            lod[0, :, int(rng.integers(0, cap))] = lod[0, :, int(rng.integers(0, cap))]
+        reg_type = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 9]))
+        fac = np.abs(rng.normal(size=nobj)) * 0.5
+        fac[rng.random(nobj) < 0.2] = 0.0
+        var = float(rng.choice([0.0, 0.0, 10.0, 1e6]))
+        ctx = f"chunk {chunk} case {case}: n={n} dims={dims.tolist()} type={reg_type} factors={fac.tolist()} var={var}"
+        ref = oracle.lse_run(lod, dims, n, reg_type=reg_type, reg_factors=fac, var_reg=var)
+        s = hip.BatchedLexLSE(1, n, dims)
+        s.setRegularization(reg_type, fac, variable_factor=var)
+        s.setProblem(lod)
+        s.factorize_solve()
+        np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
+        np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"], err_msg=ctx)
