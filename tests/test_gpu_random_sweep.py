@@ -178,3 +178,36 @@ def test_random_regularization_sweep(hip, oracle, chunk):
         s.factorize_solve()
         np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
         np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"], err_msg=ctx)
+
+
+@pytest.mark.parametrize("chunk", range(2))
+def test_random_large_path_sweep(hip, oracle, chunk):
+    """problems too large for one CU's LDS (multi-launch large path and the HBM-resident generic kernel): random sizes, ragged levels,
+    duplicated rows — the column-per-thread TRSM and the tiled reflector application must stay bit-identical to the oracle"""
+    rng = np.random.default_rng(20261100 + chunk)
+    seen = set()
+    for case in range(4):
+        n = int(rng.integers(90, 260))
+        nobj = int(rng.integers(2, 5))
+        dims = rng.integers(40, 140, nobj).astype(np.uint32)
+        cap = int(dims.sum())
+        if cap * (n + 1) * 8 <= 170 * 1024:
+            dims[0] += np.uint32((170 * 1024 // (8 * (n + 1))) - cap + 8)
+            cap = int(dims.sum())
+        lod = P.normal(int(rng.integers(1, 2**31)), (n + 1) * cap).reshape(1, n + 1, cap)
+        if rng.random() < 0.5:
+            i, j = rng.integers(0, cap, 2)
+            lod[0, :, i] = lod[0, :, j]
+        policy = int(rng.choice([0, 0, 1]))
+        ref = oracle.lse_run(lod, dims, n)
+        s = hip.BatchedLexLSE(1, n, dims)
+        s.set_kernel_policy(policy)
+        s.setProblem(lod)
+        s.factorize_solve()
+        seen.add(s.last_kernel())
+        ctx = f"chunk {chunk} case {case}: n={n} dims={dims.tolist()} policy={policy} kernel={s.last_kernel()}"
+        np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"], err_msg=ctx)
+        np.testing.assert_array_equal(s.getRanks()[0], ref["rank"], err_msg=ctx)
+        np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
+        assert_factor_equal(s, ref, dims, n)
+    assert any("large" in k for k in seen), seen
