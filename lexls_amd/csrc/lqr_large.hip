@@ -89,7 +89,11 @@ namespace lexls
         }
 
         /// serial part of one pivot (lexlse.h:205-242): one workgroup per problem
-        __global__ __launch_bounds__(1024) void large_pivot(LseArgs a, LargeState *st, double *norms_all, uint32_t level, uint32_t counter)
+#ifndef LEXLS_LARGE_NTP
+#define LEXLS_LARGE_NTP 1024
+#endif
+        constexpr uint32_t NTP = LEXLS_LARGE_NTP; // threads of the one-workgroup pivot kernel
+        __global__ __launch_bounds__(NTP) void large_pivot(LseArgs a, LargeState *st, double *norms_all, uint32_t level, uint32_t counter)
         {
             extern __shared__ double smem[];
             const uint32_t b = blockIdx.y, tid = threadIdx.x;
@@ -112,7 +116,7 @@ namespace lexls
             // first maximum of the down-dated norms
             double bv   = -INFINITY;
             uint32_t bi = 0xffffffffu;
-            for (uint32_t k = c + tid; k < n; k += 1024)
+            for (uint32_t k = c + tid; k < n; k += NTP)
                 if (norms[k] > bv)
                 {
                     bv = norms[k];
@@ -141,7 +145,7 @@ namespace lexls
             {
                 double v0   = red_v[0];
                 uint32_t i0 = red_i[0];
-                for (int w = 1; w < 16; w++)
+                for (int w = 1; w < (int)(NTP / 64); w++)
                 {
                     const double v2   = red_v[w];
                     const uint32_t i2 = red_i[w];
@@ -157,7 +161,7 @@ namespace lexls
             const uint32_t piv = red_i[0];
 
             // stage the pivot column (coalesced) and run the two ordered chains on two different waves
-            for (uint32_t i = tid; i < R; i += 1024) colv[i] = W[row + i + (size_t)piv * cap];
+            for (uint32_t i = tid; i < R; i += NTP) colv[i] = W[row + i + (size_t)piv * cap];
             __syncthreads();
             if (tid == 0)
             {
@@ -202,7 +206,7 @@ namespace lexls
                 }
             }
             // column swap over ALL rows (lexlse.h:222-232) fused with writing beta / the essential part
-            for (uint32_t i = tid; i < M; i += 1024)
+            for (uint32_t i = tid; i < M; i += NTP)
             {
                 const double a1 = W[i + (size_t)c * cap];
                 const double a2 = (i >= row && i < row + R) ? colv[i - row] : W[i + (size_t)piv * cap];
@@ -536,7 +540,7 @@ namespace lexls
             if (!all_exhausted)
                 for (uint32_t counter = 0; counter < h_level_max[level]; counter++)
                 {
-                    hipLaunchKernelGGL(large_pivot, dim3(1, B), dim3(1024), piv_lds, s, a, st, d_norms, level, counter);
+                    hipLaunchKernelGGL(large_pivot, dim3(1, B), dim3(NTP), piv_lds, s, a, st, d_norms, level, counter);
                     hipLaunchKernelGGL(large_apply, dim3((n + TC) / TC, B), dim3(256), app_lds, s, a, st, d_norms, level, counter);
                 }
             hipLaunchKernelGGL(large_level_end, dim3((B + 63) / 64), dim3(64), 0, s, a, st, level);
