@@ -50,6 +50,8 @@ enum lexls_array
     LEXLS_ARRAY_INPUT       /* double   batch x cap x (nVar+1)  library-owned input buffer            */
 };
 
+/* replaces LexLS::Exception::what() (typedefs.h:300-314): no exception crosses the ABI — every entry point returns a status code and
+ * leaves the message of the last failure here */
 const char *lexls_last_error(void);
 int lexls_version(void);
 
