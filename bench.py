@@ -111,6 +111,33 @@ def main():
     if not all_ok:
         raise SystemExit("bench: wrong ranks / non-finite solution — refusing to report a number")
 
+    # ---- outside the timed region, N = 1 only, for the record: the same batch as two half batches on two streams.  Their launches overlap each
+    #      other's launch / first-load / drain floor; a serving loop that keeps two batches in flight gets this rate.  Never `value`.
+    overlapped = None
+    if world == 1 and batch % 2 == 0:
+        try:
+            halves = []
+            for i in range(2):
+                st2 = torch.cuda.Stream()
+                h2 = lexls_amd.BatchedLexLSE(batch // 2, NVAR, DIMS, device=device_index)
+                h2.set_stream(st2.cuda_stream)
+                h2.setProblemDevice(lod_dev.data_ptr() + i * (batch // 2) * lod_host.shape[1] * lod_host.shape[2] * 8)
+                halves.append((h2, st2))
+            for h2, _ in halves:
+                h2.factorize_solve(keep_factor=args.keep_factor)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                for h2, _ in halves:
+                    h2.factorize_solve(keep_factor=args.keep_factor)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            overlapped = {"streams": 2, "value": batch * args.steps / dt, "unit": "factorizations/s", "ms_per_step": 1e3 * dt / args.steps,
+                          "note": "two half batches in flight on two streams; reported next to, not as, the metric"}
+            del halves
+        except Exception as exc:  # noqa: BLE001
+            overlapped = {"error": f"{type(exc).__name__}: {exc}"}
+
     # ---- outside the timed region: the one place RCCL carries data (north_star: "used only to scatter problem blocks and gather
     #      solutions").  Rank 0 builds the whole batch, scatters the blocks, every rank checks its block against the shard it generated
     #      itself, the solutions are gathered on rank 0.  Reported separately; never part of `value`.  A failure here is
@@ -174,6 +201,8 @@ def main():
         }
         if scatter_gather is not None:
             line["scatter_gather"] = scatter_gather
+        if world == 1 and overlapped is not None:
+            line["overlapped"] = overlapped
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(lod_host, args.cpu_seconds)
         print(json.dumps(line), flush=True)
