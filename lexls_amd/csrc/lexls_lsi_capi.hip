@@ -90,6 +90,8 @@ namespace
     struct BatchCtx
     {
         lexls_lse_t h = NULL;
+        hipStream_t stream = NULL; // every group of a lock-step batch has its own stream: group A's kernels run while group B's host logic does
+        bool stage_fs = false, stage_sens = false; // what the stage in flight serves
         uint32_t B = 0, n = 0, nObjL = 0, cap = 0;
         size_t pstride = 0;
         std::vector<uint32_t> maxdim, rank, totalrank;
@@ -106,7 +108,7 @@ namespace
         std::atomic<bool> reg_dirty{false};
         bool gather = false;                   // constraint data resident on the device: only row references travel per round
         int rounds_fs = 0, rounds_sens = 0;
-        double t_up = 0, t_kern = 0, t_down = 0, t_sens = 0; // seconds, reported when LEXLS_LSI_TIMING is set
+        double t_enqueue = 0, t_wait = 0; // seconds, reported when LEXLS_LSI_TIMING is set
         static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
         void create(int device, uint32_t B_, uint32_t n_, uint32_t nObjL_, const uint32_t *maxdim_)
@@ -119,6 +121,8 @@ namespace
             for (uint32_t k = 0; k < nObjL; k++) cap += maxdim[k];
             pstride = (size_t)cap * (n + 1);
             hip_check(lexls_lse_create(&h, device, B, n, nObjL, maxdim.data()));
+            if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) throw Exception("hipStreamCreate failed (lock-step LSI batch)");
+            hip_check(lexls_lse_set_stream(h, stream));
             dims.assign((size_t)B * nObjL, 0);
             nfixed.assign(B, 0);
             fixed_idx.assign((size_t)B * n, 0);
@@ -145,64 +149,71 @@ namespace
         ~BatchCtx()
         {
             if (h) lexls_lse_destroy(h);
+            if (stream) (void)hipStreamDestroy(stream);
             if (lod) (void)hipHostFree(lod);
         }
 
-        /// one batched factorize+solve for every instance with skip == 0
-        void factorize_solve()
+        /// Enqueue ONE stage on this group's stream: a batched factorize+solve for the instances with skip == 0 (if serve_fs) and a batched
+        /// ObjectiveSensitivity for the instances with objidx >= 0 (if serve_sens) — disjoint sets of instances.  Nothing is waited for.
+        void enqueue_stage(bool serve_fs, bool serve_sens, double tolW, double tolC)
         {
             const double t0 = now();
-            hip_check(lexls_lse_set_obj_dim(h, dims.data(), 1));
-            hip_check(lexls_lse_set_fixed(h, nfixed.data(), fixed_idx.data(), fixed_val.data(), fixed_type.data()));
-            hip_check(lexls_lse_set_ctr_type(h, ctr_type.data()));
-            hip_check(lexls_lse_set_skip(h, skip.data()));
-            if (reg_type != 0 && reg_dirty.exchange(false)) // the factors are the same every round: uploaded once (this call synchronises)
+            stage_fs   = serve_fs;
+            stage_sens = serve_sens;
+            if (serve_fs)
             {
-                hip_check(lexls_lse_set_cg_iterations(h, reg_cg_iters));
-                hip_check(lexls_lse_set_regularization(h, reg_type, reg_factor.data(), 1, reg_variable));
-            }
-            if (gather)
-                hip_check(lexls_lse_gather_problem(h, row_src.data(), row_ld.data()));
-            else
-                hip_check(lexls_lse_set_problem_host(h, lod));
-            const double t1 = now();
-            hip_check(lexls_lse_factorize_solve(h, 1));
-            hip_check(lexls_lse_get_x(h, x_dl.data()));
-            hip_check(lexls_lse_get_ranks(h, NULL, NULL, tr_dl.data()));
-            hip_check(lexls_lse_synchronize(h)); // the ONE wait of this round: uploads, assembly, factorization and downloads were only enqueued
-            const double t2 = now();
-            for (uint32_t b = 0; b < B; b++)
-                if (!skip[b])
+                hip_check(lexls_lse_set_obj_dim(h, dims.data(), 1));
+                hip_check(lexls_lse_set_fixed(h, nfixed.data(), fixed_idx.data(), fixed_val.data(), fixed_type.data()));
+                hip_check(lexls_lse_set_ctr_type(h, ctr_type.data()));
+                hip_check(lexls_lse_set_skip(h, skip.data()));
+                if (reg_type != 0 && reg_dirty.exchange(false)) // the factors are the same every round: uploaded once (this call synchronises)
                 {
-                    std::copy(x_dl.begin() + (size_t)b * n, x_dl.begin() + (size_t)(b + 1) * n, x.begin() + (size_t)b * n);
-                    totalrank[b] = tr_dl[b];
+                    hip_check(lexls_lse_set_cg_iterations(h, reg_cg_iters));
+                    hip_check(lexls_lse_set_regularization(h, reg_type, reg_factor.data(), 1, reg_variable));
                 }
-            rounds_fs++;
-            t_up += t1 - t0;
-            t_kern += t2 - t1;
-            t_down += now() - t2;
+                if (gather)
+                    hip_check(lexls_lse_gather_problem(h, row_src.data(), row_ld.data()));
+                else
+                    hip_check(lexls_lse_set_problem_host(h, lod));
+                hip_check(lexls_lse_factorize_solve(h, 1));
+                hip_check(lexls_lse_get_x(h, x_dl.data()));
+                hip_check(lexls_lse_get_ranks(h, NULL, NULL, tr_dl.data()));
+                rounds_fs++;
+            }
+            if (serve_sens)
+            {
+                hip_check(lexls_lse_sensitivity(h, objidx.data(), 0, tolW, tolC));
+                hip_check(lexls_lse_get_sensitivity(h, sens.data(), maxabs.data()));
+                // ObjectiveSensitivity marks constraints CORRECT_SIGN_OF_LAMBDA on the device (lexlse.h:866-987) and the marks must survive
+                // until the instance re-forms its problem: a later factorize stage uploads the host arrays for EVERY instance, also for the
+                // ones that are still in the middle of their sensitivity sequence — so the host copy takes the marks over (finish_stage)
+                hip_check(lexls_lse_get_ctr_type(h, ctr_dl.data()));
+                hip_check(lexls_lse_get_fixed_type(h, fixed_dl.data()));
+                rounds_sens++;
+            }
+            t_enqueue += now() - t0;
         }
 
-        /// one batched ObjectiveSensitivity: objidx[b] < 0 skips instance b
-        void sensitivity(double tolW, double tolC)
+        /// wait for the stage in flight (the ONE synchronisation of a stage) and take its results over
+        void finish_stage()
         {
             const double t0 = now();
-            hip_check(lexls_lse_sensitivity(h, objidx.data(), 0, tolW, tolC));
-            hip_check(lexls_lse_get_sensitivity(h, sens.data(), maxabs.data()));
-            // ObjectiveSensitivity marks constraints CORRECT_SIGN_OF_LAMBDA on the device (lexlse.h:866-987) and the marks must survive
-            // until the instance re-forms its problem: the next factorize round uploads the host arrays for EVERY instance, also for the
-            // ones that are still in the middle of their sensitivity sequence — so the host copy takes the marks over
-            hip_check(lexls_lse_get_ctr_type(h, ctr_dl.data()));
-            hip_check(lexls_lse_get_fixed_type(h, fixed_dl.data()));
             hip_check(lexls_lse_synchronize(h));
-            for (uint32_t b = 0; b < B; b++)
-                if (objidx[b] >= 0)
-                {
-                    std::copy(ctr_dl.begin() + (size_t)b * cap, ctr_dl.begin() + (size_t)(b + 1) * cap, ctr_type.begin() + (size_t)b * cap);
-                    std::copy(fixed_dl.begin() + (size_t)b * n, fixed_dl.begin() + (size_t)(b + 1) * n, fixed_type.begin() + (size_t)b * n);
-                }
-            rounds_sens++;
-            t_sens += now() - t0;
+            t_wait += now() - t0;
+            if (stage_fs)
+                for (uint32_t b = 0; b < B; b++)
+                    if (!skip[b])
+                    {
+                        std::copy(x_dl.begin() + (size_t)b * n, x_dl.begin() + (size_t)(b + 1) * n, x.begin() + (size_t)b * n);
+                        totalrank[b] = tr_dl[b];
+                    }
+            if (stage_sens)
+                for (uint32_t b = 0; b < B; b++)
+                    if (objidx[b] >= 0)
+                    {
+                        std::copy(ctr_dl.begin() + (size_t)b * cap, ctr_dl.begin() + (size_t)(b + 1) * cap, ctr_type.begin() + (size_t)b * cap);
+                        std::copy(fixed_dl.begin() + (size_t)b * n, fixed_dl.begin() + (size_t)(b + 1) * n, fixed_type.begin() + (size_t)b * n);
+                    }
         }
     };
 
@@ -447,26 +458,43 @@ extern "C"
                 total += h_dims[k];
             }
             const double t_begin = BatchCtx::now();
-            BatchCtx ctx;
-            ctx.create(device, batch, nVar, nObj - off, h_dims + off);
-            hip_check(lexls_lse_set_tolerance(ctx.h, par.tol_linear_dependence));
-            ctx.reg_type     = static_cast<int>(par.regularization_type);
-            ctx.reg_variable = par.variable_regularization_factor;
-            ctx.reg_cg_iters = par.max_number_of_CG_iterations;
-            ctx.reg_dirty.store(ctx.reg_type != 0);
-            hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between rounds
-            if (per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING")) // (diagnostic switch: assemble on the host, stage over PCIe)
+            // The instances are split into groups that take turns: while one group's stage runs on the GPU (its own stream), the host
+            // advances the active-set logic of the other one.  LEXLS_LSI_GROUPS overrides the number (1 = strictly alternating host / GPU).
+            uint32_t nGroups = batch >= 256 ? 2u : 1u;
+            if (const char *e = std::getenv("LEXLS_LSI_GROUPS")) nGroups = std::max(1, std::atoi(e));
+            nGroups = std::min(nGroups, batch);
+            const bool gather = per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING"); // (diagnostic switch: assemble on the host, stage over PCIe)
+            std::vector<std::unique_ptr<BatchCtx>> grp(nGroups);
+            std::vector<uint32_t> lo(nGroups + 1, 0);
+            for (uint32_t g = 0; g < nGroups; g++) lo[g + 1] = lo[g] + batch / nGroups + (g < batch % nGroups ? 1u : 0u);
+            for (uint32_t g = 0; g < nGroups; g++)
             {
-                hip_check(lexls_lse_set_constraint_data(ctx.h, h_data, per_data));
-                ctx.gather = true;
+                grp[g].reset(new BatchCtx());
+                BatchCtx &ctx = *grp[g];
+                ctx.create(device, lo[g + 1] - lo[g], nVar, nObj - off, h_dims + off);
+                hip_check(lexls_lse_set_tolerance(ctx.h, par.tol_linear_dependence));
+                ctx.reg_type     = static_cast<int>(par.regularization_type);
+                ctx.reg_variable = par.variable_regularization_factor;
+                ctx.reg_cg_iters = par.max_number_of_CG_iterations;
+                ctx.reg_dirty.store(ctx.reg_type != 0);
+                hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between stages
+                if (gather)
+                {
+                    hip_check(lexls_lse_set_constraint_data(ctx.h, h_data + (size_t)lo[g] * per_data, per_data));
+                    ctx.gather = true;
+                }
             }
+            std::vector<uint32_t> group_of(batch);
+            for (uint32_t g = 0; g < nGroups; g++)
+                for (uint32_t b = lo[g]; b < lo[g + 1]; b++) group_of[b] = g;
 
             std::vector<std::unique_ptr<SlotLSI>> lsi(batch);
             std::vector<runner::LsiProblem> prob(batch);
             WorkerPool pool(WorkerPool::default_workers(batch));
             pool.run(batch, [&](uint32_t b) {
+                const uint32_t g = group_of[b];
                 lsi[b].reset(new SlotLSI());
-                lsi[b]->getLexLSE().bind(&ctx, b);
+                lsi[b]->getLexLSE().bind(grp[g].get(), b - lo[g]);
                 prob[b] = {nVar,
                            nObj,
                            h_dims,
@@ -480,42 +508,54 @@ extern "C"
                 runner::setup(*lsi[b], prob[b], par);
                 lsi[b]->begin();
             });
-
             const double t_setup = BatchCtx::now() - t_begin;
+            double t_host        = 0.0;
 
-            // lock-step rounds: serve every pending factorize+solve in one call, every pending sensitivity in one call
-            while (true)
-            {
+            // one stage of group g: every pending factorize+solve of the group in one call and every pending ObjectiveSensitivity in one
+            // call (different instances), both only enqueued; returns false when no instance of the group is alive any more
+            auto enqueue = [&](uint32_t g) -> bool {
+                BatchCtx &ctx = *grp[g];
                 bool any_fs = false, any_sens = false, any_alive = false;
-                for (uint32_t b = 0; b < batch; b++)
+                for (uint32_t b = lo[g]; b < lo[g + 1]; b++)
                 {
-                    const bool fs   = !lsi[b]->finished() && lsi[b]->need() == SlotLSI::NEED_FACTORIZE_SOLVE;
-                    ctx.skip[b]     = fs ? 0 : 1;
-                    any_fs          = any_fs || fs;
-                    any_alive       = any_alive || !lsi[b]->finished();
+                    const uint32_t k = b - lo[g];
+                    const bool alive = !lsi[b]->finished();
+                    const bool fs    = alive && lsi[b]->need() == SlotLSI::NEED_FACTORIZE_SOLVE;
+                    const bool se    = alive && lsi[b]->need() == SlotLSI::NEED_SENSITIVITY;
+                    ctx.skip[k]      = fs ? 0 : 1;
+                    ctx.objidx[k]    = se ? static_cast<int32_t>(lsi[b]->needLevel()) : -1;
+                    any_fs           = any_fs || fs;
+                    any_sens         = any_sens || se;
+                    any_alive        = any_alive || alive;
                 }
-                if (!any_alive) break;
-                if (any_fs)
-                {
-                    ctx.factorize_solve();
-                    pool.run(batch, [&](uint32_t b) {
-                        if (!ctx.skip[b]) lsi[b]->advance();
-                    });
-                }
-                for (uint32_t b = 0; b < batch; b++)
-                {
-                    const bool se = !lsi[b]->finished() && lsi[b]->need() == SlotLSI::NEED_SENSITIVITY;
-                    ctx.objidx[b] = se ? static_cast<int32_t>(lsi[b]->needLevel()) : -1;
-                    any_sens      = any_sens || se;
-                }
-                if (any_sens)
-                {
-                    ctx.sensitivity(par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
-                    pool.run(batch, [&](uint32_t b) {
-                        if (ctx.objidx[b] >= 0) lsi[b]->advance();
-                    });
-                }
+                if (!any_alive) return false;
                 if (!any_fs && !any_sens) throw Exception("lexls_lsi_batch_solve: an instance is alive but requests nothing");
+                ctx.enqueue_stage(any_fs, any_sens, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
+                return true;
+            };
+            auto finish = [&](uint32_t g) {
+                BatchCtx &ctx = *grp[g];
+                ctx.finish_stage();
+                const double t0 = BatchCtx::now();
+                pool.run(lo[g + 1] - lo[g], [&](uint32_t k) {
+                    if ((ctx.stage_fs && !ctx.skip[k]) || (ctx.stage_sens && ctx.objidx[k] >= 0)) lsi[lo[g] + k]->advance();
+                });
+                t_host += BatchCtx::now() - t0;
+            };
+
+            std::vector<char> alive(nGroups, 0);
+            bool any = false;
+            for (uint32_t g = 0; g < nGroups; g++) any = (alive[g] = enqueue(g)) || any;
+            while (any)
+            {
+                any = false;
+                for (uint32_t g = 0; g < nGroups; g++)
+                    if (alive[g])
+                    {
+                        finish(g);                // the other groups' stages keep the GPU busy meanwhile
+                        alive[g] = enqueue(g);
+                        any      = any || alive[g];
+                    }
             }
 
             for (uint32_t b = 0; b < batch; b++)
@@ -525,14 +565,23 @@ extern "C"
                                 h_v ? h_v + (size_t)b * total : NULL);
                 if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
             }
+            int rounds_fs = 0, rounds_sens = 0;
+            double t_enq = 0.0, t_wait = 0.0;
+            for (uint32_t g = 0; g < nGroups; g++)
+            {
+                rounds_fs += grp[g]->rounds_fs;
+                rounds_sens += grp[g]->rounds_sens;
+                t_enq += grp[g]->t_enqueue;
+                t_wait += grp[g]->t_wait;
+            }
             if (std::getenv("LEXLS_LSI_TIMING"))
-                std::fprintf(stderr, "lexls_lsi_batch_solve: total %.4f s = setup %.4f + upload %.4f + factorize_solve %.4f + download %.4f + sensitivity %.4f + host driver %.4f (%d+%d rounds)\n",
-                             BatchCtx::now() - t_begin, t_setup, ctx.t_up, ctx.t_kern, ctx.t_down, ctx.t_sens,
-                             BatchCtx::now() - t_begin - t_setup - ctx.t_up - ctx.t_kern - ctx.t_down - ctx.t_sens, ctx.rounds_fs, ctx.rounds_sens);
+                std::fprintf(stderr, "lexls_lsi_batch_solve: total %.4f s = setup %.4f + enqueue %.4f + wait for the GPU %.4f + host logic %.4f + rest %.4f (%u groups, %d+%d stages)\n",
+                             BatchCtx::now() - t_begin, t_setup, t_enq, t_wait, t_host, BatchCtx::now() - t_begin - t_setup - t_enq - t_wait - t_host, nGroups,
+                             rounds_fs, rounds_sens);
             if (h_rounds2)
             {
-                h_rounds2[0] = ctx.rounds_fs;
-                h_rounds2[1] = ctx.rounds_sens;
+                h_rounds2[0] = rounds_fs;
+                h_rounds2[1] = rounds_sens;
             }
             return LEXLS_OK;
         }
