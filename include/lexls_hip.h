@@ -105,6 +105,25 @@ int lexls_lse_set_problem_device(lexls_lse_t h, const double *d_lod);
 int lexls_lse_set_constraint_data(lexls_lse_t h, const double *h_data, uint64_t per_problem);
 int lexls_lse_gather_problem(lexls_lse_t h, const uint32_t *h_row_src, const uint32_t *h_row_ld);
 
+/* One copy each way per active-set round (lock-step LexLSI batches).  The handle keeps the small per-round arrays in two device slabs;
+ * lexls_lse_round_layout gives the byte offset of each array inside them so that a host block of the same layout can be moved with one
+ * copy instead of one per array:
+ *   in slab  : dims (u32 batch x nObj) | nfixed (u32 batch) | fixed_idx (u32 batch x nVar) | fixed_val (f64 batch x nVar) | skip (u8 batch)
+ *              | obj_index (i32 batch) | row_src, row_ld (u32 batch x cap) | fixed_type (u8 batch x nVar) | ctr_type (u8 batch x cap)
+ *   out slab : x (f64 batch x nVar) | total_rank (u32 batch) | found (i32 batch x 3) | max_abs (f64 batch)
+ * upload_round  = set_obj_dim(per_problem) + set_fixed + set_ctr_type + set_skip + the obj_index of a later sensitivity_resident
+ *                 (+ gather_problem when gather != 0), with the same argument checks;
+ * download_round: h_out receives the out slab (out_bytes), h_types the tail of the in slab from fixed_type on
+ *                 (in_bytes - fixed_type bytes: fixed_type, then ctr_type at offset ctr_type - fixed_type); either may be NULL. */
+typedef struct lexls_round_layout
+{
+    uint64_t in_bytes, dims, nfixed, fixed_idx, fixed_val, skip, obj_index, row_src, row_ld, fixed_type, ctr_type;
+    uint64_t out_bytes, x, total_rank, found, max_abs;
+} lexls_round_layout;
+int lexls_lse_round_layout(lexls_lse_t h, lexls_round_layout *out);
+int lexls_lse_upload_round(lexls_lse_t h, const void *h_in, int gather);
+int lexls_lse_download_round(lexls_lse_t h, void *h_out, void *h_types);
+
 /* ---- the hot path ------------------------------------------------------------------------------ */
 
 /* replaces factorize() (lexlse.h:117-506): factor, Householder scalars, pivots, ranks on device */
@@ -135,6 +154,8 @@ int lexls_lse_residual(lexls_lse_t h);
  * h_obj_index: one level per problem (batch values; a negative value skips that problem), or NULL
  * with `obj_index_all` applied to every problem.  Results: lexls_lse_get_sensitivity. */
 int lexls_lse_sensitivity(lexls_lse_t h, const int32_t *h_obj_index, int32_t obj_index_all, double tol_wrong_sign_lambda, double tol_correct_sign_lambda);
+/* same, with the per-problem objective indices already on the device (the obj_index array of lexls_lse_upload_round) */
+int lexls_lse_sensitivity_resident(lexls_lse_t h, double tol_wrong_sign_lambda, double tol_correct_sign_lambda);
 
 /* ---- results (synchronise the stream, then D2H) ------------------------------------------------- */
 int lexls_lse_get_x(lexls_lse_t h, double *h_x);                    /* get_x()      lexlse.h:1587 */
@@ -177,8 +198,8 @@ int lexls_lsi_solve(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_
  * active-set round issues one batched factorize+solve and one batched ObjectiveSensitivity per LexLSE level for all the
  * instances that need it (BASELINE configs[4]).  Arrays are the per-problem arrays of lexls_lsi_solve, back to back
  * (h_var_index: batch x dims[0]; h_active_guess / h_x0 may be NULL); h_rounds2 (may be NULL) receives
- * {factorize+solve stages, sensitivity stages} actually issued to the device.  Batches of >= 256 instances are split into two groups that take
- * turns (one group's stage runs on the GPU while the host advances the other group's active sets; LEXLS_LSI_GROUPS overrides the count). */
+ * {factorize+solve stages, sensitivity stages} actually issued to the device.  With LEXLS_LSI_GROUPS=g (default 1) the instances are split
+ * into g groups that take turns: one group's stage runs on the GPU while the host advances the other groups' active sets. */
 int lexls_lsi_batch_solve(int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types,
                           const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
                           const double *h_params9, double *h_x, int32_t *h_info6, uint8_t *h_active, double *h_v, int32_t *h_rounds2);

@@ -67,6 +67,8 @@ struct lexls_lse_s
     uint32_t reg_cg_iters;
     double reg_variable;
     double *d_reg_factor, *d_reg_scratch;
+    char *d_round_in, *d_round_out; // the per-round arrays live in two slabs (lexls_lse_round_layout): one copy each way per round
+    lexls_round_layout lay;
 
     LseArgs args() const
     {
@@ -166,7 +168,7 @@ extern "C"
         h->dims_event = nullptr;
         h->dims_event_pending = false;
         h->cdata_per_problem = 0;
-        h->d_row_src = h->d_row_ld = nullptr;
+        h->d_round_in = h->d_round_out = nullptr;
         h->d_in        = nullptr;
         h->d_scratch   = nullptr;
 
@@ -175,28 +177,58 @@ extern "C"
         auto alloc     = [&](void **p, size_t bytes) {
             if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 8);
         };
+        // the small per-round arrays are carved out of two slabs so that a lock-step driver moves each with ONE copy
+        {
+            auto up = [](uint64_t v) { return (v + 255) & ~uint64_t(255); };
+            lexls_round_layout &L = h->lay;
+            uint64_t o   = 0;
+            L.dims       = o, o = up(o + 4 * B * nObj);
+            L.nfixed     = o, o = up(o + 4 * B);
+            L.fixed_idx  = o, o = up(o + 4 * B * n);
+            L.fixed_val  = o, o = up(o + 8 * B * n);
+            L.skip       = o, o = up(o + B);
+            L.obj_index  = o, o = up(o + 4 * B);
+            L.row_src    = o, o = up(o + 4 * B * cap);
+            L.row_ld     = o, o = up(o + 4 * B * cap);
+            L.fixed_type = o, o = up(o + B * n);
+            L.ctr_type   = o, o = up(o + B * cap);
+            L.in_bytes   = o;
+            o            = 0;
+            L.x          = o, o = up(o + 8 * B * n);
+            L.total_rank = o, o = up(o + 4 * B);
+            L.found      = o, o = up(o + 4 * B * 3);
+            L.max_abs    = o, o = up(o + 8 * B);
+            L.out_bytes  = o;
+            alloc((void **)&h->d_round_in, L.in_bytes);
+            alloc((void **)&h->d_round_out, L.out_bytes);
+            if (e == hipSuccess) e = hipMemset(h->d_round_in, 0, L.in_bytes);
+            if (e == hipSuccess) e = hipMemset(h->d_round_out, 0, L.out_bytes);
+            if (e == hipSuccess)
+            {
+                char *in = h->d_round_in, *out_ = h->d_round_out;
+                h->d_dims       = (uint32_t *)(in + L.dims);
+                h->d_nfixed     = (uint32_t *)(in + L.nfixed);
+                h->d_fixed_idx  = (uint32_t *)(in + L.fixed_idx);
+                h->d_fixed_val  = (double *)(in + L.fixed_val);
+                h->d_skip       = (uint8_t *)(in + L.skip);
+                h->d_objidx     = (int32_t *)(in + L.obj_index);
+                h->d_row_src    = (uint32_t *)(in + L.row_src);
+                h->d_row_ld     = (uint32_t *)(in + L.row_ld);
+                h->d_fixed_type = (uint8_t *)(in + L.fixed_type);
+                h->d_ctr_type   = (uint8_t *)(in + L.ctr_type);
+                h->d_x          = (double *)(out_ + L.x);
+                h->d_totalrank  = (uint32_t *)(out_ + L.total_rank);
+                h->d_sens       = (int32_t *)(out_ + L.found);
+                h->d_maxabs     = (double *)(out_ + L.max_abs);
+            }
+        }
         alloc((void **)&h->d_fac, 8 * B * h->problem_elems());
-        alloc((void **)&h->d_x, 8 * B * n);
         alloc((void **)&h->d_hh, 8 * B * cap);
         alloc((void **)&h->d_v, 8 * B * cap);
         alloc((void **)&h->d_lambda, 8 * B * (n + cap));
-        alloc((void **)&h->d_maxabs, 8 * B);
-        alloc((void **)&h->d_fixed_val, 8 * B * n);
         alloc((void **)&h->d_perm, 4 * B * n);
         alloc((void **)&h->d_rank, 4 * B * nObj);
         alloc((void **)&h->d_fcol, 4 * B * nObj);
-        alloc((void **)&h->d_totalrank, 4 * B);
-        alloc((void **)&h->d_dims, 4 * B * nObj);
-        alloc((void **)&h->d_nfixed, 4 * B);
-        alloc((void **)&h->d_fixed_idx, 4 * B * n);
-        alloc((void **)&h->d_fixed_type, B * n);
-        alloc((void **)&h->d_ctr_type, B * cap);
-        alloc((void **)&h->d_sens, 4 * B * 3);
-        alloc((void **)&h->d_objidx, 4 * B);
-        alloc((void **)&h->d_skip, B);
-        if (e == hipSuccess) e = hipMemset(h->d_ctr_type, 0, B * cap);
-        if (e == hipSuccess) e = hipMemset(h->d_fixed_type, 0, B * n);
-        if (e == hipSuccess) e = hipMemset(h->d_nfixed, 0, 4 * B);
         if (e != hipSuccess)
         {
             lexls_lse_destroy(h);
@@ -211,9 +243,8 @@ extern "C"
     {
         if (!h) return LEXLS_OK;
         (void)hipSetDevice(h->device);
-        void *ptrs[] = {h->d_in_owned, h->d_fac,     h->d_x,      h->d_hh,        h->d_v,        h->d_lambda,     h->d_maxabs,
-                        h->d_scratch,  h->d_fixed_val, h->d_perm,   h->d_rank,      h->d_fcol,     h->d_totalrank,  h->d_dims,
-                        h->d_nfixed,   h->d_fixed_idx, h->d_fixed_type, h->d_ctr_type, h->d_sens,   h->d_objidx,      h->d_skip,       h->d_large_state, h->d_norms, h->d_cdata, h->d_row_src, h->d_row_ld, h->d_reg_factor, h->d_reg_scratch};
+        void *ptrs[] = {h->d_in_owned, h->d_fac, h->d_hh, h->d_v, h->d_lambda, h->d_scratch, h->d_perm, h->d_rank, h->d_fcol, h->d_round_in, h->d_round_out,
+                        h->d_large_state, h->d_norms, h->d_cdata, h->d_reg_factor, h->d_reg_scratch};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (h->h_dims_pinned) (void)hipHostFree(h->h_dims_pinned);
@@ -459,8 +490,6 @@ extern "C"
                 return fail(LEXLS_ERR_INVALID, "gather_problem: row reference outside the constraint data");
         }
         HIP_TRY(hipSetDevice(h->device));
-        if (!h->d_row_src) HIP_TRY(hipMalloc((void **)&h->d_row_src, 4 * B * cap));
-        if (!h->d_row_ld) HIP_TRY(hipMalloc((void **)&h->d_row_ld, 4 * B * cap));
         if (!h->d_in_owned)
         {
             HIP_TRY(hipMalloc((void **)&h->d_in_owned, 8 * B * h->problem_elems()));
@@ -472,6 +501,89 @@ extern "C"
         if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream)); // the host arrays may be reused by the caller
         h->d_in         = h->d_in_owned;
         h->factor_valid = false;
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_round_layout(lexls_lse_t h, lexls_round_layout *out)
+    {
+        CHECK_HANDLE(h);
+        if (!out) return fail(LEXLS_ERR_INVALID, "round_layout: null");
+        *out = h->lay;
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_upload_round(lexls_lse_t h, const void *h_in, int gather)
+    {
+        CHECK_HANDLE(h);
+        if (!h_in) return fail(LEXLS_ERR_INVALID, "upload_round: null");
+        const lexls_round_layout &L = h->lay;
+        const char *in           = static_cast<const char *>(h_in);
+        const uint32_t *dims     = reinterpret_cast<const uint32_t *>(in + L.dims);
+        const uint32_t *nfixed   = reinterpret_cast<const uint32_t *>(in + L.nfixed);
+        const uint32_t *fixedidx = reinterpret_cast<const uint32_t *>(in + L.fixed_idx);
+        const uint8_t *skip      = reinterpret_cast<const uint8_t *>(in + L.skip);
+        const uint32_t *row_src  = reinterpret_cast<const uint32_t *>(in + L.row_src);
+        const uint32_t *row_ld   = reinterpret_cast<const uint32_t *>(in + L.row_ld);
+        // the host-side checks and bookkeeping of set_obj_dim / set_fixed / gather_problem (skipped problems included: a later
+        // sensitivity call may still serve them, and the kernels' LDS budget follows the largest problem of the batch)
+        uint32_t max_rows = 0, max_level = 0;
+        bool any_fixed = false;
+        h->level_max.assign(h->nObj, 0);
+        if (gather && !h->d_cdata) return fail(LEXLS_ERR_INVALID, "upload_round: call lexls_lse_set_constraint_data first");
+        for (uint32_t b = 0; b < h->batch; b++)
+        {
+            uint32_t m = 0;
+            for (uint32_t k = 0; k < h->nObj; k++)
+            {
+                const uint32_t v = dims[(size_t)b * h->nObj + k];
+                if (v > h->maxdim[k]) return fail(LEXLS_ERR_INVALID, "upload_round: dimension exceeds the capacity given at creation");
+                m += v;
+                if (v > max_level) max_level = v;
+                if (v > h->level_max[k]) h->level_max[k] = v;
+            }
+            if (m > max_rows) max_rows = m;
+            if (nfixed[b] > h->nVar) return fail(LEXLS_ERR_INVALID, "Cannot fix more than nVar variables"); // lexlse.h:1453
+            for (uint32_t k = 0; k < nfixed[b]; k++)
+                if (fixedidx[(size_t)b * h->nVar + k] >= h->nVar) return fail(LEXLS_ERR_INVALID, "upload_round: variable index out of range");
+            any_fixed = any_fixed || nfixed[b] > 0;
+            if (gather && !skip[b])
+                for (size_t i = (size_t)b * h->cap; i < (size_t)(b + 1) * h->cap; i++)
+                {
+                    const uint64_t ld = row_ld[i] & 0x7fffffffu;
+                    if (ld && (uint64_t)row_src[i] + (uint64_t)(h->nVar + 1) * ld >= h->cdata_per_problem)
+                        return fail(LEXLS_ERR_INVALID, "upload_round: row reference outside the constraint data");
+                }
+        }
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpyAsync(h->d_round_in, h_in, L.in_bytes, hipMemcpyHostToDevice, h->stream));
+        h->max_rows      = max_rows ? max_rows : 1;
+        h->max_level_dim = max_level;
+        h->dims_set      = true;
+        h->has_fixed     = any_fixed;
+        h->has_skip      = true;
+        h->factor_valid  = false;
+        if (gather)
+        {
+            if (!h->d_in_owned)
+            {
+                HIP_TRY(hipMalloc((void **)&h->d_in_owned, 8 * (size_t)h->batch * h->problem_elems()));
+                HIP_TRY(hipMemsetAsync(h->d_in_owned, 0, 8 * (size_t)h->batch * h->problem_elems(), h->stream));
+            }
+            HIP_TRY(launch_gather_rows(h->args(), h->d_cdata, h->cdata_per_problem, h->d_row_src, h->d_row_ld, h->d_in_owned, h->stream));
+            h->d_in = h->d_in_owned;
+        }
+        if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_download_round(lexls_lse_t h, void *h_out, void *h_types)
+    {
+        CHECK_HANDLE(h);
+        HIP_TRY(hipSetDevice(h->device));
+        const lexls_round_layout &L = h->lay;
+        if (h_out) HIP_TRY(hipMemcpyAsync(h_out, h->d_round_out, L.out_bytes, hipMemcpyDeviceToHost, h->stream));
+        if (h_types) HIP_TRY(hipMemcpyAsync(h_types, h->d_round_in + L.fixed_type, L.in_bytes - L.fixed_type, hipMemcpyDeviceToHost, h->stream));
+        if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
         return LEXLS_OK;
     }
 
@@ -586,6 +698,14 @@ extern "C"
             return fail(LEXLS_ERR_INVALID, "ObjIndex >= nObj");
         }
         HIP_TRY(launch_sensitivity(h->args(), d_obj, obj_index_all, tolW, tolC, h->stream));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_sensitivity_resident(lexls_lse_t h, double tolW, double tolC)
+    {
+        if (int rc = need_factor(h, "lexls_lse_sensitivity_resident")) return rc;
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(launch_sensitivity(h->args(), h->d_objidx, 0, tolW, tolC, h->stream));
         return LEXLS_OK;
     }
 

@@ -87,6 +87,24 @@ namespace
         T *end() { return p + n; }
     };
 
+    /// typed window into a pinned block (the per-round arrays of a batch sit in blocks laid out like the handle's device slabs)
+    template <class T>
+    struct View
+    {
+        T *p     = NULL;
+        size_t n = 0;
+        void bind(void *base, uint64_t offset, size_t n_, T v)
+        {
+            p = reinterpret_cast<T *>(static_cast<char *>(base) + offset);
+            n = n_;
+            std::fill(p, p + n, v);
+        }
+        T *data() { return p; }
+        T &operator[](size_t i) { return p[i]; }
+        T *begin() { return p; }
+        T *end() { return p + n; }
+    };
+
     struct BatchCtx
     {
         lexls_lse_t h = NULL;
@@ -96,11 +114,13 @@ namespace
         size_t pstride = 0;
         std::vector<uint32_t> maxdim, rank, totalrank;
         std::vector<double> x;
-        Pinned<uint32_t> dims, nfixed, fixed_idx, row_src, row_ld, tr_dl; // row_src/row_ld: B x cap, where each LOD row comes from (device gather)
-        Pinned<double> fixed_val, maxabs, x_dl;
+        lexls_round_layout lay;
+        Pinned<char> in_block, out_block, types_block; // pinned mirrors of the handle's round slabs: ONE copy each per stage
+        View<uint32_t> dims, nfixed, fixed_idx, row_src, row_ld, tr_dl; // row_src/row_ld: B x cap, where each LOD row comes from (device gather)
+        View<double> fixed_val, maxabs, x_dl;
         double *lod = NULL; // B x cap x (n+1), PINNED: host-staging fallback, uploaded every active-set round
-        Pinned<uint8_t> fixed_type, ctr_type, skip, ctr_dl, fixed_dl;
-        Pinned<int32_t> sens, objidx;
+        View<uint8_t> fixed_type, ctr_type, skip, ctr_dl, fixed_dl;
+        View<int32_t> sens, objidx;
         std::vector<double> reg_factor;        // B x nObjL regularization factors (host copy; uploaded when they change)
         int reg_type = 0;                      // LexLS::RegularizationType shared by the batch
         double reg_variable = 0.0;
@@ -111,8 +131,9 @@ namespace
         double t_enqueue = 0, t_wait = 0; // seconds, reported when LEXLS_LSI_TIMING is set
         static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-        void create(int device, uint32_t B_, uint32_t n_, uint32_t nObjL_, const uint32_t *maxdim_)
+        void create(int device, uint32_t B_, uint32_t n_, uint32_t nObjL_, const uint32_t *maxdim_, bool gather_)
         {
+            gather = gather_;
             B     = B_;
             n     = n_;
             nObjL = nObjL_;
@@ -123,28 +144,35 @@ namespace
             hip_check(lexls_lse_create(&h, device, B, n, nObjL, maxdim.data()));
             if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) throw Exception("hipStreamCreate failed (lock-step LSI batch)");
             hip_check(lexls_lse_set_stream(h, stream));
-            dims.assign((size_t)B * nObjL, 0);
-            nfixed.assign(B, 0);
-            fixed_idx.assign((size_t)B * n, 0);
-            fixed_val.assign((size_t)B * n, 0.0);
-            fixed_type.assign((size_t)B * n, static_cast<uint8_t>(CTR_ACTIVE_UB));
-            ctr_type.assign((size_t)B * cap, static_cast<uint8_t>(CTR_INACTIVE));
-            if (hipHostMalloc((void **)&lod, 8 * (size_t)B * pstride, hipHostMallocDefault) != hipSuccess) throw Exception("hipHostMalloc failed for the LSI staging buffer");
-            std::memset(lod, 0, 8 * (size_t)B * pstride);
+            hip_check(lexls_lse_round_layout(h, &lay));
+            in_block.assign(lay.in_bytes, 0);
+            out_block.assign(lay.out_bytes, 0);
+            types_block.assign(lay.in_bytes - lay.fixed_type, 0);
+            dims.bind(in_block.data(), lay.dims, (size_t)B * nObjL, 0);
+            nfixed.bind(in_block.data(), lay.nfixed, B, 0);
+            fixed_idx.bind(in_block.data(), lay.fixed_idx, (size_t)B * n, 0);
+            fixed_val.bind(in_block.data(), lay.fixed_val, (size_t)B * n, 0.0);
+            skip.bind(in_block.data(), lay.skip, B, 0);
+            objidx.bind(in_block.data(), lay.obj_index, B, -1);
+            row_src.bind(in_block.data(), lay.row_src, (size_t)B * cap, 0);
+            row_ld.bind(in_block.data(), lay.row_ld, (size_t)B * cap, 0);
+            fixed_type.bind(in_block.data(), lay.fixed_type, (size_t)B * n, static_cast<uint8_t>(CTR_ACTIVE_UB));
+            ctr_type.bind(in_block.data(), lay.ctr_type, (size_t)B * cap, static_cast<uint8_t>(CTR_INACTIVE));
+            x_dl.bind(out_block.data(), lay.x, (size_t)B * n, 0.0);
+            tr_dl.bind(out_block.data(), lay.total_rank, B, 0);
+            sens.bind(out_block.data(), lay.found, (size_t)B * 3, 0);
+            maxabs.bind(out_block.data(), lay.max_abs, B, 0.0);
+            fixed_dl.bind(types_block.data(), 0, (size_t)B * n, 0);
+            ctr_dl.bind(types_block.data(), lay.ctr_type - lay.fixed_type, (size_t)B * cap, 0);
+            if (!gather) // host staging of whole problems: only without the device-side gather
+            {
+                if (hipHostMalloc((void **)&lod, 8 * (size_t)B * pstride, hipHostMallocDefault) != hipSuccess) throw Exception("hipHostMalloc failed for the LSI staging buffer");
+                std::memset(lod, 0, 8 * (size_t)B * pstride);
+            }
             x.assign((size_t)B * n, 0.0);
-            x_dl.assign((size_t)B * n, 0.0);
-            ctr_dl.assign((size_t)B * cap, 0);
-            fixed_dl.assign((size_t)B * n, 0);
-            tr_dl.assign(B, 0);
             rank.assign((size_t)B * nObjL, 0);
             totalrank.assign(B, 0);
-            skip.assign(B, 0);
-            sens.assign((size_t)B * 3, 0);
-            objidx.assign(B, -1);
-            maxabs.assign(B, 0.0);
             reg_factor.assign((size_t)B * nObjL, 0.0);
-            row_src.assign((size_t)B * cap, 0);
-            row_ld.assign((size_t)B * cap, 0);
         }
         ~BatchCtx()
         {
@@ -162,35 +190,30 @@ namespace
             stage_sens = serve_sens;
             if (serve_fs)
             {
-                hip_check(lexls_lse_set_obj_dim(h, dims.data(), 1));
-                hip_check(lexls_lse_set_fixed(h, nfixed.data(), fixed_idx.data(), fixed_val.data(), fixed_type.data()));
-                hip_check(lexls_lse_set_ctr_type(h, ctr_type.data()));
-                hip_check(lexls_lse_set_skip(h, skip.data()));
                 if (reg_type != 0 && reg_dirty.exchange(false)) // the factors are the same every round: uploaded once (this call synchronises)
                 {
                     hip_check(lexls_lse_set_cg_iterations(h, reg_cg_iters));
                     hip_check(lexls_lse_set_regularization(h, reg_type, reg_factor.data(), 1, reg_variable));
                 }
-                if (gather)
-                    hip_check(lexls_lse_gather_problem(h, row_src.data(), row_ld.data()));
-                else
-                    hip_check(lexls_lse_set_problem_host(h, lod));
+                // dims, fixed variables, types, skip flags, sensitivity levels and row references: one copy (+ the gather kernel)
+                hip_check(lexls_lse_upload_round(h, in_block.data(), gather ? 1 : 0));
+                if (!gather) hip_check(lexls_lse_set_problem_host(h, lod));
                 hip_check(lexls_lse_factorize_solve(h, 1));
-                hip_check(lexls_lse_get_x(h, x_dl.data()));
-                hip_check(lexls_lse_get_ranks(h, NULL, NULL, tr_dl.data()));
                 rounds_fs++;
             }
             if (serve_sens)
             {
-                hip_check(lexls_lse_sensitivity(h, objidx.data(), 0, tolW, tolC));
-                hip_check(lexls_lse_get_sensitivity(h, sens.data(), maxabs.data()));
-                // ObjectiveSensitivity marks constraints CORRECT_SIGN_OF_LAMBDA on the device (lexlse.h:866-987) and the marks must survive
-                // until the instance re-forms its problem: a later factorize stage uploads the host arrays for EVERY instance, also for the
-                // ones that are still in the middle of their sensitivity sequence — so the host copy takes the marks over (finish_stage)
-                hip_check(lexls_lse_get_ctr_type(h, ctr_dl.data()));
-                hip_check(lexls_lse_get_fixed_type(h, fixed_dl.data()));
+                if (serve_fs)
+                    hip_check(lexls_lse_sensitivity_resident(h, tolW, tolC));
+                else
+                    hip_check(lexls_lse_sensitivity(h, objidx.data(), 0, tolW, tolC));
                 rounds_sens++;
             }
+            // x / total rank / sensitivity verdicts in one copy.  ObjectiveSensitivity marks constraints CORRECT_SIGN_OF_LAMBDA on the device
+            // (lexlse.h:866-987) and the marks must survive until the instance re-forms its problem: a later factorize stage uploads the
+            // host arrays for EVERY instance, also for the ones that are still in the middle of their sensitivity sequence — so the host
+            // copy takes the marks over (finish_stage) from the second copy
+            hip_check(lexls_lse_download_round(h, out_block.data(), serve_sens ? types_block.data() : NULL));
             t_enqueue += now() - t0;
         }
 
@@ -458,9 +481,11 @@ extern "C"
                 total += h_dims[k];
             }
             const double t_begin = BatchCtx::now();
-            // The instances are split into groups that take turns: while one group's stage runs on the GPU (its own stream), the host
-            // advances the active-set logic of the other one.  LEXLS_LSI_GROUPS overrides the number (1 = strictly alternating host / GPU).
-            uint32_t nGroups = batch >= 256 ? 2u : 1u;
+            // The instances can be split into groups that take turns: while one group's stage runs on the GPU (its own stream), the host
+            // advances the active-set logic of the other one.  Measured on MI355X at batch 1024 one group — host and
+            // GPU strictly alternating — is as fast as two and faster than more: every stage carries fixed costs (copies, launches, one
+            // synchronisation) that a split doubles.  LEXLS_LSI_GROUPS overrides the number.
+            uint32_t nGroups = 1u;
             if (const char *e = std::getenv("LEXLS_LSI_GROUPS")) nGroups = std::max(1, std::atoi(e));
             nGroups = std::min(nGroups, batch);
             const bool gather = per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING"); // (diagnostic switch: assemble on the host, stage over PCIe)
@@ -471,18 +496,14 @@ extern "C"
             {
                 grp[g].reset(new BatchCtx());
                 BatchCtx &ctx = *grp[g];
-                ctx.create(device, lo[g + 1] - lo[g], nVar, nObj - off, h_dims + off);
+                ctx.create(device, lo[g + 1] - lo[g], nVar, nObj - off, h_dims + off, gather);
                 hip_check(lexls_lse_set_tolerance(ctx.h, par.tol_linear_dependence));
                 ctx.reg_type     = static_cast<int>(par.regularization_type);
                 ctx.reg_variable = par.variable_regularization_factor;
                 ctx.reg_cg_iters = par.max_number_of_CG_iterations;
                 ctx.reg_dirty.store(ctx.reg_type != 0);
                 hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between stages
-                if (gather)
-                {
-                    hip_check(lexls_lse_set_constraint_data(ctx.h, h_data + (size_t)lo[g] * per_data, per_data));
-                    ctx.gather = true;
-                }
+                if (gather) hip_check(lexls_lse_set_constraint_data(ctx.h, h_data + (size_t)lo[g] * per_data, per_data));
             }
             std::vector<uint32_t> group_of(batch);
             for (uint32_t g = 0; g < nGroups; g++)
@@ -558,13 +579,12 @@ extern "C"
                     }
             }
 
-            for (uint32_t b = 0; b < batch; b++)
-            {
+            pool.run(batch, [&](uint32_t b) {
                 runner::LsiInfo info;
                 runner::collect(*lsi[b], prob[b], h_x + (size_t)b * nVar, &info, h_active ? h_active + (size_t)b * total : NULL,
                                 h_v ? h_v + (size_t)b * total : NULL);
                 if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
-            }
+            });
             int rounds_fs = 0, rounds_sens = 0;
             double t_enq = 0.0, t_wait = 0.0;
             for (uint32_t g = 0; g < nGroups; g++)

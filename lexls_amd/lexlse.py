@@ -101,6 +101,49 @@ class BatchedLexLSE:
         """Bind a device buffer (e.g. torch_tensor.data_ptr()) holding batch x cap x (nVar+1) doubles as the input."""
         capi.check(capi.lib().lexls_lse_set_problem_device(self._h, C.c_void_p(device_ptr)))
 
+    # ---- one copy each way per round (lock-step active-set batches) -----------------------------
+    _ROUND_FIELDS = ("in_bytes", "dims", "nfixed", "fixed_idx", "fixed_val", "skip", "obj_index", "row_src", "row_ld", "fixed_type", "ctr_type",
+                     "out_bytes", "x", "total_rank", "found", "max_abs")
+
+    def round_layout(self) -> dict:
+        """byte offsets of the per-round arrays inside the handle's two device slabs (lexls_lse_round_layout)"""
+        lay = (C.c_uint64 * len(self._ROUND_FIELDS))()
+        capi.check(capi.lib().lexls_lse_round_layout(self._h, lay))
+        return dict(zip(self._ROUND_FIELDS, [int(v) for v in lay]))
+
+    def round_views(self, block: np.ndarray) -> dict:
+        """typed numpy views of an in-slab-shaped uint8 block (round_layout()['in_bytes'] bytes)"""
+        L, B, n, cap = self.round_layout(), self.batch, self.nVar, self.cap
+        def view(off, dtype, shape):
+            count = int(np.prod(shape))
+            return block[off:off + count * np.dtype(dtype).itemsize].view(dtype).reshape(shape)
+        return dict(dims=view(L["dims"], np.uint32, (B, self.nObj)), nfixed=view(L["nfixed"], np.uint32, (B,)),
+                    fixed_idx=view(L["fixed_idx"], np.uint32, (B, n)), fixed_val=view(L["fixed_val"], np.float64, (B, n)),
+                    skip=view(L["skip"], np.uint8, (B,)), obj_index=view(L["obj_index"], np.int32, (B,)),
+                    row_src=view(L["row_src"], np.uint32, (B, cap)), row_ld=view(L["row_ld"], np.uint32, (B, cap)),
+                    fixed_type=view(L["fixed_type"], np.uint8, (B, n)), ctr_type=view(L["ctr_type"], np.uint8, (B, cap)))
+
+    def upload_round(self, block: np.ndarray, gather: bool = False):
+        assert block.dtype == np.uint8 and block.flags.c_contiguous and block.size == self.round_layout()["in_bytes"]
+        capi.check(capi.lib().lexls_lse_upload_round(self._h, block.ctypes.data_as(C.c_void_p), C.c_int(1 if gather else 0)))
+
+    def download_round(self, with_types: bool = True) -> dict:
+        L, B, n, cap = self.round_layout(), self.batch, self.nVar, self.cap
+        out = np.zeros(L["out_bytes"], np.uint8)
+        types = np.zeros(L["in_bytes"] - L["fixed_type"], np.uint8) if with_types else None
+        capi.check(capi.lib().lexls_lse_download_round(self._h, out.ctypes.data_as(C.c_void_p), types.ctypes.data_as(C.c_void_p) if with_types else None))
+        r = dict(x=out[L["x"]:L["x"] + 8 * B * n].view(np.float64).reshape(B, n), total_rank=out[L["total_rank"]:L["total_rank"] + 4 * B].view(np.uint32),
+                 found=out[L["found"]:L["found"] + 12 * B].view(np.int32).reshape(B, 3), max_abs=out[L["max_abs"]:L["max_abs"] + 8 * B].view(np.float64))
+        if with_types:
+            o = L["ctr_type"] - L["fixed_type"]
+            r["fixed_type"] = types[:B * n].reshape(B, n)
+            r["ctr_type"] = types[o:o + B * cap].reshape(B, cap)
+        return r
+
+    def sensitivity_resident(self, tol_wrong_sign_lambda=1e-8, tol_correct_sign_lambda=1e-12):
+        """ObjectiveSensitivity with the per-problem objective indices uploaded by upload_round"""
+        capi.check(capi.lib().lexls_lse_sensitivity_resident(self._h, C.c_double(tol_wrong_sign_lambda), C.c_double(tol_correct_sign_lambda)))
+
     # ---- hot path -------------------------------------------------------------------------------
     def factorize(self):
         capi.check(capi.lib().lexls_lse_factorize(self._h))

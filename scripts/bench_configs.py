@@ -96,5 +96,5 @@ out["config4_lsi_lockstep"] = dict(batch=batch, instances_checked_against_oracle
                                    warm_30=dict(seconds=t_warm30, mean_factorizations=float(f30.mean()), max=int(f30.max()), rounds=warm30["rounds"],
                                                 solved=int(sum(i["status"] == 0 for i in warm30["info"])), factorizations_per_s=float(f30.sum() / t_warm30),
                                                 perturbation=0.9),
-                                   note="wall time of lexls_lsi_batch_solve on pre-packed problems: host active-set driver (worker pool) + per-round PCIe staging of the gathered rows (SURVEY 8(f) item 1 is the next step) + kernels")
+                                   note="wall time of lexls_lsi_batch_solve on pre-packed problems: host active-set driver (worker pool) + one block copy each way per stage + device-side gather of the active rows + kernels")
 print(json.dumps(out, indent=1))

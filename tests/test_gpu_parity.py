@@ -268,6 +268,55 @@ def test_sensitivity_with_fixed_variables(hip, oracle):
     np.testing.assert_array_equal(s.getWorkspace(), ref["lam"])
 
 
+def test_round_blocks_match_separate_setters(hip, oracle):
+    """lexls_lse_upload_round / download_round / sensitivity_resident (one copy each way per active-set round) give what the separate
+    set_* / get_* calls give: dims, fixed variables, constraint types, skip flags and sensitivity levels from one host block."""
+    n, dims, batch = 12, [4, 4, 6], 6
+    lod = P.lse_batch(51, batch, n, dims)
+    nfixed = np.array([1, 2, 3, 0, 4, 2], np.uint32)
+    idx = np.zeros((batch, n), np.uint32)
+    val = np.zeros((batch, n))
+    typ = np.zeros((batch, n), np.uint8)
+    for b in range(batch):
+        perm = np.argsort(P.uniform(800 + b, n))
+        idx[b, :nfixed[b]] = perm[:nfixed[b]]
+        val[b, :nfixed[b]] = P.normal(810 + b, n)[:nfixed[b]]
+        typ[b, :nfixed[b]] = 1 + (P.uniform(820 + b, n)[:nfixed[b]] * 2).astype(np.uint8)
+    types = np.full((batch, 14), 2, np.uint8)
+    ref = oracle.lse_run(lod, dims, n, nfixed=nfixed, fixed_idx=idx, fixed_val=val, fixed_type=typ, ctr_type=types, sens_obj=2)
+    s = hip.BatchedLexLSE(batch, n, dims)
+    L = s.round_layout()
+    assert all(L[k] % 256 == 0 for k in L) and L["ctr_type"] > L["fixed_type"] > L["row_ld"]
+    block = np.zeros(L["in_bytes"], np.uint8)
+    v = s.round_views(block)
+    v["dims"][:] = dims
+    v["nfixed"][:], v["fixed_idx"][:], v["fixed_val"][:], v["fixed_type"][:] = nfixed, idx, val, typ
+    v["ctr_type"][:] = types
+    v["obj_index"][:] = 2
+    v["skip"][3], v["obj_index"][3] = 1, -1  # problem 3 sits this round out
+    s.setProblem(lod)
+    s.upload_round(block)
+    s.factorize_solve()
+    s.sensitivity_resident()
+    r = s.download_round()
+    keep = np.arange(batch) != 3
+    np.testing.assert_array_equal(r["x"][keep], ref["x"][keep])
+    np.testing.assert_array_equal(r["total_rank"][keep], ref["totalrank"][keep])
+    np.testing.assert_array_equal(r["found"][keep], ref["sens"][keep])
+    np.testing.assert_array_equal(r["max_abs"][keep], ref["maxabs"][keep])
+    np.testing.assert_array_equal(r["ctr_type"][keep], ref["ctr_type_out"][keep])
+    np.testing.assert_array_equal(s.getWorkspace()[keep], ref["lam"][keep])
+    assert (r["x"][3] == 0).all() and (r["ctr_type"][3] == 2).all()  # the skipped problem was not touched
+    # argument checks of the separate setters are kept
+    v["dims"][0, 0] = 99
+    with pytest.raises(hip.LexlsError, match="exceeds the capacity"):
+        s.upload_round(block)
+    v["dims"][0, 0] = dims[0]
+    v["fixed_idx"][0, 0] = n
+    with pytest.raises(hip.LexlsError, match="out of range"):
+        s.upload_round(block)
+
+
 def test_least_norm_givens(hip, oracle):
     n, dims, batch = 40, [6] * 5, 8
     lod = P.lse_batch(61, batch, n, dims)
