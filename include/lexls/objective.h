@@ -2,8 +2,8 @@
 // Host side by design (north star: "LexLSI's outer active-set loop is kept on the host").
 //
 // Restates the behaviour of the reference include/lexls/objective.h; each method cites the lines
-// it follows.  Dense products are evaluated row-by-row with a left-to-right fma chain (the
-// reference leaves the order to Eigen's GEMV).
+// it follows.  Dense products are one left-to-right fma chain per row (the reference leaves the
+// order to Eigen's GEMV).
 #pragma once
 #include <type_traits>
 #include <utility>
@@ -415,11 +415,16 @@ namespace LexLS
             {
                 if (obj_type == GENERAL_OBJECTIVE)
                 {
-                    for (Index i = 0; i < nCtr; i++)
+                    // per row i the chain s = fma(A(i,j), x(j), s) over ascending j; the loops are interchanged (the data are column-major:
+                    // contiguous in i), which leaves every row's chain — and its result — as it is
+                    if (nCtr == 0) return;
+                    for (Index i = 0; i < nCtr; i++) out(i) = 0.0;
+                    for (Index j = 0; j < nVar; j++)
                     {
-                        RealScalar s = 0.0;
-                        for (Index j = 0; j < nVar; j++) s = std::fma(data(i, j), x(j), s);
-                        out(i) = s;
+                        const RealScalar xj    = x(j);
+                        const RealScalar *col  = &data(0, j);
+                        RealScalar *o          = &out(0);
+                        for (Index i = 0; i < nCtr; i++) o[i] = std::fma(col[i], xj, o[i]);
                     }
                 }
                 else

@@ -109,6 +109,8 @@ namespace
     {
         lexls_lse_t h = NULL;
         hipStream_t stream = NULL; // every group of a lock-step batch has its own stream: group A's kernels run while group B's host logic does
+        hipStream_t stream_sens = NULL; // the sensitivity kernel of a stage serves other instances than its l-QR kernel: they run side by side
+        hipEvent_t ev_uploaded = NULL, ev_sens_done = NULL;
         bool stage_fs = false, stage_sens = false; // what the stage in flight serves
         uint32_t B = 0, n = 0, nObjL = 0, cap = 0;
         size_t pstride = 0;
@@ -142,7 +144,9 @@ namespace
             for (uint32_t k = 0; k < nObjL; k++) cap += maxdim[k];
             pstride = (size_t)cap * (n + 1);
             hip_check(lexls_lse_create(&h, device, B, n, nObjL, maxdim.data()));
-            if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) throw Exception("hipStreamCreate failed (lock-step LSI batch)");
+            if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&stream_sens, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_uploaded, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_sens_done, hipEventDisableTiming) != hipSuccess)
+                throw Exception("hipStreamCreate / hipEventCreate failed (lock-step LSI batch)");
             hip_check(lexls_lse_set_stream(h, stream));
             hip_check(lexls_lse_round_layout(h, &lay));
             in_block.assign(lay.in_bytes, 0);
@@ -178,6 +182,9 @@ namespace
         {
             if (h) lexls_lse_destroy(h);
             if (stream) (void)hipStreamDestroy(stream);
+            if (stream_sens) (void)hipStreamDestroy(stream_sens);
+            if (ev_uploaded) (void)hipEventDestroy(ev_uploaded);
+            if (ev_sens_done) (void)hipEventDestroy(ev_sens_done);
             if (lod) (void)hipHostFree(lod);
         }
 
@@ -197,6 +204,7 @@ namespace
                 }
                 // dims, fixed variables, types, skip flags, sensitivity levels and row references: one copy (+ the gather kernel)
                 hip_check(lexls_lse_upload_round(h, in_block.data(), gather ? 1 : 0));
+                if (serve_sens && hipEventRecord(ev_uploaded, stream) != hipSuccess) throw Exception("hipEventRecord failed");
                 if (!gather) hip_check(lexls_lse_set_problem_host(h, lod));
                 hip_check(lexls_lse_factorize_solve(h, 1));
                 rounds_fs++;
@@ -204,7 +212,16 @@ namespace
             if (serve_sens)
             {
                 if (serve_fs)
+                {
+                    // disjoint instances (a problem is either re-factorised or asked for multipliers): the two kernels are both
+                    // latency-bound at these batch sizes and share the chip — second stream, joined again before the download
+                    if (hipStreamWaitEvent(stream_sens, ev_uploaded, 0) != hipSuccess) throw Exception("hipStreamWaitEvent failed");
+                    hip_check(lexls_lse_set_stream(h, stream_sens));
                     hip_check(lexls_lse_sensitivity_resident(h, tolW, tolC));
+                    hip_check(lexls_lse_set_stream(h, stream));
+                    if (hipEventRecord(ev_sens_done, stream_sens) != hipSuccess || hipStreamWaitEvent(stream, ev_sens_done, 0) != hipSuccess)
+                        throw Exception("hipEventRecord / hipStreamWaitEvent failed");
+                }
                 else
                     hip_check(lexls_lse_sensitivity(h, objidx.data(), 0, tolW, tolC));
                 rounds_sens++;
