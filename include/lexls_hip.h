@@ -174,8 +174,9 @@ int lexls_lse_device_ptr(lexls_lse_t h, int which, void **d_ptr);
 
 /* name of the kernel variant the last factorize/factorize_solve call dispatched to (diagnostics) */
 const char *lexls_lse_last_kernel(lexls_lse_t h);
-/* diagnostics (parity tests run every path): policy 0 = automatic dispatch; 1 = only the generic one-workgroup-per-problem kernel;
- * 2 = automatic, but without the left-looking wave kernel (the register-resident wave kernel serves the small shapes) */
+/* diagnostics (parity tests run every path): policy 0 = automatic dispatch (small shapes: the register-resident wave kernel while the batch
+ * fits one round of it, the left-looking wave kernel beyond); 1 = only the generic one-workgroup-per-problem kernel; 2 = automatic, but never
+ * the left-looking wave kernel; 3 = automatic, but the left-looking wave kernel whenever the shape allows it, whatever the batch size */
 int lexls_lse_set_kernel_policy(lexls_lse_t h, int policy);
 
 /* ---- inequality problems: the reference's LexLSI active-set driver (lexlsi.h), kept on the host -------------

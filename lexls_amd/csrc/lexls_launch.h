@@ -23,7 +23,7 @@ namespace lexls
 
     // lqr_small.hip — one wavefront per problem, problem in VGPRs (n+1 <= 64, rows <= 64, level dims <= 16)
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed);
-    hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, bool left_looking, hipStream_t s,
+    hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
                                const char **variant);
 
     // lqr_large.hip — problems too large for one CU's LDS: one launch per stage, the whole chip per problem

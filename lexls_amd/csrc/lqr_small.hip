@@ -23,12 +23,29 @@ namespace lexls
         return a.nVar + 1 <= 64 && max_rows <= 64 && max_level_dim <= 16 && a.nObj <= 16;
     }
 
-    hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, bool left_looking, hipStream_t s,
+    /// waves of the register-resident kernel the device holds at once (2 per SIMD): up to that many problems run in ONE round of it
+    static uint32_t resident_wave_capacity()
+    {
+        static uint32_t cap = 0;
+        if (!cap)
+        {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            cap = (uint32_t)cus * 4u * 2u;
+        }
+        return cap;
+    }
+
+    hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
                                const char **variant)
     {
         const uint32_t nc = a.nVar + 1;
-        // left-looking form (lqr_lwave_impl.h): one level block live per wave, 4 waves/SIMD; no fixed variables
-        if (left_looking && !has_fixed && max_level_dim <= 12 && nc <= 41 && a.nObj <= 8)
+        // left-looking form (lqr_lwave_impl.h): one level block live per wave, 4 waves/SIMD; no fixed variables.  Measured on MI355X
+        // (scripts/latency_scan.py, n = 40, 5 x 12): while the batch fits one round of the register-resident kernel (<= 2048 problems)
+        // that kernel has the shorter latency (factor kept: 79-88 us vs 97-101 us; x only: equal); beyond that the left-looking kernel
+        // still runs in one round (4096: 115 us vs 158 us).  left_looking: 0 = decide by batch size, > 0 = always, < 0 = never
+        const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
+        if (lwave_pays && !has_fixed && max_level_dim <= 12 && nc <= 41 && a.nObj <= 8)
         {
             if (nc == 41)
             {

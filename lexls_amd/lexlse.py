@@ -230,9 +230,10 @@ class BatchedLexLSE:
         capi.check(capi.lib().lexls_lse_device_ptr(self._h, C.c_int(capi.ARRAY[name]), C.byref(p)))
         return int(p.value)
 
-    def set_kernel_policy(self, force_generic: bool):
-        """diagnostics: route every factorization through the generic kernels"""
-        capi.check(capi.lib().lexls_lse_set_kernel_policy(self._h, C.c_int(int(force_generic))))
+    def set_kernel_policy(self, policy: int):
+        """diagnostics (lexls_lse_set_kernel_policy): 0 automatic dispatch, 1 generic kernel only, 2 never the left-looking wave kernel,
+        3 the left-looking wave kernel whenever the shape allows it"""
+        capi.check(capi.lib().lexls_lse_set_kernel_policy(self._h, C.c_int(int(policy))))
 
     def last_kernel(self) -> str:
         return capi.lib().lexls_lse_last_kernel(self._h).decode()

@@ -41,8 +41,9 @@ def assert_factor_equal(s, ref, dims, nvar):
         np.testing.assert_array_equal(f[b, :, :m[b]], ref["factor"][b, :, :m[b]])
 
 
-# kernel policy (include/lexls_hip.h): 0 = automatic dispatch, 1 = generic kernel only, 2 = automatic without the left-looking wave kernel
-BOTH_PATHS = pytest.mark.parametrize("force_generic", [0, 1, 2], ids=["specialised", "generic", "register-resident"])
+# kernel policy (include/lexls_hip.h): 0 = automatic dispatch (small shapes: register-resident wave kernel up to one round of it, left-looking
+# beyond), 1 = generic kernel only, 2 = never the left-looking wave kernel, 3 = the left-looking wave kernel whenever the shape allows
+BOTH_PATHS = pytest.mark.parametrize("force_generic", [0, 1, 2, 3], ids=["automatic", "generic", "register-resident", "left-looking"])
 
 
 @BOTH_PATHS
@@ -53,7 +54,7 @@ def test_ik_batch_bit_exact(hip, oracle, force_generic):
     assert (ref["rank"] == [12, 12, 12, 4, 0]).all()
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
-    assert s.last_kernel() == {0: "lqr_lwave<41,12,exact>", 1: "lqr_generic<64,lds>", 2: "lqr_wave<41,12,exact>"}[force_generic]
+    assert s.last_kernel() == {0: "lqr_wave<41,12,exact>", 1: "lqr_generic<64,lds>", 2: "lqr_wave<41,12,exact>", 3: "lqr_lwave<41,12,exact>"}[force_generic]
 
 
 @BOTH_PATHS
@@ -105,18 +106,18 @@ def test_ragged_batch(hip, oracle, force_generic):
 
 
 @pytest.mark.parametrize("n,dims", [(63, [16, 16, 16, 16]), (30, [14, 9, 16]), (40, [6] * 5), (5, [12, 12]), (40, [12, 0, 12, 12, 12]), (12, [1, 1, 1, 1, 1, 1, 1, 1])])
-@pytest.mark.parametrize("policy", [0, 2], ids=["left-looking-if-it-fits", "register-resident"])
+@pytest.mark.parametrize("policy", [3, 2], ids=["left-looking-if-it-fits", "register-resident"])
 def test_wave_kernel_shapes(hip, oracle, n, dims, policy):
     lod = P.lse_batch(1000 + n, 9, n, dims)
     s, ref = run_both(hip, oracle, lod, dims, n, force_generic=policy)
     assert "wave<" in s.last_kernel()
-    if policy == 0 and n <= 40 and max(dims) <= 12:
+    if policy == 3 and n <= 40 and max(dims) <= 12:
         assert s.last_kernel().startswith("lqr_lwave")
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
-@pytest.mark.parametrize("policy", [0, 2], ids=["left-looking", "register-resident"])
+@pytest.mark.parametrize("policy", [3, 2], ids=["left-looking", "register-resident"])
 def test_wave_kernel_tied_norms(hip, oracle, policy):
     """duplicated columns: exact ties in the pivot search must resolve to the first position (maxCoeff semantics)."""
     n, dims = 10, [4, 4, 4]
@@ -435,8 +436,14 @@ def test_full_size_batch_4096(hip, oracle):
     s = hip.BatchedLexLSE(batch, n, dims)
     s.setProblem(lod)
     s.factorize_solve(keep_factor=False)
+    assert s.last_kernel() == "lqr_lwave<41,12,exact>"  # more problems than one round of the register-resident kernel holds
     np.testing.assert_array_equal(s.get_x(), ref["x"])
     np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    small = hip.BatchedLexLSE(1024, n, dims)
+    small.setProblem(lod[:1024])
+    small.factorize_solve(keep_factor=False)
+    assert small.last_kernel() == "lqr_wave<41,12,exact>"  # latency-bound batch sizes: the register-resident kernel
+    np.testing.assert_array_equal(small.get_x(), ref["x"][:1024])
 
 
 def test_error_behaviour(hip):

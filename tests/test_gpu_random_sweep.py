@@ -50,7 +50,7 @@ def test_random_sweep(hip, oracle, chunk):
                 idx[b, :nf[b]] = rng.choice(n, int(nf[b]), replace=False)
                 val[b, :nf[b]] = rng.normal(size=int(nf[b]))
             fixed = dict(nfixed=nf, fixed_idx=idx, fixed_val=val)
-        policy = int(rng.choice([0, 0, 1, 2]))
+        policy = int(rng.choice([0, 3, 1, 2]))
         keep = bool(rng.random() < 0.6)
         ref = oracle.lse_run(lod, dims, n, maxdim=cap_dims, **fixed)
         s = hip.BatchedLexLSE(batch, n, cap_dims)
