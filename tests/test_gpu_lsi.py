@@ -220,6 +220,22 @@ def test_cpp_drop_in_example(hip, tmp_path):
     assert "LexLSI: status 0" in r.stdout and "LexLSE: ranks 3 1" in r.stdout, r.stdout
 
 
+def test_cpp_resolve_active_set_reproduces_factor_and_solution(hip, tmp_path):
+    """the property of the reference's tests/test_numerical_error.cpp:83-137 through the same classes: the equality problem of LexLSI's
+    last iteration, handed to a fresh LexLSE (fixed variables, active rows in working-set order, constraint types), gives the same
+    factor bit for bit (the reference sees small differences there, :5-22) and the same x up to the rounding of the final step."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "lexls_amd", "csrc")
+    exe = str(tmp_path / "resolve_active_set")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "resolve_active_set.cpp"),
+                           "-L" + libdir, "-llexls_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    r = subprocess.run([exe, os.path.join(GOLDEN, "test_01.dat")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "error(data) = 0.000e+00, error(lexqr) = 0.000e+00" in r.stdout, r.stdout
+
+
 def test_lock_step_batch_with_regularization(hip, oracle):
     """lexls_lsi_batch_solve_ex: the damped hierarchies of a batch run lock-step on the generic kernel; every instance ends exactly where
     its stand-alone oracle-backed solve with the same regularization ends."""
