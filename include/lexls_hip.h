@@ -211,6 +211,16 @@ int lexls_lsi_batch_solve_ex(int device, uint32_t batch, uint32_t nVar, uint32_t
                              const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
                              const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6,
                              uint8_t *h_active, double *h_v, int32_t *h_rounds2);
+/* The same batch as an object that outlives one solve — the way the reference uses LexLSI (constructed and sized once, lexlsi.h:56-112, then
+ * fed successive problems): lexls_lsi_batch_create makes the device buffers, pinned blocks, streams and the host worker pool for `batch`
+ * problems of the structure (nVar, dims, types); every lexls_lsi_batch_run solves `batch` new problems of that structure (arguments as
+ * lexls_lsi_batch_solve_ex).  lexls_lsi_batch_solve(_ex) = create + run + destroy; a serving loop saves the 6-8 ms of create per call. */
+typedef struct lexls_lsi_batch_s *lexls_lsi_batch_t;
+int lexls_lsi_batch_create(lexls_lsi_batch_t *out, int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types);
+int lexls_lsi_batch_run(lexls_lsi_batch_t b, const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
+                        const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
+                        double *h_v, int32_t *h_rounds2);
+int lexls_lsi_batch_destroy(lexls_lsi_batch_t b);
 /* lexls_lsi_solve plus what the MEX front end also passes (interfaces/matlab-octave/lexlsi.cpp:527-625): h_v0 = initial residuals,
  * sum(dims) doubles (set_v0 per objective) or NULL; h_reg_factors = one regularization factor per objective or NULL; h_params with
  * nparams == 9 (as lexls_lsi_solve) or 12: + regularization_type, variable_regularization_factor, max_number_of_CG_iterations. */

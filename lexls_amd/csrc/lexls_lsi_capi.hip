@@ -152,6 +152,16 @@ namespace
             in_block.assign(lay.in_bytes, 0);
             out_block.assign(lay.out_bytes, 0);
             types_block.assign(lay.in_bytes - lay.fixed_type, 0);
+            if (!gather) // host staging of whole problems: only without the device-side gather
+            {
+                if (hipHostMalloc((void **)&lod, 8 * (size_t)B * pstride, hipHostMallocDefault) != hipSuccess) throw Exception("hipHostMalloc failed for the LSI staging buffer");
+            }
+            reset();
+        }
+
+        /// per-solve state: what a freshly created context holds (a context serves many lexls_lsi_batch_run calls)
+        void reset()
+        {
             dims.bind(in_block.data(), lay.dims, (size_t)B * nObjL, 0);
             nfixed.bind(in_block.data(), lay.nfixed, B, 0);
             fixed_idx.bind(in_block.data(), lay.fixed_idx, (size_t)B * n, 0);
@@ -168,15 +178,14 @@ namespace
             maxabs.bind(out_block.data(), lay.max_abs, B, 0.0);
             fixed_dl.bind(types_block.data(), 0, (size_t)B * n, 0);
             ctr_dl.bind(types_block.data(), lay.ctr_type - lay.fixed_type, (size_t)B * cap, 0);
-            if (!gather) // host staging of whole problems: only without the device-side gather
-            {
-                if (hipHostMalloc((void **)&lod, 8 * (size_t)B * pstride, hipHostMallocDefault) != hipSuccess) throw Exception("hipHostMalloc failed for the LSI staging buffer");
-                std::memset(lod, 0, 8 * (size_t)B * pstride);
-            }
+            if (lod) std::memset(lod, 0, 8 * (size_t)B * pstride);
             x.assign((size_t)B * n, 0.0);
             rank.assign((size_t)B * nObjL, 0);
             totalrank.assign(B, 0);
             reg_factor.assign((size_t)B * nObjL, 0.0);
+            rounds_fs = rounds_sens = 0;
+            t_enqueue = t_wait = 0.0;
+            stage_fs = stage_sens = false;
         }
         ~BatchCtx()
         {
@@ -466,6 +475,180 @@ namespace
     };
 } // namespace
 
+/// A lock-step batch that outlives one solve (the reference constructs a LexLSI once and feeds it successive problems, lexlsi.h:56-112):
+/// device buffers, pinned blocks, streams and the worker pool are made once; every run() re-reads the problem data.
+struct lexls_lsi_batch_s
+{
+    int device;
+    uint32_t batch, nVar, nObj, off;
+    std::vector<uint32_t> dims;
+    std::vector<int32_t> types;
+    size_t per_data = 0, total = 0;
+    bool gather = false;
+    uint32_t nGroups = 1;
+    std::vector<std::unique_ptr<BatchCtx>> grp;
+    std::vector<uint32_t> lo, group_of;
+    std::unique_ptr<WorkerPool> pool;
+    double t_create = 0.0;
+
+    lexls_lsi_batch_s(int device_, uint32_t batch_, uint32_t nVar_, uint32_t nObj_, const uint32_t *h_dims, const int32_t *h_types)
+    : device(device_), batch(batch_), nVar(nVar_), nObj(nObj_)
+    {
+        if (batch == 0 || nObj == 0) throw Exception("lexls_lsi_batch_solve: empty batch");
+        dims.assign(h_dims, h_dims + nObj);
+        types.assign(h_types, h_types + nObj);
+        off = (h_types[0] == 1) ? 1 : 0;
+        if (nObj - off == 0) throw Exception("Problems consisting of one level of simple bounds are not supported."); // lexlsi.cpp:417
+        for (uint32_t k = 0; k < nObj; k++)
+        {
+            per_data += (size_t)h_dims[k] * (h_types[k] == 1 ? 2 : nVar + 2);
+            total += h_dims[k];
+        }
+        const double t_begin = BatchCtx::now();
+        // The instances can be split into groups that take turns: while one group's stage runs on the GPU (its own stream), the host
+        // advances the active-set logic of the other one.  Measured on MI355X at batch 1024 one group — host and
+        // GPU strictly alternating — is as fast as two and faster than more: every stage carries fixed costs (copies, launches, one
+        // synchronisation) that a split doubles.  LEXLS_LSI_GROUPS overrides the number.
+        nGroups = 1u;
+        if (const char *e = std::getenv("LEXLS_LSI_GROUPS")) nGroups = std::max(1, std::atoi(e));
+        nGroups = std::min(nGroups, batch);
+        gather = per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING"); // (diagnostic switch: assemble on the host, stage over PCIe)
+        grp.resize(nGroups);
+        lo.assign(nGroups + 1, 0);
+        for (uint32_t g = 0; g < nGroups; g++) lo[g + 1] = lo[g] + batch / nGroups + (g < batch % nGroups ? 1u : 0u);
+        for (uint32_t g = 0; g < nGroups; g++)
+        {
+            grp[g].reset(new BatchCtx());
+            BatchCtx &ctx = *grp[g];
+            ctx.create(device, lo[g + 1] - lo[g], nVar, nObj - off, h_dims + off, gather);
+            hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between stages
+        }
+        group_of.resize(batch);
+        for (uint32_t g = 0; g < nGroups; g++)
+            for (uint32_t b = lo[g]; b < lo[g + 1]; b++) group_of[b] = g;
+        pool.reset(new WorkerPool(WorkerPool::default_workers(batch)));
+        t_create = BatchCtx::now() - t_begin;
+    }
+
+    void run(const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_reg_factors,
+             const ParametersLexLSI &par, double *h_x, int32_t *h_info6, uint8_t *h_active, double *h_v, int32_t *h_rounds2)
+    {
+        if (par.deactivate_first_wrong_sign) throw Exception("lexls_lsi_batch_solve: deactivate_first_wrong_sign has no device path");
+        if (!h_data || !h_x) throw Exception("lexls_lsi_batch_run: null data / x");
+        const uint32_t *h_dims = dims.data();
+        const int32_t *h_types = types.data();
+        WorkerPool &pool       = *this->pool;
+        const double t_begin   = BatchCtx::now();
+        for (uint32_t g = 0; g < nGroups; g++)
+        {
+            BatchCtx &ctx = *grp[g];
+            ctx.reset();
+            hip_check(lexls_lse_set_tolerance(ctx.h, par.tol_linear_dependence));
+            ctx.reg_type     = static_cast<int>(par.regularization_type);
+            ctx.reg_variable = par.variable_regularization_factor;
+            ctx.reg_cg_iters = par.max_number_of_CG_iterations;
+            ctx.reg_dirty.store(ctx.reg_type != 0);
+            if (ctx.reg_type == 0) hip_check(lexls_lse_set_regularization(ctx.h, 0, NULL, 0, 0.0));
+            if (gather) hip_check(lexls_lse_set_constraint_data(ctx.h, h_data + (size_t)lo[g] * per_data, per_data));
+        }
+        const double t_ctx = BatchCtx::now() - t_begin;
+        std::vector<std::unique_ptr<SlotLSI>> lsi(batch);
+        std::vector<runner::LsiProblem> prob(batch);
+        pool.run(batch, [&](uint32_t b) {
+            const uint32_t g = group_of[b];
+            lsi[b].reset(new SlotLSI());
+            lsi[b]->getLexLSE().bind(grp[g].get(), b - lo[g]);
+            prob[b] = {nVar,
+                       nObj,
+                       h_dims,
+                       h_types,
+                       h_data + (size_t)b * per_data,
+                       h_var_index ? h_var_index + (size_t)b * h_dims[0] : NULL,
+                       h_active_guess ? h_active_guess + (size_t)b * total : NULL,
+                       h_x0 ? h_x0 + (size_t)b * nVar : NULL,
+                       NULL,
+                       h_reg_factors};
+            runner::setup(*lsi[b], prob[b], par);
+            lsi[b]->begin();
+        });
+        const double t_setup = BatchCtx::now() - t_begin;
+        double t_host        = 0.0;
+
+        // one stage of group g: every pending factorize+solve of the group in one call and every pending ObjectiveSensitivity in one
+        // call (different instances), both only enqueued; returns false when no instance of the group is alive any more
+        auto enqueue = [&](uint32_t g) -> bool {
+            BatchCtx &ctx = *grp[g];
+            bool any_fs = false, any_sens = false, any_alive = false;
+            for (uint32_t b = lo[g]; b < lo[g + 1]; b++)
+            {
+                const uint32_t k = b - lo[g];
+                const bool alive = !lsi[b]->finished();
+                const bool fs    = alive && lsi[b]->need() == SlotLSI::NEED_FACTORIZE_SOLVE;
+                const bool se    = alive && lsi[b]->need() == SlotLSI::NEED_SENSITIVITY;
+                ctx.skip[k]      = fs ? 0 : 1;
+                ctx.objidx[k]    = se ? static_cast<int32_t>(lsi[b]->needLevel()) : -1;
+                any_fs           = any_fs || fs;
+                any_sens         = any_sens || se;
+                any_alive        = any_alive || alive;
+            }
+            if (!any_alive) return false;
+            if (!any_fs && !any_sens) throw Exception("lexls_lsi_batch_solve: an instance is alive but requests nothing");
+            ctx.enqueue_stage(any_fs, any_sens, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
+            return true;
+        };
+        auto finish = [&](uint32_t g) {
+            BatchCtx &ctx = *grp[g];
+            ctx.finish_stage();
+            const double t0 = BatchCtx::now();
+            pool.run(lo[g + 1] - lo[g], [&](uint32_t k) {
+                if ((ctx.stage_fs && !ctx.skip[k]) || (ctx.stage_sens && ctx.objidx[k] >= 0)) lsi[lo[g] + k]->advance();
+            });
+            t_host += BatchCtx::now() - t0;
+        };
+
+        std::vector<char> alive(nGroups, 0);
+        bool any = false;
+        for (uint32_t g = 0; g < nGroups; g++) any = (alive[g] = enqueue(g)) || any;
+        while (any)
+        {
+            any = false;
+            for (uint32_t g = 0; g < nGroups; g++)
+                if (alive[g])
+                {
+                    finish(g);                // the other groups' stages keep the GPU busy meanwhile
+                    alive[g] = enqueue(g);
+                    any      = any || alive[g];
+                }
+        }
+
+        pool.run(batch, [&](uint32_t b) {
+            runner::LsiInfo info;
+            runner::collect(*lsi[b], prob[b], h_x + (size_t)b * nVar, &info, h_active ? h_active + (size_t)b * total : NULL,
+                            h_v ? h_v + (size_t)b * total : NULL);
+            if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
+        });
+        int rounds_fs = 0, rounds_sens = 0;
+        double t_enq = 0.0, t_wait = 0.0;
+        for (uint32_t g = 0; g < nGroups; g++)
+        {
+            rounds_fs += grp[g]->rounds_fs;
+            rounds_sens += grp[g]->rounds_sens;
+            t_enq += grp[g]->t_enqueue;
+            t_wait += grp[g]->t_wait;
+        }
+        if (std::getenv("LEXLS_LSI_TIMING"))
+            std::fprintf(stderr, "lexls_lsi_batch_solve: setup = %.4f s reset / constraint upload + %.4f s LexLSI objects (batch created in %.4f s)\n", t_ctx, t_setup - t_ctx, t_create),
+            std::fprintf(stderr, "lexls_lsi_batch_solve: total %.4f s = setup %.4f + enqueue %.4f + wait for the GPU %.4f + host logic %.4f + rest %.4f (%u groups, %d+%d stages)\n",
+                         BatchCtx::now() - t_begin, t_setup, t_enq, t_wait, t_host, BatchCtx::now() - t_begin - t_setup - t_enq - t_wait - t_host, nGroups,
+                         rounds_fs, rounds_sens);
+        if (h_rounds2)
+        {
+            h_rounds2[0] = rounds_fs;
+            h_rounds2[1] = rounds_sens;
+        }
+    }
+};
+
 extern "C"
 {
     void lexls_internal_set_error(const char *msg);
@@ -478,148 +661,12 @@ extern "C"
                                         h_info6, h_active, h_v, h_rounds2);
     }
 
-    int lexls_lsi_batch_solve_ex(int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types,
-                                 const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
-                                 const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6,
-                                 uint8_t *h_active, double *h_v, int32_t *h_rounds2)
+    int lexls_lsi_batch_create(lexls_lsi_batch_t *out, int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types)
     {
         try
         {
-            if (batch == 0 || nObj == 0) throw Exception("lexls_lsi_batch_solve: empty batch");
-            if (h_params && nparams != 9 && nparams != 12) throw Exception("lexls_lsi_batch_solve_ex: 9 or 12 parameters expected");
-            const ParametersLexLSI par = unpack(h_params, nparams);
-            if (par.deactivate_first_wrong_sign) throw Exception("lexls_lsi_batch_solve: deactivate_first_wrong_sign has no device path");
-            const uint32_t off = (h_types[0] == 1) ? 1 : 0;
-            if (nObj - off == 0) throw Exception("Problems consisting of one level of simple bounds are not supported."); // lexlsi.cpp:417
-            size_t per_data = 0, total = 0;
-            for (uint32_t k = 0; k < nObj; k++)
-            {
-                per_data += (size_t)h_dims[k] * (h_types[k] == 1 ? 2 : nVar + 2);
-                total += h_dims[k];
-            }
-            const double t_begin = BatchCtx::now();
-            // The instances can be split into groups that take turns: while one group's stage runs on the GPU (its own stream), the host
-            // advances the active-set logic of the other one.  Measured on MI355X at batch 1024 one group — host and
-            // GPU strictly alternating — is as fast as two and faster than more: every stage carries fixed costs (copies, launches, one
-            // synchronisation) that a split doubles.  LEXLS_LSI_GROUPS overrides the number.
-            uint32_t nGroups = 1u;
-            if (const char *e = std::getenv("LEXLS_LSI_GROUPS")) nGroups = std::max(1, std::atoi(e));
-            nGroups = std::min(nGroups, batch);
-            const bool gather = per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING"); // (diagnostic switch: assemble on the host, stage over PCIe)
-            std::vector<std::unique_ptr<BatchCtx>> grp(nGroups);
-            std::vector<uint32_t> lo(nGroups + 1, 0);
-            for (uint32_t g = 0; g < nGroups; g++) lo[g + 1] = lo[g] + batch / nGroups + (g < batch % nGroups ? 1u : 0u);
-            for (uint32_t g = 0; g < nGroups; g++)
-            {
-                grp[g].reset(new BatchCtx());
-                BatchCtx &ctx = *grp[g];
-                ctx.create(device, lo[g + 1] - lo[g], nVar, nObj - off, h_dims + off, gather);
-                hip_check(lexls_lse_set_tolerance(ctx.h, par.tol_linear_dependence));
-                ctx.reg_type     = static_cast<int>(par.regularization_type);
-                ctx.reg_variable = par.variable_regularization_factor;
-                ctx.reg_cg_iters = par.max_number_of_CG_iterations;
-                ctx.reg_dirty.store(ctx.reg_type != 0);
-                hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between stages
-                if (gather) hip_check(lexls_lse_set_constraint_data(ctx.h, h_data + (size_t)lo[g] * per_data, per_data));
-            }
-            std::vector<uint32_t> group_of(batch);
-            for (uint32_t g = 0; g < nGroups; g++)
-                for (uint32_t b = lo[g]; b < lo[g + 1]; b++) group_of[b] = g;
-
-            std::vector<std::unique_ptr<SlotLSI>> lsi(batch);
-            std::vector<runner::LsiProblem> prob(batch);
-            WorkerPool pool(WorkerPool::default_workers(batch));
-            pool.run(batch, [&](uint32_t b) {
-                const uint32_t g = group_of[b];
-                lsi[b].reset(new SlotLSI());
-                lsi[b]->getLexLSE().bind(grp[g].get(), b - lo[g]);
-                prob[b] = {nVar,
-                           nObj,
-                           h_dims,
-                           h_types,
-                           h_data + (size_t)b * per_data,
-                           h_var_index ? h_var_index + (size_t)b * h_dims[0] : NULL,
-                           h_active_guess ? h_active_guess + (size_t)b * total : NULL,
-                           h_x0 ? h_x0 + (size_t)b * nVar : NULL,
-                           NULL,
-                           h_reg_factors};
-                runner::setup(*lsi[b], prob[b], par);
-                lsi[b]->begin();
-            });
-            const double t_setup = BatchCtx::now() - t_begin;
-            double t_host        = 0.0;
-
-            // one stage of group g: every pending factorize+solve of the group in one call and every pending ObjectiveSensitivity in one
-            // call (different instances), both only enqueued; returns false when no instance of the group is alive any more
-            auto enqueue = [&](uint32_t g) -> bool {
-                BatchCtx &ctx = *grp[g];
-                bool any_fs = false, any_sens = false, any_alive = false;
-                for (uint32_t b = lo[g]; b < lo[g + 1]; b++)
-                {
-                    const uint32_t k = b - lo[g];
-                    const bool alive = !lsi[b]->finished();
-                    const bool fs    = alive && lsi[b]->need() == SlotLSI::NEED_FACTORIZE_SOLVE;
-                    const bool se    = alive && lsi[b]->need() == SlotLSI::NEED_SENSITIVITY;
-                    ctx.skip[k]      = fs ? 0 : 1;
-                    ctx.objidx[k]    = se ? static_cast<int32_t>(lsi[b]->needLevel()) : -1;
-                    any_fs           = any_fs || fs;
-                    any_sens         = any_sens || se;
-                    any_alive        = any_alive || alive;
-                }
-                if (!any_alive) return false;
-                if (!any_fs && !any_sens) throw Exception("lexls_lsi_batch_solve: an instance is alive but requests nothing");
-                ctx.enqueue_stage(any_fs, any_sens, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
-                return true;
-            };
-            auto finish = [&](uint32_t g) {
-                BatchCtx &ctx = *grp[g];
-                ctx.finish_stage();
-                const double t0 = BatchCtx::now();
-                pool.run(lo[g + 1] - lo[g], [&](uint32_t k) {
-                    if ((ctx.stage_fs && !ctx.skip[k]) || (ctx.stage_sens && ctx.objidx[k] >= 0)) lsi[lo[g] + k]->advance();
-                });
-                t_host += BatchCtx::now() - t0;
-            };
-
-            std::vector<char> alive(nGroups, 0);
-            bool any = false;
-            for (uint32_t g = 0; g < nGroups; g++) any = (alive[g] = enqueue(g)) || any;
-            while (any)
-            {
-                any = false;
-                for (uint32_t g = 0; g < nGroups; g++)
-                    if (alive[g])
-                    {
-                        finish(g);                // the other groups' stages keep the GPU busy meanwhile
-                        alive[g] = enqueue(g);
-                        any      = any || alive[g];
-                    }
-            }
-
-            pool.run(batch, [&](uint32_t b) {
-                runner::LsiInfo info;
-                runner::collect(*lsi[b], prob[b], h_x + (size_t)b * nVar, &info, h_active ? h_active + (size_t)b * total : NULL,
-                                h_v ? h_v + (size_t)b * total : NULL);
-                if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
-            });
-            int rounds_fs = 0, rounds_sens = 0;
-            double t_enq = 0.0, t_wait = 0.0;
-            for (uint32_t g = 0; g < nGroups; g++)
-            {
-                rounds_fs += grp[g]->rounds_fs;
-                rounds_sens += grp[g]->rounds_sens;
-                t_enq += grp[g]->t_enqueue;
-                t_wait += grp[g]->t_wait;
-            }
-            if (std::getenv("LEXLS_LSI_TIMING"))
-                std::fprintf(stderr, "lexls_lsi_batch_solve: total %.4f s = setup %.4f + enqueue %.4f + wait for the GPU %.4f + host logic %.4f + rest %.4f (%u groups, %d+%d stages)\n",
-                             BatchCtx::now() - t_begin, t_setup, t_enq, t_wait, t_host, BatchCtx::now() - t_begin - t_setup - t_enq - t_wait - t_host, nGroups,
-                             rounds_fs, rounds_sens);
-            if (h_rounds2)
-            {
-                h_rounds2[0] = rounds_fs;
-                h_rounds2[1] = rounds_sens;
-            }
+            if (!out || !h_dims || !h_types) throw Exception("lexls_lsi_batch_create: null argument");
+            *out = new lexls_lsi_batch_s(device, batch, nVar, nObj, h_dims, h_types);
             return LEXLS_OK;
         }
         catch (const std::exception &e)
@@ -627,6 +674,42 @@ extern "C"
             lexls_internal_set_error(e.what());
             return LEXLS_ERR_INVALID;
         }
+    }
+
+    int lexls_lsi_batch_destroy(lexls_lsi_batch_t b)
+    {
+        delete b;
+        return LEXLS_OK;
+    }
+
+    int lexls_lsi_batch_run(lexls_lsi_batch_t b, const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
+                            const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
+                            double *h_v, int32_t *h_rounds2)
+    {
+        try
+        {
+            if (!b) throw Exception("lexls_lsi_batch_run: null handle");
+            if (h_params && nparams != 9 && nparams != 12) throw Exception("lexls_lsi_batch_solve_ex: 9 or 12 parameters expected");
+            b->run(h_data, h_var_index, h_active_guess, h_x0, h_reg_factors, unpack(h_params, nparams), h_x, h_info6, h_active, h_v, h_rounds2);
+            return LEXLS_OK;
+        }
+        catch (const std::exception &e)
+        {
+            lexls_internal_set_error(e.what());
+            return LEXLS_ERR_INVALID;
+        }
+    }
+
+    int lexls_lsi_batch_solve_ex(int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types,
+                                 const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
+                                 const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6,
+                                 uint8_t *h_active, double *h_v, int32_t *h_rounds2)
+    {
+        lexls_lsi_batch_t b = NULL;
+        int rc              = lexls_lsi_batch_create(&b, device, batch, nVar, nObj, h_dims, h_types);
+        if (rc == LEXLS_OK) rc = lexls_lsi_batch_run(b, h_data, h_var_index, h_active_guess, h_x0, h_reg_factors, h_params, nparams, h_x, h_info6, h_active, h_v, h_rounds2);
+        lexls_lsi_batch_destroy(b);
+        return rc;
     }
 
     int lexls_lsi_solve(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types, const double *h_data,

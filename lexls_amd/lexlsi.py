@@ -116,32 +116,64 @@ def pack_batch(nvar: int, problems) -> PackedBatch:
     return PackedBatch(nvar, dims, types, data, var_index)
 
 
+class LsiBatch:
+    """A lock-step batch that outlives one solve (lexls_lsi_batch_create / _run / _destroy): device buffers, pinned blocks, streams and the
+    host worker pool are made once for `batch` problems of one structure; every run() solves new data of that structure."""
+
+    def __init__(self, nvar: int, dims, types, batch: int, device: int = 0):
+        self.nvar, self.batch = int(nvar), int(batch)
+        self.dims = np.ascontiguousarray(dims, np.uint32)
+        self.types = np.ascontiguousarray(types, np.int32)
+        self.total = int(self.dims.sum())
+        self._h = C.c_void_p()
+        capi.check(capi.lib().lexls_lsi_batch_create(C.byref(self._h), C.c_int(device), C.c_uint32(self.batch), C.c_uint32(self.nvar),
+                                                     C.c_uint32(len(self.dims)), _p(self.dims, C.c_uint32), _p(self.types, C.c_int32)))
+
+    def close(self):
+        if self._h:
+            capi.lib().lexls_lsi_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, problems, active_guess=None, x0=None, regularization_factors=None, **params):
+        """`problems`: list of objective lists or a PackedBatch of this batch's structure; other arguments as lsi_batch_solve"""
+        pk = problems if isinstance(problems, PackedBatch) else pack_batch(self.nvar, problems)
+        if pk.batch != self.batch or not np.array_equal(pk.dims, self.dims) or not np.array_equal(pk.types, self.types):
+            raise ValueError("problems do not have the structure this batch was created for")
+        batch, total, nvar = self.batch, self.total, self.nvar
+        guess = None
+        if isinstance(active_guess, np.ndarray):
+            guess = np.ascontiguousarray(active_guess.reshape(batch, total), np.uint8)
+        elif active_guess is not None:
+            guess = np.ascontiguousarray(np.stack([np.concatenate([np.asarray(g, np.uint8) for g in ag]) for ag in active_guess]))
+        x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
+        x, info = np.zeros((batch, nvar)), np.zeros((batch, 6), np.int32)
+        active, v, rounds = np.zeros((batch, total), np.uint8), np.zeros((batch, total)), np.zeros(2, np.int32)
+        if regularization_factors is not None or any(k in REG_PARAM_KEYS for k in params):
+            par = pack_params_ex(**params)
+        else:
+            par = pack_params(**params)
+        rfa = None if regularization_factors is None else np.ascontiguousarray(regularization_factors, np.float64)
+        capi.check(capi.lib().lexls_lsi_batch_run(
+            self._h, _p(pk.data, C.c_double), _p(pk.var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(rfa, C.c_double),
+            _p(par, C.c_double), C.c_uint32(len(par)), _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8), _p(v, C.c_double),
+            _p(rounds, C.c_int32)))
+        return dict(x=x, info=[dict(zip(INFO_KEYS, row.tolist())) for row in info], active=active, v=v,
+                    rounds=dict(factorize_solve=int(rounds[0]), sensitivity=int(rounds[1])), dims=self.dims)
+
+
 def lsi_batch_solve(nvar: int, problems, active_guess=None, x0=None, device: int = 0, regularization_factors=None, **params):
     """Lock-step batch of LexLSI problems of one structure (BASELINE configs[4]).  `problems`: list of objective lists
     (same dims / types) or a PackedBatch; `active_guess`: per problem list of per-objective flag arrays, a (batch, total) uint8
-    array, or None; `x0`: (batch, nvar) or None."""
+    array, or None; `x0`: (batch, nvar) or None.  One-shot form of LsiBatch (create + run + destroy)."""
     pk = problems if isinstance(problems, PackedBatch) else pack_batch(nvar, problems)
-    dims, types, data, var_index, batch, total = pk.dims, pk.types, pk.data, pk.var_index, pk.batch, pk.total
-    guess = None
-    if isinstance(active_guess, np.ndarray):
-        guess = np.ascontiguousarray(active_guess.reshape(batch, total), np.uint8)
-    elif active_guess is not None:
-        guess = np.ascontiguousarray(np.stack([np.concatenate([np.asarray(g, np.uint8) for g in ag]) for ag in active_guess]))
-    x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
-    x, info = np.zeros((batch, nvar)), np.zeros((batch, 6), np.int32)
-    active, v, rounds = np.zeros((batch, total), np.uint8), np.zeros((batch, total)), np.zeros(2, np.int32)
-    if regularization_factors is not None or any(k in REG_PARAM_KEYS for k in params):
-        par = pack_params_ex(**params)
-        rfa = None if regularization_factors is None else np.ascontiguousarray(regularization_factors, np.float64)
-        capi.check(capi.lib().lexls_lsi_batch_solve_ex(
-            C.c_int(device), C.c_uint32(batch), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32),
-            _p(data, C.c_double), _p(var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(rfa, C.c_double), _p(par, C.c_double),
-            C.c_uint32(len(par)), _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8), _p(v, C.c_double), _p(rounds, C.c_int32)))
-    else:
-        par = pack_params(**params)
-        capi.check(capi.lib().lexls_lsi_batch_solve(
-            C.c_int(device), C.c_uint32(batch), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32), _p(data, C.c_double),
-            _p(var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(par, C.c_double), _p(x, C.c_double), _p(info, C.c_int32),
-            _p(active, C.c_uint8), _p(v, C.c_double), _p(rounds, C.c_int32)))
-    return dict(x=x, info=[dict(zip(INFO_KEYS, row.tolist())) for row in info], active=active, v=v,
-                rounds=dict(factorize_solve=int(rounds[0]), sensitivity=int(rounds[1])), dims=dims)
+    b = LsiBatch(nvar, pk.dims, pk.types, pk.batch, device=device)
+    try:
+        return b.run(pk, active_guess=active_guess, x0=x0, regularization_factors=regularization_factors, **params)
+    finally:
+        b.close()

@@ -236,6 +236,37 @@ def test_cpp_resolve_active_set_reproduces_factor_and_solution(hip, tmp_path):
     assert "error(data) = 0.000e+00, error(lexqr) = 0.000e+00" in r.stdout, r.stdout
 
 
+def test_persistent_batch_object_is_stateless_between_runs(hip, oracle):
+    """lexls_lsi_batch_create / _run / _destroy: one batch object serves successive problem sets (different data, warm starts, with and
+    without regularization) and every run equals the one-shot call — nothing of a previous run (working-set marks, fixed variables,
+    regularization factors, constraint data) leaks into the next."""
+    n, dims, batch = 16, [5, 4, 6, 5], 10
+    A = [P.lsi_problem(900 + b, n, dims) for b in range(batch)]
+    B = [P.lsi_problem(900 + b, n, dims, perturb=0.3) for b in range(batch)]
+    pkA = lexlsi.pack_batch(n, A)
+    srv = lexlsi.LsiBatch(n, pkA.dims, pkA.types, batch)
+    r1 = srv.run(A)
+    guess = np.where(r1["active"] == 3, 0, r1["active"]).astype(np.uint8)
+    r2 = srv.run(B, active_guess=guess, x0=r1["x"])
+    r3 = srv.run(A, regularization_type=1, regularization_factors=[0, 0.3, 0.2, 0.4])
+    r4 = srv.run(A)
+    srv.close()
+    o1 = lexlsi.lsi_batch_solve(n, A)
+    o2 = lexlsi.lsi_batch_solve(n, B, active_guess=guess, x0=r1["x"])
+    o3 = lexlsi.lsi_batch_solve(n, A, regularization_type=1, regularization_factors=[0, 0.3, 0.2, 0.4])
+    for r, o in ((r1, o1), (r2, o2), (r3, o3), (r4, o1)):
+        assert r["info"] == o["info"]
+        np.testing.assert_array_equal(r["x"], o["x"])
+        np.testing.assert_array_equal(r["active"], o["active"])
+        np.testing.assert_array_equal(r["v"], o["v"])
+    for b in range(batch):  # and the one-shot call equals the stand-alone oracle-backed driver
+        ob = oracle.lsi_run(n, A[b])
+        assert o1["info"][b] == ob["info"]
+        np.testing.assert_array_equal(o1["x"][b], ob["x"])
+    with pytest.raises(ValueError):
+        lexlsi.LsiBatch(n, pkA.dims, pkA.types, batch + 1).run(A)
+
+
 def test_lock_step_batch_with_regularization(hip, oracle):
     """lexls_lsi_batch_solve_ex: the damped hierarchies of a batch run lock-step on the generic kernel; every instance ends exactly where
     its stand-alone oracle-backed solve with the same regularization ends."""
