@@ -199,8 +199,9 @@ int lexls_lsi_solve(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_
  * active-set round issues one batched factorize+solve and one batched ObjectiveSensitivity per LexLSE level for all the
  * instances that need it (BASELINE configs[4]).  Arrays are the per-problem arrays of lexls_lsi_solve, back to back
  * (h_var_index: batch x dims[0]; h_active_guess / h_x0 may be NULL); h_rounds2 (may be NULL) receives
- * {factorize+solve stages, sensitivity stages} actually issued to the device.  With LEXLS_LSI_GROUPS=g (default 1) the instances are split
- * into g groups that take turns: one group's stage runs on the GPU while the host advances the other groups' active sets. */
+ * {factorize+solve stages, sensitivity stages} actually issued to the device.  The instances are split into g groups (default: 2 from 768
+ * instances on, else 1; LEXLS_LSI_GROUPS=g overrides) that take turns: one group's stage runs on the GPU while the host advances the other
+ * groups' active sets. */
 int lexls_lsi_batch_solve(int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types,
                           const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
                           const double *h_params9, double *h_x, int32_t *h_info6, uint8_t *h_active, double *h_v, int32_t *h_rounds2);

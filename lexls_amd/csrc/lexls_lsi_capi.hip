@@ -243,26 +243,22 @@ namespace
             t_enqueue += now() - t0;
         }
 
-        /// wait for the stage in flight (the ONE synchronisation of a stage) and take its results over
+        /// wait for the stage in flight (the ONE synchronisation of a stage); its results are taken over per instance, on the worker pool
         void finish_stage()
         {
             const double t0 = now();
             hip_check(lexls_lse_synchronize(h));
             t_wait += now() - t0;
-            if (stage_fs)
-                for (uint32_t b = 0; b < B; b++)
-                    if (!skip[b])
-                    {
-                        std::copy(x_dl.begin() + (size_t)b * n, x_dl.begin() + (size_t)(b + 1) * n, x.begin() + (size_t)b * n);
-                        totalrank[b] = tr_dl[b];
-                    }
-            if (stage_sens)
-                for (uint32_t b = 0; b < B; b++)
-                    if (objidx[b] >= 0)
-                    {
-                        std::copy(ctr_dl.begin() + (size_t)b * cap, ctr_dl.begin() + (size_t)(b + 1) * cap, ctr_type.begin() + (size_t)b * cap);
-                        std::copy(fixed_dl.begin() + (size_t)b * n, fixed_dl.begin() + (size_t)(b + 1) * n, fixed_type.begin() + (size_t)b * n);
-                    }
+        }
+        void take_solution(uint32_t b)
+        {
+            std::copy(x_dl.begin() + (size_t)b * n, x_dl.begin() + (size_t)(b + 1) * n, x.begin() + (size_t)b * n);
+            totalrank[b] = tr_dl[b];
+        }
+        void take_marks(uint32_t b)
+        {
+            std::copy(ctr_dl.begin() + (size_t)b * cap, ctr_dl.begin() + (size_t)(b + 1) * cap, ctr_type.begin() + (size_t)b * cap);
+            std::copy(fixed_dl.begin() + (size_t)b * n, fixed_dl.begin() + (size_t)(b + 1) * n, fixed_type.begin() + (size_t)b * n);
         }
     };
 
@@ -506,10 +502,11 @@ struct lexls_lsi_batch_s
         }
         const double t_begin = BatchCtx::now();
         // The instances can be split into groups that take turns: while one group's stage runs on the GPU (its own stream), the host
-        // advances the active-set logic of the other one.  Measured on MI355X at batch 1024 one group — host and
-        // GPU strictly alternating — is as fast as two and faster than more: every stage carries fixed costs (copies, launches, one
-        // synchronisation) that a split doubles.  LEXLS_LSI_GROUPS overrides the number.
-        nGroups = 1u;
+        // advances the active-set logic of the other one.  Every stage carries fixed costs (one copy each way, launches, one
+        // synchronisation) that a split multiplies, so it pays for large batches only.  Measured on MI355X, cold
+        // solve of n = 40, 5 x 12: 256 instances 0.045 s in one group / 0.050 s in two; 1024 instances 0.066 s / 0.048-0.057 s
+        // (three groups 0.056-0.062 s, four 0.076 s).  LEXLS_LSI_GROUPS overrides the number.
+        nGroups = batch >= 768 ? 2u : 1u;
         if (const char *e = std::getenv("LEXLS_LSI_GROUPS")) nGroups = std::max(1, std::atoi(e));
         nGroups = std::min(nGroups, batch);
         gather = per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING"); // (diagnostic switch: assemble on the host, stage over PCIe)
@@ -574,41 +571,52 @@ struct lexls_lsi_batch_s
         const double t_setup = BatchCtx::now() - t_begin;
         double t_host        = 0.0;
 
-        // one stage of group g: every pending factorize+solve of the group in one call and every pending ObjectiveSensitivity in one
-        // call (different instances), both only enqueued; returns false when no instance of the group is alive any more
-        auto enqueue = [&](uint32_t g) -> bool {
+        // One stage of group g serves every pending factorize+solve of the group in one call and every pending ObjectiveSensitivity in
+        // one call (different instances), both only enqueued.  Between two stages every instance of the group runs ONE job on the worker
+        // pool: take over the results of the stage that just finished (if it was served), advance its active-set logic, and post what it
+        // needs next into the group's round block.
+        std::vector<std::atomic<uint32_t>> wants(nGroups); // bit 0: somebody alive, bit 1: a factorize+solve, bit 2: a sensitivity
+        auto turn = [&](uint32_t g) {
             BatchCtx &ctx = *grp[g];
-            bool any_fs = false, any_sens = false, any_alive = false;
-            for (uint32_t b = lo[g]; b < lo[g + 1]; b++)
-            {
-                const uint32_t k = b - lo[g];
-                const bool alive = !lsi[b]->finished();
-                const bool fs    = alive && lsi[b]->need() == SlotLSI::NEED_FACTORIZE_SOLVE;
-                const bool se    = alive && lsi[b]->need() == SlotLSI::NEED_SENSITIVITY;
+            wants[g].store(0);
+            const double t0 = BatchCtx::now();
+            pool.run(lo[g + 1] - lo[g], [&](uint32_t k) {
+                SlotLSI &inst        = *lsi[lo[g] + k];
+                const bool served_fs = ctx.stage_fs && !ctx.skip[k], served_sens = ctx.stage_sens && ctx.objidx[k] >= 0;
+                if (served_fs) ctx.take_solution(k);
+                if (served_sens) ctx.take_marks(k);
+                if (served_fs || served_sens) inst.advance();
+                const bool alive = !inst.finished();
+                const bool fs    = alive && inst.need() == SlotLSI::NEED_FACTORIZE_SOLVE;
+                const bool se    = alive && inst.need() == SlotLSI::NEED_SENSITIVITY;
                 ctx.skip[k]      = fs ? 0 : 1;
-                ctx.objidx[k]    = se ? static_cast<int32_t>(lsi[b]->needLevel()) : -1;
-                any_fs           = any_fs || fs;
-                any_sens         = any_sens || se;
-                any_alive        = any_alive || alive;
-            }
-            if (!any_alive) return false;
-            if (!any_fs && !any_sens) throw Exception("lexls_lsi_batch_solve: an instance is alive but requests nothing");
-            ctx.enqueue_stage(any_fs, any_sens, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
+                ctx.objidx[k]    = se ? static_cast<int32_t>(inst.needLevel()) : -1;
+                const uint32_t w = (alive ? 1u : 0u) | (fs ? 2u : 0u) | (se ? 4u : 0u);
+                if (w & ~wants[g].load(std::memory_order_relaxed)) wants[g].fetch_or(w, std::memory_order_relaxed);
+            });
+            t_host += BatchCtx::now() - t0;
+        };
+        auto enqueue = [&](uint32_t g) -> bool { // false when no instance of the group is alive any more
+            BatchCtx &ctx    = *grp[g];
+            const uint32_t w = wants[g].load();
+            ctx.stage_fs = ctx.stage_sens = false;
+            if (!(w & 1u)) return false;
+            if (!(w & 6u)) throw Exception("lexls_lsi_batch_solve: an instance is alive but requests nothing");
+            ctx.enqueue_stage((w & 2u) != 0, (w & 4u) != 0, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
             return true;
         };
         auto finish = [&](uint32_t g) {
-            BatchCtx &ctx = *grp[g];
-            ctx.finish_stage();
-            const double t0 = BatchCtx::now();
-            pool.run(lo[g + 1] - lo[g], [&](uint32_t k) {
-                if ((ctx.stage_fs && !ctx.skip[k]) || (ctx.stage_sens && ctx.objidx[k] >= 0)) lsi[lo[g] + k]->advance();
-            });
-            t_host += BatchCtx::now() - t0;
+            grp[g]->finish_stage();
+            turn(g);
         };
 
         std::vector<char> alive(nGroups, 0);
         bool any = false;
-        for (uint32_t g = 0; g < nGroups; g++) any = (alive[g] = enqueue(g)) || any;
+        for (uint32_t g = 0; g < nGroups; g++)
+        {
+            turn(g); // nothing served yet: only posts the first requests
+            any = (alive[g] = enqueue(g)) || any;
+        }
         while (any)
         {
             any = false;
