@@ -152,11 +152,16 @@ namespace
             in_block.assign(lay.in_bytes, 0);
             out_block.assign(lay.out_bytes, 0);
             types_block.assign(lay.in_bytes - lay.fixed_type, 0);
-            if (!gather) // host staging of whole problems: only without the device-side gather
-            {
-                if (hipHostMalloc((void **)&lod, 8 * (size_t)B * pstride, hipHostMallocDefault) != hipSuccess) throw Exception("hipHostMalloc failed for the LSI staging buffer");
-            }
+            if (!gather) need_staging();
             reset();
+        }
+
+        /// host staging of whole problems (pinned, B x cap x (n+1)): only for runs without the device-side gather
+        void need_staging()
+        {
+            if (lod) return;
+            if (hipHostMalloc((void **)&lod, 8 * (size_t)B * pstride, hipHostMallocDefault) != hipSuccess) throw Exception("hipHostMalloc failed for the LSI staging buffer");
+            std::memset(lod, 0, 8 * (size_t)B * pstride);
         }
 
         /// per-solve state: what a freshly created context holds (a context serves many lexls_lsi_batch_run calls)
@@ -536,9 +541,14 @@ struct lexls_lsi_batch_s
         const int32_t *h_types = types.data();
         WorkerPool &pool       = *this->pool;
         const double t_begin   = BatchCtx::now();
+        // Cycling handling relaxes bounds in the host copy of the constraint data (cycling.h:32-65, objective.h:774-790): such a run
+        // assembles its problems on the host from that copy instead of gathering rows of the resident (unrelaxed) device copy
+        const bool run_gather = gather && !par.cycling_handling_enabled;
         for (uint32_t g = 0; g < nGroups; g++)
         {
             BatchCtx &ctx = *grp[g];
+            ctx.gather    = run_gather;
+            if (!run_gather) ctx.need_staging();
             ctx.reset();
             hip_check(lexls_lse_set_tolerance(ctx.h, par.tol_linear_dependence));
             ctx.reg_type     = static_cast<int>(par.regularization_type);
@@ -546,7 +556,7 @@ struct lexls_lsi_batch_s
             ctx.reg_cg_iters = par.max_number_of_CG_iterations;
             ctx.reg_dirty.store(ctx.reg_type != 0);
             if (ctx.reg_type == 0) hip_check(lexls_lse_set_regularization(ctx.h, 0, NULL, 0, 0.0));
-            if (gather) hip_check(lexls_lse_set_constraint_data(ctx.h, h_data + (size_t)lo[g] * per_data, per_data));
+            if (run_gather) hip_check(lexls_lse_set_constraint_data(ctx.h, h_data + (size_t)lo[g] * per_data, per_data));
         }
         const double t_ctx = BatchCtx::now() - t_begin;
         std::vector<std::unique_ptr<SlotLSI>> lsi(batch);

@@ -267,6 +267,26 @@ def test_persistent_batch_object_is_stateless_between_runs(hip, oracle):
         lexlsi.LsiBatch(n, pkA.dims, pkA.types, batch + 1).run(A)
 
 
+def test_lock_step_batch_with_cycling_handling_enabled(hip, oracle):
+    """cycling handling (cycling.h:32-65) relaxes bounds in the HOST copy of the constraint data, so a run with it enabled must not gather
+    rows from the resident device copy: the driver assembles such runs on the host — same trajectories as the oracle-backed driver, and
+    the same batch object goes back to the device gather afterwards."""
+    n, dims, batch = 14, [4, 5, 5, 4], 9
+    problems = [P.lsi_problem(1300 + b, n, dims) for b in range(batch)]
+    pk = lexlsi.pack_batch(n, problems)
+    srv = lexlsi.LsiBatch(n, pk.dims, pk.types, batch)
+    r = srv.run(pk, cycling_handling_enabled=1, cycling_max_counter=3, cycling_relax_step=1e-6)
+    plain = srv.run(pk)
+    srv.close()
+    for b in range(batch):
+        o = oracle.lsi_run(n, problems[b], cycling_handling_enabled=1, cycling_max_counter=3, cycling_relax_step=1e-6)
+        assert r["info"][b] == o["info"], b
+        np.testing.assert_array_equal(r["x"][b], o["x"])
+        o0 = oracle.lsi_run(n, problems[b])
+        assert plain["info"][b] == o0["info"], b
+        np.testing.assert_array_equal(plain["x"][b], o0["x"])
+
+
 def test_lock_step_batch_with_regularization(hip, oracle):
     """lexls_lsi_batch_solve_ex: the damped hierarchies of a batch run lock-step on the generic kernel; every instance ends exactly where
     its stand-alone oracle-backed solve with the same regularization ends."""
