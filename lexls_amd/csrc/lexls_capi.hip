@@ -512,7 +512,13 @@ extern "C"
         return LEXLS_OK;
     }
 
-    int lexls_lse_upload_round(lexls_lse_t h, const void *h_in, int gather)
+    static int upload_round(lexls_lse_t h, const void *h_in, int gather, bool trusted);
+    int lexls_lse_upload_round(lexls_lse_t h, const void *h_in, int gather) { return upload_round(h, h_in, gather, false); }
+    /* internal (not in include/lexls_hip.h): the lock-step LexLSI driver of this library fills the block itself — variable indices and
+     * row references come from its own working sets — and skips the per-element argument checks */
+    int lexls_internal_upload_round_trusted(lexls_lse_t h, const void *h_in, int gather) { return upload_round(h, h_in, gather, true); }
+
+    static int upload_round(lexls_lse_t h, const void *h_in, int gather, bool trusted)
     {
         CHECK_HANDLE(h);
         if (!h_in) return fail(LEXLS_ERR_INVALID, "upload_round: null");
@@ -543,9 +549,10 @@ extern "C"
             }
             if (m > max_rows) max_rows = m;
             if (nfixed[b] > h->nVar) return fail(LEXLS_ERR_INVALID, "Cannot fix more than nVar variables"); // lexlse.h:1453
+            any_fixed = any_fixed || nfixed[b] > 0;
+            if (trusted) continue;
             for (uint32_t k = 0; k < nfixed[b]; k++)
                 if (fixedidx[(size_t)b * h->nVar + k] >= h->nVar) return fail(LEXLS_ERR_INVALID, "upload_round: variable index out of range");
-            any_fixed = any_fixed || nfixed[b] > 0;
             if (gather && !skip[b])
                 for (size_t i = (size_t)b * h->cap; i < (size_t)(b + 1) * h->cap; i++)
                 {

@@ -17,6 +17,8 @@
 
 using namespace LexLS;
 
+extern "C" int lexls_internal_upload_round_trusted(lexls_lse_t h, const void *h_in, int gather); // lexls_capi.hip
+
 namespace
 {
 
@@ -217,7 +219,7 @@ namespace
                     hip_check(lexls_lse_set_regularization(h, reg_type, reg_factor.data(), 1, reg_variable));
                 }
                 // dims, fixed variables, types, skip flags, sensitivity levels and row references: one copy (+ the gather kernel)
-                hip_check(lexls_lse_upload_round(h, in_block.data(), gather ? 1 : 0));
+                hip_check(lexls_internal_upload_round_trusted(h, in_block.data(), gather ? 1 : 0));
                 if (serve_sens && hipEventRecord(ev_uploaded, stream) != hipSuccess) throw Exception("hipEventRecord failed");
                 if (!gather) hip_check(lexls_lse_set_problem_host(h, lod));
                 hip_check(lexls_lse_factorize_solve(h, 1));
