@@ -445,6 +445,20 @@ namespace LexLS
             // were pre-computed by a batch call implements them as look-ups (lexls_amd/csrc/lexls_lsi_capi.hip),
             // a stand-alone LSE computes on the spot, so solve_resumable() == solve() for any LSE.
             // -------------------------------------------------------------------------------------
+            /// Optional owner of the step of an iteration (a backend that keeps x, v, A*x and the constraint data resident
+            /// can form the step, run the ratio test and update the state next to its equality solve).  Absent (NULL) everywhere but
+            /// in lock-step device batches; with it the statements of lexlsi.h:987-1029 / :1234-1240 are executed by the hook, from the
+            /// second iteration on (the first one belongs to phase 1 and stays here).
+            struct StepHook
+            {
+                virtual ~StepHook() {}
+                /// the working set of the equality problem just formed (lexlsi.h:968-982); on the first call x / v / A*x leave the host
+                virtual void prepare(const dVectorType &x, const std::vector<Objective> &objectives) = 0;
+                /// result of checkBlockingConstraints (lexlsi.h:1006-1029) for the iteration whose equality problem was just solved
+                virtual bool blocking(Index &ObjIndex, Index &CtrIndex, ConstraintActivationType &CtrType, RealScalar &alpha) = 0;
+            };
+            void setStepHook(StepHook *hook) { step_hook = hook; }
+
             enum DeviceNeed
             {
                 NEED_NOTHING = 0,
@@ -503,7 +517,8 @@ namespace LexLS
                     lexlse.factorize();
                     lexlse.solve();
                     lexlse_rank = getTotalRank();
-                    formStep();
+                    it_hooked   = step_hook != NULL;
+                    if (!it_hooked) formStep();
                     nFactorizations++;
                     iteration_blocking();
                     break;
@@ -591,9 +606,11 @@ namespace LexLS
                 it_operation = OPERATION_UNDEFINED;
                 it_constraint.set(0, 0, CTR_INACTIVE);
                 it_normal = true;
+                it_hooked = false;
                 if (nIterations != 0)
                 {
                     formLexLSE();
+                    if (step_hook) step_hook->prepare(x, objectives);
                     pc      = PC_IT_SOLVED;
                     pending = NEED_FACTORIZE_SOLVE;
                 }
@@ -609,7 +626,7 @@ namespace LexLS
             {
                 Index o = 0, c = 0;
                 ConstraintActivationType t = CTR_INACTIVE;
-                if (checkBlockingConstraints(o, c, t, it_alpha))
+                if (it_hooked ? step_hook->blocking(o, c, t, it_alpha) : checkBlockingConstraints(o, c, t, it_alpha))
                 {
                     it_constraint.set(o, c, t);
                     if (parameters.log_working_set_enabled) working_set_log.push_back(WorkingSetLogEntry(o, c, t, it_alpha, lexlse_rank));
@@ -634,7 +651,7 @@ namespace LexLS
             void iteration_finish()
             {
                 step_length = (it_operation == OPERATION_ADD) ? it_alpha : -1;
-                if (it_alpha > 0)
+                if (it_alpha > 0 && !it_hooked) // (a hook has applied the step to the state it owns)
                 {
                     for (Index i = 0; i < nVar; i++) x(i) += it_alpha * dx(i);
                     for (Index k = 0; k < nObj; k++) objectives[k].step(it_alpha);
@@ -669,6 +686,8 @@ namespace LexLS
             ConstraintIdentifier it_constraint;
             RealScalar it_alpha = 1;
             bool it_normal      = true;
+            bool it_hooked      = false; // this iteration's step is formed and applied by step_hook
+            StepHook *step_hook = NULL;
 
             /// lexlsi.h:758-793
             void hot_start_related_tests()

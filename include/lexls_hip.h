@@ -221,6 +221,10 @@ int lexls_lsi_batch_create(lexls_lsi_batch_t *out, int device, uint32_t batch, u
 int lexls_lsi_batch_run(lexls_lsi_batch_t b, const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
                         const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
                         double *h_v, int32_t *h_rounds2);
+/* of the last lexls_lsi_batch_run: {factorize+solve stages, sensitivity stages, stages whose iteration step ran on the device, groups}.
+ * The step of an iteration (A*dx, ratio test, update of x / v / A*x: lexlsi.h:987-1029, :1234-1240) runs on the device
+ * next to the equality solve when the batch is created with LEXLS_LSI_DEVICE_STEP=1 in the environment; off by default. */
+int lexls_lsi_batch_stats(lexls_lsi_batch_t b, int32_t *h_stats4);
 int lexls_lsi_batch_destroy(lexls_lsi_batch_t b);
 /* lexls_lsi_solve plus what the MEX front end also passes (interfaces/matlab-octave/lexlsi.cpp:527-625): h_v0 = initial residuals,
  * sum(dims) doubles (set_v0 per objective) or NULL; h_reg_factors = one regularization factor per objective or NULL; h_params with

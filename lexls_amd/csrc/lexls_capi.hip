@@ -512,6 +512,9 @@ extern "C"
         return LEXLS_OK;
     }
 
+    /* internal: the resident constraint data (lexls_lse_set_constraint_data), read by the lock-step driver's step kernel */
+    const double *lexls_internal_cdata(lexls_lse_t h) { return h ? h->d_cdata : nullptr; }
+
     static int upload_round(lexls_lse_t h, const void *h_in, int gather, bool trusted);
     int lexls_lse_upload_round(lexls_lse_t h, const void *h_in, int gather) { return upload_round(h, h_in, gather, false); }
     /* internal (not in include/lexls_hip.h): the lock-step LexLSI driver of this library fills the block itself — variable indices and

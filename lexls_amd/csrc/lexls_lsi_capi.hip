@@ -1,6 +1,7 @@
 // C ABI for inequality problems: the host-side active-set driver (include/lexls/lexlsi.h) instantiated over
-// the HIP-backed equality solver (include/lexls/lexlse.h).  Host code only; the device work happens inside the
-// lexls_lse_* calls the driver issues.
+// the HIP-backed equality solver (include/lexls/lexlse.h).  The equality solves happen inside the lexls_lse_* calls the driver
+// issues; lock-step batches additionally run the step of an iteration (A*dx, ratio test, state update — SURVEY 8(f) item 1) in the
+// kernel below, next to the equality solve, on the constraint data that is resident for the row gather anyway.
 #include <lexls/lexls.h>
 #include <lexls/lsi_runner.h>
 
@@ -18,6 +19,8 @@
 using namespace LexLS;
 
 extern "C" int lexls_internal_upload_round_trusted(lexls_lse_t h, const void *h_in, int gather); // lexls_capi.hip
+extern "C" const double *lexls_internal_cdata(lexls_lse_t h);                                        // lexls_capi.hip
+#include "lqr_wave_common.h" // wave_max
 
 namespace
 {
@@ -59,6 +62,181 @@ namespace
     void hip_check(int rc)
     {
         if (rc != LEXLS_OK) throw Exception(std::string("liblexls_hip: ") + lexls_last_error());
+    }
+
+    // =============================================================================================
+    // The step of one active-set iteration on the device (lexlsi.h:987-1029 + :1234-1240, objective.h:260-338, :521-589)
+    // =============================================================================================
+    constexpr uint32_t STEP_MAX_OBJ = 16;
+    struct StepShape
+    {
+        uint32_t n, nObj, total, SD; // SD = n + 2 total: per instance [x | v | A x]
+        uint32_t dim[STEP_MAX_OBJ], simple[STEP_MAX_OBJ], first[STEP_MAX_OBJ];
+        uint64_t off[STEP_MAX_OBJ]; // first element of the objective's [A | lb | ub] (or [lb | ub]) block inside a problem's data
+        uint64_t per_data;
+        uint32_t dim0;
+        double tol_feasibility;
+    };
+    /// working-set block of a stage: per instance `mode` (0: no step, 1: state on the device, 2: state arrives in the staging copy),
+    /// per constraint its activation type (0 = inactive) and, for the inactive ones, the position in the objective's inactive list
+    struct StepArgs
+    {
+        StepShape sh;
+        uint32_t B;
+        const double *cdata;      // B x per_data
+        const uint32_t *var;      // B x dim0: variable indices of a simple-bounds objective 0
+        const double *x_lse;      // B x n: solution of the equality problem
+        double *state;            // B x SD
+        const double *state_in;   // B x SD staging (mode 2)
+        const uint8_t *mode;      // B
+        const uint8_t *ctr_state; // B x total
+        const uint16_t *inact_pos; // B x total
+        double *res;              // B x 4: alpha, blocking objective (-1: none), constraint, type
+    };
+
+    __global__ __launch_bounds__(256) void lsi_step_kernel(StepArgs a)
+    {
+        extern __shared__ double smem[];
+        const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+        const uint32_t b = blockIdx.x * 4 + wib;
+        if (b >= a.B) return;
+        const uint32_t md = a.mode[b];
+        if (md == 0) return;
+        const StepShape &sh = a.sh;
+        const uint32_t n = sh.n, total = sh.total;
+        double *dx_s  = smem + (size_t)wib * sh.SD; // n
+        double *adx_s = dx_s + n;                   // total
+        double *dv_s  = adx_s + total;              // total
+        double *st         = a.state + (size_t)b * sh.SD;
+        const double *src  = (md == 2 ? a.state_in : a.state) + (size_t)b * sh.SD;
+        const double *data = a.cdata + (size_t)b * sh.per_data;
+
+        // dx = x_lse - x (lexlsi.h:990-991)
+        for (uint32_t j = lane; j < n; j += 64) dx_s[j] = a.x_lse[(size_t)b * n + j] - src[j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        asm volatile("" ::: "memory");
+
+        double best = INFINITY; // smallest ratio below 1 this lane has seen, first in scan order on ties
+        uint32_t best_key = 0xffffffffu, best_ctr = 0, best_type = 0;
+        for (uint32_t g = lane; g < total; g += 64) // lane = constraint (all objectives side by side)
+        {
+            uint32_t k = 0;
+            while (k + 1 < sh.nObj && g >= sh.first[k + 1]) k++;
+            const uint32_t dim = sh.dim[k], c = g - sh.first[k];
+            const double *blk  = data + sh.off[k];
+            double adx, lb, ub;
+            if (sh.simple[k])
+            {
+                adx = dx_s[a.var[(size_t)b * sh.dim0 + c]]; // objective.h:266-270
+                lb  = blk[c];
+                ub  = blk[c + dim];
+            }
+            else
+            {
+                adx = 0.0; // one ordered chain per row, as the host's apply_A; eight loads in flight
+                uint32_t j = 0;
+                for (; j + 8 <= n; j += 8)
+                {
+                    double av[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) av[u] = blk[c + (size_t)(j + u) * dim];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) adx = lexls::dfma(av[u], dx_s[j + u], adx);
+                }
+                for (; j < n; j++) adx = lexls::dfma(blk[c + (size_t)j * dim], dx_s[j], adx);
+                lb = blk[c + (size_t)n * dim];
+                ub = blk[c + (size_t)(n + 1) * dim];
+            }
+            const double v = src[n + g], ax = src[n + total + g];
+            const uint32_t act = a.ctr_state[(size_t)b * total + g];
+            double dv = -v; // objective.h:292
+            if (act)
+            {
+                const double rhs = (act == CTR_ACTIVE_LB) ? lb : ub;
+                dv               = dv + ((ax + adx) - rhs); // :300-330
+            }
+            else
+            {
+                const double den = adx - dv; // objective.h:532-569
+                uint32_t type    = 0;
+                double rhs       = 0.0;
+                if (den < -sh.tol_feasibility)
+                {
+                    type = CTR_ACTIVE_LB;
+                    rhs  = lb;
+                }
+                else if (den > sh.tol_feasibility)
+                {
+                    type = CTR_ACTIVE_UB;
+                    rhs  = ub;
+                }
+                if (type)
+                {
+                    const double num = (rhs - ax) + v;
+                    double ratio     = num / den;
+                    if (ratio < 0.0) ratio = 0.0;
+                    const uint32_t key = (k << 16) | a.inact_pos[(size_t)b * total + g];
+                    if (ratio < 1.0 && (ratio < best || (ratio == best && key < best_key)))
+                    {
+                        best      = ratio;
+                        best_key  = key;
+                        best_ctr  = c;
+                        best_type = type;
+                    }
+                }
+            }
+            adx_s[g] = adx;
+            dv_s[g]  = dv;
+        }
+        // first minimum in scan order over the wave (strict '<' of the sequential scan, lexlsi.h:1011-1019)
+        const double wmin        = -lexls::wave_max(-best);
+        double alpha             = 1.0;
+        int blk_obj              = -1;
+        uint32_t blk_ctr = 0, blk_type = 0;
+        if (wmin < 1.0)
+        {
+            unsigned long long tied = __ballot(best == wmin);
+            uint32_t kmin           = 0xffffffffu;
+            int win                 = 0;
+            while (tied)
+            {
+                const int l = (int)__builtin_ctzll(tied);
+                tied &= tied - 1;
+                const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)best_key, l);
+                if (key < kmin)
+                {
+                    kmin = key;
+                    win  = l;
+                }
+            }
+            alpha    = wmin;
+            blk_obj  = (int)(kmin >> 16);
+            blk_ctr  = (uint32_t)__builtin_amdgcn_readlane((int)best_ctr, win);
+            blk_type = (uint32_t)__builtin_amdgcn_readlane((int)best_type, win);
+        }
+        if (lane == 0)
+        {
+            double *r = a.res + (size_t)b * 4;
+            r[0]      = alpha;
+            r[1]      = (double)blk_obj;
+            r[2]      = (double)blk_ctr;
+            r[3]      = (double)blk_type;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        asm volatile("" ::: "memory");
+        // the step itself (lexlsi.h:1236-1240, objective.h:585-589); with alpha == 0 the state only moves to its home
+        const bool move = alpha > 0.0;
+        for (uint32_t j = lane; j < n; j += 64)
+        {
+            const double xo = src[j];
+            st[j]           = move ? xo + alpha * dx_s[j] : xo;
+        }
+        for (uint32_t g = lane; g < total; g += 64)
+        {
+            const double v = src[n + g], ax = src[n + total + g];
+            st[n + g]         = move ? v + alpha * dv_s[g] : v;
+            st[n + total + g] = move ? ax + alpha * adx_s[g] : ax;
+        }
     }
 
     /// host array in pinned memory (hipHostMalloc): the per-round copies of a lock-step batch are enqueued, not waited for
@@ -131,7 +309,19 @@ namespace
         uint32_t reg_cg_iters = 10;
         std::atomic<bool> reg_dirty{false};
         bool gather = false;                   // constraint data resident on the device: only row references travel per round
-        int rounds_fs = 0, rounds_sens = 0;
+        // ---- step of an iteration on the device (lsi_step_kernel) ----
+        bool device_step = false;
+        StepShape shape;
+        double *d_state = NULL, *d_state_in = NULL, *d_res = NULL;
+        uint32_t *d_var = NULL;
+        uint8_t *d_wset = NULL;
+        Pinned<double> state_host, res_host;       // B x SD (hand-over staging, final download), B x 4
+        Pinned<uint8_t> wset_host;                 // [mode B | ctr_state B x total | inact_pos (u16) B x total]
+        size_t wset_bytes = 0, wset_state = 0, wset_pos = 0;
+        std::vector<uint8_t> on_device;            // per instance: x / v / A x live on the device
+        std::atomic<bool> handover{false};         // some instance put its state into state_host for the next stage
+        bool stage_step = false;
+        int rounds_fs = 0, rounds_sens = 0, rounds_step = 0;
         double t_enqueue = 0, t_wait = 0; // seconds, reported when LEXLS_LSI_TIMING is set
         static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -166,6 +356,28 @@ namespace
             std::memset(lod, 0, 8 * (size_t)B * pstride);
         }
 
+        /// buffers of the device-side step for a batch of this structure (once per batch object)
+        void create_step(const StepShape &sh)
+        {
+            shape = sh;
+            const size_t SD = sh.SD, total = sh.total;
+            wset_state = ((size_t)B + 15) & ~size_t(15);
+            wset_pos   = (wset_state + (size_t)B * total + 15) & ~size_t(15);
+            wset_bytes = wset_pos + 2 * (size_t)B * total;
+            if (hipMalloc((void **)&d_state, 8 * B * SD) != hipSuccess || hipMalloc((void **)&d_state_in, 8 * B * SD) != hipSuccess ||
+                hipMalloc((void **)&d_res, 8 * (size_t)B * 4) != hipSuccess || hipMalloc((void **)&d_var, 4 * (size_t)B * (sh.dim0 ? sh.dim0 : 1)) != hipSuccess ||
+                hipMalloc((void **)&d_wset, wset_bytes) != hipSuccess)
+                throw Exception("hipMalloc failed (device-side LSI step)");
+            state_host.assign((size_t)B * SD, 0.0);
+            res_host.assign((size_t)B * 4, 0.0);
+            wset_host.assign(wset_bytes, 0);
+            on_device.assign(B, 0);
+            device_step = true;
+        }
+        uint8_t *mode() { return wset_host.data(); }
+        uint8_t *ctr_state(uint32_t b) { return wset_host.data() + wset_state + (size_t)b * shape.total; }
+        uint16_t *inact_pos(uint32_t b) { return reinterpret_cast<uint16_t *>(wset_host.data() + wset_pos) + (size_t)b * shape.total; }
+
         /// per-solve state: what a freshly created context holds (a context serves many lexls_lsi_batch_run calls)
         void reset()
         {
@@ -190,13 +402,23 @@ namespace
             rank.assign((size_t)B * nObjL, 0);
             totalrank.assign(B, 0);
             reg_factor.assign((size_t)B * nObjL, 0.0);
-            rounds_fs = rounds_sens = 0;
+            rounds_fs = rounds_sens = rounds_step = 0;
             t_enqueue = t_wait = 0.0;
+            if (device_step)
+            {
+                std::fill(wset_host.begin(), wset_host.end(), 0);
+                std::fill(on_device.begin(), on_device.end(), 0);
+                handover.store(false);
+                stage_step = false;
+            }
             stage_fs = stage_sens = false;
         }
         ~BatchCtx()
         {
             if (h) lexls_lse_destroy(h);
+            void *dev[] = {d_state, d_state_in, d_res, d_var, d_wset};
+            for (void *q : dev)
+                if (q) (void)hipFree(q);
             if (stream) (void)hipStreamDestroy(stream);
             if (stream_sens) (void)hipStreamDestroy(stream_sens);
             if (ev_uploaded) (void)hipEventDestroy(ev_uploaded);
@@ -206,8 +428,9 @@ namespace
 
         /// Enqueue ONE stage on this group's stream: a batched factorize+solve for the instances with skip == 0 (if serve_fs) and a batched
         /// ObjectiveSensitivity for the instances with objidx >= 0 (if serve_sens) — disjoint sets of instances.  Nothing is waited for.
-        void enqueue_stage(bool serve_fs, bool serve_sens, double tolW, double tolC)
+        void enqueue_stage(bool serve_fs, bool serve_sens, bool use_step, double tolW, double tolC)
         {
+            stage_step = false;
             const double t0 = now();
             stage_fs   = serve_fs;
             stage_sens = serve_sens;
@@ -224,6 +447,33 @@ namespace
                 if (!gather) hip_check(lexls_lse_set_problem_host(h, lod));
                 hip_check(lexls_lse_factorize_solve(h, 1));
                 rounds_fs++;
+                stage_step = use_step;
+                if (use_step) rounds_step++;
+                if (use_step) // the step of the iteration, right behind its equality solve (same stream)
+                {
+                    if (hipMemcpyAsync(d_wset, wset_host.data(), wset_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) throw Exception("hipMemcpyAsync failed (working sets)");
+                    if (handover.exchange(false) &&
+                        hipMemcpyAsync(d_state_in, state_host.data(), 8 * (size_t)B * shape.SD, hipMemcpyHostToDevice, stream) != hipSuccess)
+                        throw Exception("hipMemcpyAsync failed (state hand-over)");
+                    void *d_x = NULL;
+                    hip_check(lexls_lse_device_ptr(h, LEXLS_ARRAY_X, &d_x));
+                    StepArgs sa;
+                    sa.sh        = shape;
+                    sa.B         = B;
+                    sa.cdata     = lexls_internal_cdata(h);
+                    sa.var       = d_var;
+                    sa.x_lse     = static_cast<const double *>(d_x);
+                    sa.state     = d_state;
+                    sa.state_in  = d_state_in;
+                    sa.mode      = d_wset;
+                    sa.ctr_state = d_wset + wset_state;
+                    sa.inact_pos = reinterpret_cast<const uint16_t *>(d_wset + wset_pos);
+                    sa.res       = d_res;
+                    hipLaunchKernelGGL(lsi_step_kernel, dim3((B + 3) / 4), dim3(256), 8 * (size_t)shape.SD * 4, stream, sa);
+                    if (hipGetLastError() != hipSuccess ||
+                        hipMemcpyAsync(res_host.data(), d_res, 8 * (size_t)B * 4, hipMemcpyDeviceToHost, stream) != hipSuccess)
+                        throw Exception("lsi_step_kernel launch / result copy failed");
+                }
             }
             if (serve_sens)
             {
@@ -378,6 +628,56 @@ namespace
 
     typedef internal::LexLSI_T<SlotLSE> SlotLSI;
 
+    /// One instance's side of the device-side step (LexLSI_T::StepHook): posts the working set of the equality problem just formed,
+    /// hands x / v / A x over to the device the first time, and reads the ratio test's verdict back.
+    struct SlotStep : SlotLSI::StepHook
+    {
+        BatchCtx *c = NULL;
+        uint32_t b  = 0;
+        void prepare(const dVectorType &x, const std::vector<internal::Objective> &obj) override
+        {
+            const StepShape &sh = c->shape;
+            uint8_t *cs         = c->ctr_state(b);
+            uint16_t *ip        = c->inact_pos(b);
+            std::memset(cs, 0, sh.total);
+            for (uint32_t k = 0; k < sh.nObj; k++)
+            {
+                const uint32_t first = sh.first[k];
+                for (Index a = 0; a < obj[k].getActiveCtrCount(); a++) cs[first + obj[k].getActiveCtrIndex(a)] = static_cast<uint8_t>(obj[k].getActiveCtrType(a));
+                for (Index i = 0; i < obj[k].getInactiveCtrCount(); i++) ip[first + obj[k].getInactiveCtrIndex(i)] = static_cast<uint16_t>(i);
+            }
+            if (!c->on_device[b])
+            {
+                double *st = c->state_host.data() + (size_t)b * sh.SD;
+                for (uint32_t j = 0; j < sh.n; j++) st[j] = x(j);
+                for (uint32_t k = 0; k < sh.nObj; k++)
+                {
+                    const dVectorType &v = obj[k].get_v(), &ax = obj[k].get_Ax();
+                    for (uint32_t i = 0; i < sh.dim[k]; i++)
+                    {
+                        st[sh.n + sh.first[k] + i]            = v(i);
+                        st[sh.n + sh.total + sh.first[k] + i] = ax(i);
+                    }
+                }
+                c->on_device[b] = 1;
+                c->mode()[b]    = 2;
+                c->handover.store(true);
+            }
+            else
+                c->mode()[b] = 1;
+        }
+        bool blocking(Index &ObjIndex, Index &CtrIndex, ConstraintActivationType &CtrType, RealScalar &alpha) override
+        {
+            const double *r = c->res_host.data() + (size_t)b * 4;
+            alpha           = r[0];
+            if (r[1] < 0.0) return false;
+            ObjIndex = static_cast<Index>(r[1]);
+            CtrIndex = static_cast<Index>(r[2]);
+            CtrType  = static_cast<ConstraintActivationType>(static_cast<int>(r[3]));
+            return true;
+        }
+    };
+
     /// Persistent host worker pool for the per-instance work of a lock-step batch (the instances are independent; each touches only
     /// its own LexLSI object and its own slot of the staging arrays).  Created once per lexls_lsi_batch_solve call: the active-set
     /// rounds are short (~1 ms of host work for 1024 instances), so threads must not be spawned per round.
@@ -386,13 +686,14 @@ namespace
     public:
         explicit WorkerPool(uint32_t workers)
         {
+            if (const char *e = std::getenv("LEXLS_POOL_SPIN_US")) spin_seconds = 1e-6 * std::atof(e); // diagnostic: 0 = sleep at once
             for (uint32_t i = 0; i < workers; i++) th.emplace_back([this]() { loop(); });
         }
         ~WorkerPool()
         {
             {
                 std::lock_guard<std::mutex> lk(m);
-                stop = true;
+                stop.store(true);
             }
             cv_start.notify_all();
             for (auto &t : th) t.join();
@@ -403,7 +704,9 @@ namespace
             const uint32_t nt = std::min<uint32_t>(std::min<uint32_t>(hw, 16u), batch / 64);
             return nt > 1 ? nt - 1 : 0; // the calling thread works too
         }
-        /// f(b) for b in [0, count); returns when all are done; rethrows the first exception
+        /// f(b) for b in [0, count); returns when all are done; rethrows the first exception.
+        /// The stages of a batch solve follow each other every ~50 us: a condition-variable wake-up per stage would cost more than
+        /// the stage's host work, so idle workers spin on the generation counter for a while (spin_seconds) before they go to sleep.
         void run(uint32_t count_, const std::function<void(uint32_t)> &f)
         {
             if (th.empty() || count_ < 128)
@@ -411,24 +714,27 @@ namespace
                 for (uint32_t b = 0; b < count_; b++) f(b);
                 return;
             }
+            job   = &f;
+            count = count_;
+            next.store(0);
+            err = nullptr;
+            pending.store(static_cast<uint32_t>(th.size()), std::memory_order_relaxed);
+            gen.fetch_add(1); // seq_cst with the sleepers' increment / generation check below: one side always sees the other
+            if (sleepers.load() != 0)
             {
-                std::lock_guard<std::mutex> lk(m);
-                job     = &f;
-                count   = count_;
-                pending = static_cast<uint32_t>(th.size());
-                next.store(0);
-                err = nullptr;
-                gen++;
+                std::lock_guard<std::mutex> lk(m); // a worker between its last check and its wait holds m: it sees the new generation
+                cv_start.notify_all();
             }
-            cv_start.notify_all();
             work();
-            std::unique_lock<std::mutex> lk(m);
-            cv_done.wait(lk, [&]() { return pending == 0; });
+            while (pending.load(std::memory_order_acquire) != 0) relax(); // every worker acknowledges every generation
             job = nullptr;
             if (err) std::rethrow_exception(err);
         }
 
     private:
+        double spin_seconds = 300e-6;
+        static void relax() { __builtin_ia32_pause(); }
+        static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
         void work()
         {
             const uint32_t chunk = 16;
@@ -453,27 +759,34 @@ namespace
             uint64_t seen = 0;
             for (;;)
             {
+                uint32_t spins = 0;
+                double t_idle  = 0.0;
+                while (gen.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed))
                 {
+                    relax();
+                    if ((++spins & 255u) != 0) continue;
+                    const double t = now();
+                    if (t_idle == 0.0) t_idle = t;
+                    if (t - t_idle < spin_seconds) continue;
                     std::unique_lock<std::mutex> lk(m);
-                    cv_start.wait(lk, [&]() { return stop || gen != seen; });
-                    if (stop) return;
-                    seen = gen;
+                    sleepers.fetch_add(1);
+                    cv_start.wait(lk, [&]() { return stop.load() || gen.load() != seen; });
+                    sleepers.fetch_sub(1);
                 }
+                if (stop.load()) return;
+                seen = gen.load(std::memory_order_acquire);
                 work();
-                {
-                    std::lock_guard<std::mutex> lk(m);
-                    if (--pending == 0) cv_done.notify_one();
-                }
+                pending.fetch_sub(1, std::memory_order_release);
             }
         }
         std::vector<std::thread> th;
         std::mutex m;
-        std::condition_variable cv_start, cv_done;
+        std::condition_variable cv_start;
         const std::function<void(uint32_t)> *job = nullptr;
-        uint32_t count = 0, pending = 0;
-        std::atomic<uint32_t> next{0};
-        uint64_t gen = 0;
-        bool stop    = false;
+        uint32_t count                           = 0;
+        std::atomic<uint32_t> next{0}, pending{0}, sleepers{0};
+        std::atomic<uint64_t> gen{0};
+        std::atomic<bool> stop{false};
         std::exception_ptr err;
     };
 } // namespace
@@ -493,6 +806,7 @@ struct lexls_lsi_batch_s
     std::vector<uint32_t> lo, group_of;
     std::unique_ptr<WorkerPool> pool;
     double t_create = 0.0;
+    int32_t last_stats[4] = {0, 0, 0, 0}; // of the last run: factorize+solve stages, sensitivity stages, stages with the step on the device, groups
 
     lexls_lsi_batch_s(int device_, uint32_t batch_, uint32_t nVar_, uint32_t nObj_, const uint32_t *h_dims, const int32_t *h_types)
     : device(device_), batch(batch_), nVar(nVar_), nObj(nObj_)
@@ -527,6 +841,29 @@ struct lexls_lsi_batch_s
             ctx.create(device, lo[g + 1] - lo[g], nVar, nObj - off, h_dims + off, gather);
             hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between stages
         }
+        // the step of an iteration can run on the device when the constraint data is resident
+        StepShape sh;
+        std::memset(&sh, 0, sizeof(sh));
+        sh.n = nVar, sh.nObj = nObj, sh.total = (uint32_t)total, sh.SD = nVar + 2 * (uint32_t)total, sh.per_data = per_data, sh.dim0 = off ? h_dims[0] : 0;
+        // Off by default: measured on MI355X (scripts/lsi_ab.sh; 1024 / 2048 / 4096 instances of n = 40, 5 x 12) it is as fast as the
+        // host's step at 4096 (0.115-0.120 s vs 0.116-0.127 s) and slower below (1024: 0.055 s vs 0.051 s) — the host's share of a stage
+        // is parallel and small, the extra copy + kernel + copy of a stage is not free.  LEXLS_LSI_DEVICE_STEP=1 turns it on.
+        const char *want_step = std::getenv("LEXLS_LSI_DEVICE_STEP");
+        bool step_ok = want_step && std::atoi(want_step) != 0 && gather && nObj <= STEP_MAX_OBJ && 8 * (size_t)sh.SD * 4 <= 48 * 1024;
+        if (step_ok)
+        {
+            uint64_t o = 0;
+            uint32_t f = 0;
+            for (uint32_t k = 0; k < nObj; k++)
+            {
+                sh.dim[k] = h_dims[k], sh.simple[k] = h_types[k] == 1, sh.first[k] = f, sh.off[k] = o;
+                if (h_dims[k] > 65535) step_ok = false;
+                o += (uint64_t)h_dims[k] * (h_types[k] == 1 ? 2 : nVar + 2);
+                f += h_dims[k];
+            }
+        }
+        if (step_ok)
+            for (uint32_t g = 0; g < nGroups; g++) grp[g]->create_step(sh);
         group_of.resize(batch);
         for (uint32_t g = 0; g < nGroups; g++)
             for (uint32_t b = lo[g]; b < lo[g + 1]; b++) group_of[b] = g;
@@ -559,7 +896,20 @@ struct lexls_lsi_batch_s
             ctx.reg_dirty.store(ctx.reg_type != 0);
             if (ctx.reg_type == 0) hip_check(lexls_lse_set_regularization(ctx.h, 0, NULL, 0, 0.0));
             if (run_gather) hip_check(lexls_lse_set_constraint_data(ctx.h, h_data + (size_t)lo[g] * per_data, per_data));
+            if (run_gather && ctx.device_step)
+            {
+                ctx.shape.tol_feasibility = par.tol_feasibility;
+                if (ctx.shape.dim0)
+                {
+                    if (!h_var_index) throw Exception("lexls_lsi_batch_run: a simple-bounds objective needs variable indices");
+                    if (hipMemcpyAsync(ctx.d_var, h_var_index + (size_t)lo[g] * ctx.shape.dim0, 4 * (size_t)ctx.B * ctx.shape.dim0, hipMemcpyHostToDevice, ctx.stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx.stream) != hipSuccess)
+                        throw Exception("upload of the variable indices failed");
+                }
+            }
         }
+        const bool run_step = run_gather && grp[0]->device_step;
+        std::vector<SlotStep> hooks(run_step ? batch : 0);
         const double t_ctx = BatchCtx::now() - t_begin;
         std::vector<std::unique_ptr<SlotLSI>> lsi(batch);
         std::vector<runner::LsiProblem> prob(batch);
@@ -578,6 +928,12 @@ struct lexls_lsi_batch_s
                        NULL,
                        h_reg_factors};
             runner::setup(*lsi[b], prob[b], par);
+            if (run_step)
+            {
+                hooks[b].c = grp[g].get();
+                hooks[b].b = b - lo[g];
+                lsi[b]->setStepHook(&hooks[b]);
+            }
             lsi[b]->begin();
         });
         const double t_setup = BatchCtx::now() - t_begin;
@@ -587,7 +943,7 @@ struct lexls_lsi_batch_s
         // one call (different instances), both only enqueued.  Between two stages every instance of the group runs ONE job on the worker
         // pool: take over the results of the stage that just finished (if it was served), advance its active-set logic, and post what it
         // needs next into the group's round block.
-        std::vector<std::atomic<uint32_t>> wants(nGroups); // bit 0: somebody alive, bit 1: a factorize+solve, bit 2: a sensitivity
+        std::vector<std::atomic<uint32_t>> wants(nGroups); // bit 0: somebody alive, bit 1: a factorize+solve, bit 2: a sensitivity, bit 3: a device-side step
         auto turn = [&](uint32_t g) {
             BatchCtx &ctx = *grp[g];
             wants[g].store(0);
@@ -595,6 +951,7 @@ struct lexls_lsi_batch_s
             pool.run(lo[g + 1] - lo[g], [&](uint32_t k) {
                 SlotLSI &inst        = *lsi[lo[g] + k];
                 const bool served_fs = ctx.stage_fs && !ctx.skip[k], served_sens = ctx.stage_sens && ctx.objidx[k] >= 0;
+                if (run_step) ctx.mode()[k] = 0; // (the hook raises it again when the instance posts an iteration's equality problem)
                 if (served_fs) ctx.take_solution(k);
                 if (served_sens) ctx.take_marks(k);
                 if (served_fs || served_sens) inst.advance();
@@ -603,7 +960,7 @@ struct lexls_lsi_batch_s
                 const bool se    = alive && inst.need() == SlotLSI::NEED_SENSITIVITY;
                 ctx.skip[k]      = fs ? 0 : 1;
                 ctx.objidx[k]    = se ? static_cast<int32_t>(inst.needLevel()) : -1;
-                const uint32_t w = (alive ? 1u : 0u) | (fs ? 2u : 0u) | (se ? 4u : 0u);
+                const uint32_t w = (alive ? 1u : 0u) | (fs ? 2u : 0u) | (se ? 4u : 0u) | ((run_step && fs && ctx.mode()[k]) ? 8u : 0u);
                 if (w & ~wants[g].load(std::memory_order_relaxed)) wants[g].fetch_or(w, std::memory_order_relaxed);
             });
             t_host += BatchCtx::now() - t0;
@@ -614,7 +971,7 @@ struct lexls_lsi_batch_s
             ctx.stage_fs = ctx.stage_sens = false;
             if (!(w & 1u)) return false;
             if (!(w & 6u)) throw Exception("lexls_lsi_batch_solve: an instance is alive but requests nothing");
-            ctx.enqueue_stage((w & 2u) != 0, (w & 4u) != 0, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
+            ctx.enqueue_stage((w & 2u) != 0, (w & 4u) != 0, (w & 8u) != 0, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
             return true;
         };
         auto finish = [&](uint32_t g) {
@@ -641,31 +998,52 @@ struct lexls_lsi_batch_s
                 }
         }
 
+        if (run_step) // x and v of the instances whose state lives on the device
+            for (uint32_t g = 0; g < nGroups; g++)
+            {
+                BatchCtx &ctx = *grp[g];
+                if (hipMemcpyAsync(ctx.state_host.data(), ctx.d_state, 8 * (size_t)ctx.B * ctx.shape.SD, hipMemcpyDeviceToHost, ctx.stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx.stream) != hipSuccess)
+                    throw Exception("download of the final state failed");
+            }
         pool.run(batch, [&](uint32_t b) {
             runner::LsiInfo info;
             runner::collect(*lsi[b], prob[b], h_x + (size_t)b * nVar, &info, h_active ? h_active + (size_t)b * total : NULL,
                             h_v ? h_v + (size_t)b * total : NULL);
             if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
+            if (run_step)
+            {
+                BatchCtx &ctx    = *grp[group_of[b]];
+                const uint32_t k = b - lo[group_of[b]];
+                if (ctx.on_device[k])
+                {
+                    const double *st = ctx.state_host.data() + (size_t)k * ctx.shape.SD;
+                    std::copy(st, st + nVar, h_x + (size_t)b * nVar);
+                    if (h_v) std::copy(st + nVar, st + nVar + total, h_v + (size_t)b * total);
+                }
+            }
         });
-        int rounds_fs = 0, rounds_sens = 0;
+        int rounds_fs = 0, rounds_sens = 0, rounds_step = 0;
         double t_enq = 0.0, t_wait = 0.0;
         for (uint32_t g = 0; g < nGroups; g++)
         {
             rounds_fs += grp[g]->rounds_fs;
             rounds_sens += grp[g]->rounds_sens;
+            rounds_step += grp[g]->rounds_step;
             t_enq += grp[g]->t_enqueue;
             t_wait += grp[g]->t_wait;
         }
         if (std::getenv("LEXLS_LSI_TIMING"))
             std::fprintf(stderr, "lexls_lsi_batch_solve: setup = %.4f s reset / constraint upload + %.4f s LexLSI objects (batch created in %.4f s)\n", t_ctx, t_setup - t_ctx, t_create),
-            std::fprintf(stderr, "lexls_lsi_batch_solve: total %.4f s = setup %.4f + enqueue %.4f + wait for the GPU %.4f + host logic %.4f + rest %.4f (%u groups, %d+%d stages)\n",
+            std::fprintf(stderr, "lexls_lsi_batch_solve: total %.4f s = setup %.4f + enqueue %.4f + wait for the GPU %.4f + host logic %.4f + rest %.4f (%u groups, %d+%d stages, %d with the step on the device)\n",
                          BatchCtx::now() - t_begin, t_setup, t_enq, t_wait, t_host, BatchCtx::now() - t_begin - t_setup - t_enq - t_wait - t_host, nGroups,
-                         rounds_fs, rounds_sens);
+                         rounds_fs, rounds_sens, rounds_step);
         if (h_rounds2)
         {
             h_rounds2[0] = rounds_fs;
             h_rounds2[1] = rounds_sens;
         }
+        last_stats[0] = rounds_fs, last_stats[1] = rounds_sens, last_stats[2] = rounds_step, last_stats[3] = (int32_t)nGroups;
     }
 };
 
@@ -694,6 +1072,17 @@ extern "C"
             lexls_internal_set_error(e.what());
             return LEXLS_ERR_INVALID;
         }
+    }
+
+    int lexls_lsi_batch_stats(lexls_lsi_batch_t b, int32_t *h_stats4)
+    {
+        if (!b || !h_stats4)
+        {
+            lexls_internal_set_error("lexls_lsi_batch_stats: null argument");
+            return LEXLS_ERR_INVALID;
+        }
+        std::memcpy(h_stats4, b->last_stats, sizeof(b->last_stats));
+        return LEXLS_OK;
     }
 
     int lexls_lsi_batch_destroy(lexls_lsi_batch_t b)

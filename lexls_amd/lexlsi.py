@@ -140,6 +140,12 @@ class LsiBatch:
         except Exception:
             pass
 
+    def stats(self) -> dict:
+        """of the last run: stage counts and whether the iteration step ran on the device (LEXLS_LSI_DEVICE_STEP=1 at creation)"""
+        st = np.zeros(4, np.int32)
+        capi.check(capi.lib().lexls_lsi_batch_stats(self._h, _p(st, C.c_int32)))
+        return dict(factorize_solve=int(st[0]), sensitivity=int(st[1]), device_step=int(st[2]), groups=int(st[3]))
+
     def run(self, problems, active_guess=None, x0=None, regularization_factors=None, **params):
         """`problems`: list of objective lists or a PackedBatch of this batch's structure; other arguments as lsi_batch_solve"""
         pk = problems if isinstance(problems, PackedBatch) else pack_batch(self.nvar, problems)

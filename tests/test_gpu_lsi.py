@@ -287,6 +287,37 @@ def test_lock_step_batch_with_cycling_handling_enabled(hip, oracle):
         np.testing.assert_array_equal(plain["x"][b], o0["x"])
 
 
+@pytest.mark.parametrize("simple_bounds", [True, False])
+def test_device_side_step_matches_host_step(hip, oracle, monkeypatch, simple_bounds):
+    """SURVEY 8(f) item 1, LEXLS_LSI_DEVICE_STEP=1: from the second iteration on A*dx, the ratio test (first minimum in working-set scan
+    order, lexlsi.h:1006-1029) and the update of x / v / A*x run on the device next to the equality solve; the host keeps the working
+    sets.  Same trajectories, same x and v bit for bit as the host step and as the oracle-backed driver — cold and warm-started."""
+    n, dims, batch = 18, [6, 5, 7, 4], 14
+    problems = [P.lsi_problem(1500 + b, n, dims, simple_bounds=simple_bounds) for b in range(batch)]
+    pk = lexlsi.pack_batch(n, problems)
+    host = lexlsi.lsi_batch_solve(n, pk)
+    monkeypatch.setenv("LEXLS_LSI_DEVICE_STEP", "1")
+    srv = lexlsi.LsiBatch(n, pk.dims, pk.types, batch)
+    monkeypatch.delenv("LEXLS_LSI_DEVICE_STEP")
+    dev = srv.run(pk)
+    assert srv.stats()["device_step"] > 0
+    guess = np.where(dev["active"] == 3, 0, dev["active"]).astype(np.uint8)
+    pert = lexlsi.pack_batch(n, [P.lsi_problem(1500 + b, n, dims, simple_bounds=simple_bounds, perturb=0.4) for b in range(batch)])
+    dev_w = srv.run(pert, active_guess=guess, x0=dev["x"])
+    srv.close()
+    host_w = lexlsi.lsi_batch_solve(n, pert, active_guess=guess, x0=dev["x"])
+    for d, h in ((dev, host), (dev_w, host_w)):
+        assert d["info"] == h["info"]
+        np.testing.assert_array_equal(d["x"], h["x"])
+        np.testing.assert_array_equal(d["v"], h["v"])
+        np.testing.assert_array_equal(d["active"], h["active"])
+    for b in range(batch):
+        o = oracle.lsi_run(n, problems[b])
+        assert dev["info"][b] == o["info"]
+        np.testing.assert_array_equal(dev["x"][b], o["x"])
+        np.testing.assert_array_equal(dev["v"][b], np.concatenate(o["v"]))
+
+
 def test_lock_step_batch_with_regularization(hip, oracle):
     """lexls_lsi_batch_solve_ex: the damped hierarchies of a batch run lock-step on the generic kernel; every instance ends exactly where
     its stand-alone oracle-backed solve with the same regularization ends."""
