@@ -199,7 +199,7 @@ int lexls_lsi_solve(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_
  * active-set round issues one batched factorize+solve and one batched ObjectiveSensitivity per LexLSE level for all the
  * instances that need it (BASELINE configs[4]).  Arrays are the per-problem arrays of lexls_lsi_solve, back to back
  * (h_var_index: batch x dims[0]; h_active_guess / h_x0 may be NULL); h_rounds2 (may be NULL) receives
- * {factorize+solve stages, sensitivity stages} actually issued to the device.  The instances are split into g groups (default: 2 from 768
+ * {factorize+solve stages, sensitivity stages} actually issued to the device.  The instances are split into g groups (default: 2 from 512
  * instances on, else 1; LEXLS_LSI_GROUPS=g overrides) that take turns: one group's stage runs on the GPU while the host advances the other
  * groups' active sets. */
 int lexls_lsi_batch_solve(int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types,

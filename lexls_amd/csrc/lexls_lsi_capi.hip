@@ -825,9 +825,9 @@ struct lexls_lsi_batch_s
         // The instances can be split into groups that take turns: while one group's stage runs on the GPU (its own stream), the host
         // advances the active-set logic of the other one.  Every stage carries fixed costs (one copy each way, launches, one
         // synchronisation) that a split multiplies, so it pays for large batches only.  Measured on MI355X, cold
-        // solve of n = 40, 5 x 12: 256 instances 0.045 s in one group / 0.050 s in two; 1024 instances 0.066 s / 0.048-0.057 s
-        // (three groups 0.056-0.062 s, four 0.076 s).  LEXLS_LSI_GROUPS overrides the number.
-        nGroups = batch >= 768 ? 2u : 1u;
+        // solve of n = 40, 5 x 12, seconds with 1 / 2 / 3 groups: 256 instances 0.044 / 0.047; 512: 0.050 / 0.043 / 0.056;
+        // 1024: 0.057 / 0.050 / 0.053.  LEXLS_LSI_GROUPS overrides the number.
+        nGroups = batch >= 512 ? 2u : 1u;
         if (const char *e = std::getenv("LEXLS_LSI_GROUPS")) nGroups = std::max(1, std::atoi(e));
         nGroups = std::min(nGroups, batch);
         gather = per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING"); // (diagnostic switch: assemble on the host, stage over PCIe)
