@@ -428,7 +428,7 @@ namespace
 
         /// Enqueue ONE stage on this group's stream: a batched factorize+solve for the instances with skip == 0 (if serve_fs) and a batched
         /// ObjectiveSensitivity for the instances with objidx >= 0 (if serve_sens) — disjoint sets of instances.  Nothing is waited for.
-        void enqueue_stage(bool serve_fs, bool serve_sens, bool use_step, double tolW, double tolC)
+        void enqueue_stage(bool serve_fs, bool serve_sens, bool use_step, bool x_needed, double tolW, double tolC)
         {
             stage_step = false;
             const double t0 = now();
@@ -496,7 +496,19 @@ namespace
             // (lexlse.h:866-987) and the marks must survive until the instance re-forms its problem: a later factorize stage uploads the
             // host arrays for EVERY instance, also for the ones that are still in the middle of their sensitivity sequence — so the host
             // copy takes the marks over (finish_stage) from the second copy
-            hip_check(lexls_lse_download_round(h, out_block.data(), serve_sens ? types_block.data() : NULL));
+            if (x_needed || !serve_fs)
+                hip_check(lexls_lse_download_round(h, out_block.data(), serve_sens ? types_block.data() : NULL));
+            else
+            {
+                // every equality solve of this stage feeds a device-side step: x stays on the device, only the tail of the out slab
+                // (total ranks, sensitivity verdicts) and the marks come back
+                void *d_out = NULL;
+                hip_check(lexls_lse_device_ptr(h, LEXLS_ARRAY_X, &d_out)); // x is the head of the out slab (lexls_lse_round_layout)
+                if (hipMemcpyAsync(out_block.data() + lay.total_rank, static_cast<char *>(d_out) + lay.total_rank, lay.out_bytes - lay.total_rank, hipMemcpyDeviceToHost,
+                                   stream) != hipSuccess)
+                    throw Exception("hipMemcpyAsync failed (results without x)");
+                if (serve_sens) hip_check(lexls_lse_download_round(h, NULL, types_block.data()));
+            }
             t_enqueue += now() - t0;
         }
 
@@ -845,9 +857,9 @@ struct lexls_lsi_batch_s
         StepShape sh;
         std::memset(&sh, 0, sizeof(sh));
         sh.n = nVar, sh.nObj = nObj, sh.total = (uint32_t)total, sh.SD = nVar + 2 * (uint32_t)total, sh.per_data = per_data, sh.dim0 = off ? h_dims[0] : 0;
-        // Off by default: measured on MI355X (scripts/lsi_ab.sh; 1024 / 2048 / 4096 instances of n = 40, 5 x 12) it is as fast as the
-        // host's step at 4096 (0.115-0.120 s vs 0.116-0.127 s) and slower below (1024: 0.055 s vs 0.051 s) — the host's share of a stage
-        // is parallel and small, the extra copy + kernel + copy of a stage is not free.  LEXLS_LSI_DEVICE_STEP=1 turns it on.
+        // Off by default: measured on MI355X (scripts/lsi_ab.sh; 1024 / 4096 instances of n = 40, 5 x 12) it is a wash — cold 0.052 s
+        // vs 0.049 s at 1024, 0.117 s vs 0.120 s at 4096: the host's share of a stage is parallel and small, the extra copy + kernel +
+        // copy of a stage is not free.  LEXLS_LSI_DEVICE_STEP=1 turns it on.
         const char *want_step = std::getenv("LEXLS_LSI_DEVICE_STEP");
         bool step_ok = want_step && std::atoi(want_step) != 0 && gather && nObj <= STEP_MAX_OBJ && 8 * (size_t)sh.SD * 4 <= 48 * 1024;
         if (step_ok)
@@ -943,7 +955,7 @@ struct lexls_lsi_batch_s
         // one call (different instances), both only enqueued.  Between two stages every instance of the group runs ONE job on the worker
         // pool: take over the results of the stage that just finished (if it was served), advance its active-set logic, and post what it
         // needs next into the group's round block.
-        std::vector<std::atomic<uint32_t>> wants(nGroups); // bit 0: somebody alive, bit 1: a factorize+solve, bit 2: a sensitivity, bit 3: a device-side step
+        std::vector<std::atomic<uint32_t>> wants(nGroups); // bit 0: somebody alive, bit 1: a factorize+solve, bit 2: a sensitivity, bit 3: a device-side step, bit 4: a solve whose x the host needs
         auto turn = [&](uint32_t g) {
             BatchCtx &ctx = *grp[g];
             wants[g].store(0);
@@ -960,7 +972,8 @@ struct lexls_lsi_batch_s
                 const bool se    = alive && inst.need() == SlotLSI::NEED_SENSITIVITY;
                 ctx.skip[k]      = fs ? 0 : 1;
                 ctx.objidx[k]    = se ? static_cast<int32_t>(inst.needLevel()) : -1;
-                const uint32_t w = (alive ? 1u : 0u) | (fs ? 2u : 0u) | (se ? 4u : 0u) | ((run_step && fs && ctx.mode()[k]) ? 8u : 0u);
+                const bool dstep = run_step && fs && ctx.mode()[k] != 0;
+                const uint32_t w = (alive ? 1u : 0u) | (fs ? 2u : 0u) | (se ? 4u : 0u) | (dstep ? 8u : 0u) | ((fs && !dstep) ? 16u : 0u);
                 if (w & ~wants[g].load(std::memory_order_relaxed)) wants[g].fetch_or(w, std::memory_order_relaxed);
             });
             t_host += BatchCtx::now() - t0;
@@ -971,7 +984,7 @@ struct lexls_lsi_batch_s
             ctx.stage_fs = ctx.stage_sens = false;
             if (!(w & 1u)) return false;
             if (!(w & 6u)) throw Exception("lexls_lsi_batch_solve: an instance is alive but requests nothing");
-            ctx.enqueue_stage((w & 2u) != 0, (w & 4u) != 0, (w & 8u) != 0, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
+            ctx.enqueue_stage((w & 2u) != 0, (w & 4u) != 0, (w & 8u) != 0, (w & 16u) != 0, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda);
             return true;
         };
         auto finish = [&](uint32_t g) {
