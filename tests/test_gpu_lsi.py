@@ -318,6 +318,25 @@ def test_device_side_step_matches_host_step(hip, oracle, monkeypatch, simple_bou
         np.testing.assert_array_equal(dev["v"][b], np.concatenate(o["v"]))
 
 
+@pytest.mark.parametrize("groups", [2, 3])
+def test_lock_step_groups_take_turns(hip, oracle, monkeypatch, groups):
+    """large batches are split into groups that take turns on their own streams (default from 512 instances on); forced here on a small
+    batch, with an uneven split: every instance ends where its stand-alone oracle-backed solve ends, and the worker pool is exercised
+    (>= 128 instances per group)."""
+    n, dims, batch = 10, [4, 3, 4], 128 * groups + 5
+    problems = [P.lsi_problem(1700 + (b % 40), n, dims, perturb=0.01 * (b // 40)) for b in range(batch)]
+    monkeypatch.setenv("LEXLS_LSI_GROUPS", str(groups))
+    srv = lexlsi.LsiBatch(n, *[getattr(lexlsi.pack_batch(n, problems[:1]), k) for k in ("dims", "types")], batch)
+    r = srv.run(problems)
+    assert srv.stats()["groups"] == groups
+    srv.close()
+    for b in list(range(0, batch, 17)) + [batch - 1]:
+        o = oracle.lsi_run(n, problems[b])
+        assert r["info"][b] == o["info"], b
+        np.testing.assert_array_equal(r["x"][b], o["x"])
+        np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
+
+
 def test_lock_step_batch_with_regularization(hip, oracle):
     """lexls_lsi_batch_solve_ex: the damped hierarchies of a batch run lock-step on the generic kernel; every instance ends exactly where
     its stand-alone oracle-backed solve with the same regularization ends."""
