@@ -1,7 +1,9 @@
 // Cycling detection for the active-set driver (host side; off by default, typedefs.h:277).
-// Behaviour restated from the reference include/lexls/cycling.h:32-65: an ADD that immediately
-// follows a REMOVE of the very same (objective, constraint, type) is a cycle; the bound that was
-// just re-activated is relaxed by relax_step, at most max_counter times.
+//
+// Behaviour of the reference's include/lexls/cycling.h:32-65, restated: the driver reports every working-set change; when a
+// constraint is ADDED right after the very same (objective, constraint, type) was REMOVED, the driver is going round in a
+// circle.  The answer is to relax the bound that was just re-activated by `relax_step` (Objective::relax_bounds) and to count
+// the event; after `max_counter` relaxations the solve ends with PROBLEM_SOLVED_CYCLING_HANDLING.
 #pragma once
 
 #include <lexls/objective.h>
@@ -13,43 +15,53 @@ namespace LexLS
         class CyclingHandler
         {
         public:
-            CyclingHandler() : counter(0), max_counter(50), relax_step(1e-08), previous_operation(OPERATION_UNDEFINED)
-            {
-                previous_ctr_identifier.set(0, 0, CTR_INACTIVE);
-            }
+            CyclingHandler() : relaxations_done(0), relaxations_allowed(50), step(1e-08) { forget(); }
 
             void reset()
             {
-                counter            = 0;
-                previous_operation = OPERATION_UNDEFINED;
-                previous_ctr_identifier.set(0, 0, CTR_INACTIVE);
+                relaxations_done = 0;
+                forget();
             }
 
-            TerminationStatus update(OperationType operation, ConstraintIdentifier ctr_identifier, std::vector<Objective> &Obj, bool &cycling_detected)
+            /// one working-set change; `cycling_detected` tells whether it closed a REMOVE -> ADD circle (and a bound was relaxed)
+            TerminationStatus update(OperationType operation, ConstraintIdentifier what, std::vector<Objective> &objectives, bool &cycling_detected)
             {
-                cycling_detected = false;
-                if (operation == OPERATION_ADD && previous_operation == OPERATION_REMOVE && ctr_identifier == previous_ctr_identifier)
+                const bool circle = last.valid && operation == OPERATION_ADD && last.operation == OPERATION_REMOVE && what == last.what;
+                cycling_detected  = false;
+                if (circle && relaxations_done >= relaxations_allowed) return PROBLEM_SOLVED_CYCLING_HANDLING; // (the event is not recorded)
+                if (circle)
                 {
-                    if (counter >= max_counter) return PROBLEM_SOLVED_CYCLING_HANDLING;
-                    Obj[previous_ctr_identifier.obj_index].relax_bounds(previous_ctr_identifier.ctr_index, previous_ctr_identifier.ctr_type, relax_step);
-                    counter++;
+                    objectives[last.what.obj_index].relax_bounds(last.what.ctr_index, last.what.ctr_type, step);
+                    relaxations_done++;
                     cycling_detected = true;
                 }
-                previous_operation      = operation;
-                previous_ctr_identifier = ctr_identifier;
+                last.valid     = true;
+                last.operation = operation;
+                last.what      = what;
                 return TERMINATION_STATUS_UNKNOWN;
             }
 
-            void set_max_counter(Index m) { max_counter = m; }
-            void set_relax_step(RealScalar s) { relax_step = s; }
-            Index get_counter() const { return counter; }
+            void set_max_counter(Index m) { relaxations_allowed = m; }
+            void set_relax_step(RealScalar s) { step = s; }
+            Index get_counter() const { return relaxations_done; }
 
         private:
-            Index counter;
-            Index max_counter;
-            RealScalar relax_step;
-            OperationType previous_operation;
-            ConstraintIdentifier previous_ctr_identifier;
+            struct Event
+            {
+                bool valid;
+                OperationType operation;
+                ConstraintIdentifier what;
+            };
+            void forget()
+            {
+                last.valid     = false;
+                last.operation = OPERATION_UNDEFINED;
+                last.what.set(0, 0, CTR_INACTIVE);
+            }
+
+            Index relaxations_done, relaxations_allowed;
+            RealScalar step;
+            Event last;
         };
     } // namespace internal
 } // namespace LexLS
