@@ -219,7 +219,7 @@ int lexls_lsi_batch_solve_ex(int device, uint32_t batch, uint32_t nVar, uint32_t
 typedef struct lexls_lsi_batch_s *lexls_lsi_batch_t;
 int lexls_lsi_batch_create(lexls_lsi_batch_t *out, int device, uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types);
 int lexls_lsi_batch_run(lexls_lsi_batch_t b, const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
-                        const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
+                        const double *h_v0 /* batch x sum(dims) initial residuals (set_v0, lexlsi.cpp:571-588) or NULL */, const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
                         double *h_v, int32_t *h_rounds2);
 /* of the last lexls_lsi_batch_run: {factorize+solve stages, sensitivity stages, stages whose iteration step ran on the device, groups}.
  * The step of an iteration (A*dx, ratio test, update of x / v / A*x: lexlsi.h:987-1029, :1234-1240) runs on the device

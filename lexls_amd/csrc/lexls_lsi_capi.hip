@@ -883,8 +883,8 @@ struct lexls_lsi_batch_s
         t_create = BatchCtx::now() - t_begin;
     }
 
-    void run(const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_reg_factors,
-             const ParametersLexLSI &par, double *h_x, int32_t *h_info6, uint8_t *h_active, double *h_v, int32_t *h_rounds2)
+    void run(const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_v0,
+             const double *h_reg_factors, const ParametersLexLSI &par, double *h_x, int32_t *h_info6, uint8_t *h_active, double *h_v, int32_t *h_rounds2)
     {
         if (par.deactivate_first_wrong_sign) throw Exception("lexls_lsi_batch_solve: deactivate_first_wrong_sign has no device path");
         if (!h_data || !h_x) throw Exception("lexls_lsi_batch_run: null data / x");
@@ -937,7 +937,7 @@ struct lexls_lsi_batch_s
                        h_var_index ? h_var_index + (size_t)b * h_dims[0] : NULL,
                        h_active_guess ? h_active_guess + (size_t)b * total : NULL,
                        h_x0 ? h_x0 + (size_t)b * nVar : NULL,
-                       NULL,
+                       h_v0 ? h_v0 + (size_t)b * total : NULL,
                        h_reg_factors};
             runner::setup(*lsi[b], prob[b], par);
             if (run_step)
@@ -1105,14 +1105,14 @@ extern "C"
     }
 
     int lexls_lsi_batch_run(lexls_lsi_batch_t b, const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
-                            const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
+                            const double *h_v0, const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
                             double *h_v, int32_t *h_rounds2)
     {
         try
         {
             if (!b) throw Exception("lexls_lsi_batch_run: null handle");
             if (h_params && nparams != 9 && nparams != 12) throw Exception("lexls_lsi_batch_solve_ex: 9 or 12 parameters expected");
-            b->run(h_data, h_var_index, h_active_guess, h_x0, h_reg_factors, unpack(h_params, nparams), h_x, h_info6, h_active, h_v, h_rounds2);
+            b->run(h_data, h_var_index, h_active_guess, h_x0, h_v0, h_reg_factors, unpack(h_params, nparams), h_x, h_info6, h_active, h_v, h_rounds2);
             return LEXLS_OK;
         }
         catch (const std::exception &e)
@@ -1129,7 +1129,7 @@ extern "C"
     {
         lexls_lsi_batch_t b = NULL;
         int rc              = lexls_lsi_batch_create(&b, device, batch, nVar, nObj, h_dims, h_types);
-        if (rc == LEXLS_OK) rc = lexls_lsi_batch_run(b, h_data, h_var_index, h_active_guess, h_x0, h_reg_factors, h_params, nparams, h_x, h_info6, h_active, h_v, h_rounds2);
+        if (rc == LEXLS_OK) rc = lexls_lsi_batch_run(b, h_data, h_var_index, h_active_guess, h_x0, NULL, h_reg_factors, h_params, nparams, h_x, h_info6, h_active, h_v, h_rounds2);
         lexls_lsi_batch_destroy(b);
         return rc;
     }

@@ -146,7 +146,7 @@ class LsiBatch:
         capi.check(capi.lib().lexls_lsi_batch_stats(self._h, _p(st, C.c_int32)))
         return dict(factorize_solve=int(st[0]), sensitivity=int(st[1]), device_step=int(st[2]), groups=int(st[3]))
 
-    def run(self, problems, active_guess=None, x0=None, regularization_factors=None, **params):
+    def run(self, problems, active_guess=None, x0=None, regularization_factors=None, v0=None, **params):
         """`problems`: list of objective lists or a PackedBatch of this batch's structure; other arguments as lsi_batch_solve"""
         pk = problems if isinstance(problems, PackedBatch) else pack_batch(self.nvar, problems)
         if pk.batch != self.batch or not np.array_equal(pk.dims, self.dims) or not np.array_equal(pk.types, self.types):
@@ -158,6 +158,7 @@ class LsiBatch:
         elif active_guess is not None:
             guess = np.ascontiguousarray(np.stack([np.concatenate([np.asarray(g, np.uint8) for g in ag]) for ag in active_guess]))
         x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
+        v0a = None if v0 is None else np.ascontiguousarray(np.asarray(v0, np.float64).reshape(batch, total))  # initial residuals, (batch, sum(dims))
         x, info = np.zeros((batch, nvar)), np.zeros((batch, 6), np.int32)
         active, v, rounds = np.zeros((batch, total), np.uint8), np.zeros((batch, total)), np.zeros(2, np.int32)
         if regularization_factors is not None or any(k in REG_PARAM_KEYS for k in params):
@@ -166,7 +167,7 @@ class LsiBatch:
             par = pack_params(**params)
         rfa = None if regularization_factors is None else np.ascontiguousarray(regularization_factors, np.float64)
         capi.check(capi.lib().lexls_lsi_batch_run(
-            self._h, _p(pk.data, C.c_double), _p(pk.var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(rfa, C.c_double),
+            self._h, _p(pk.data, C.c_double), _p(pk.var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(v0a, C.c_double), _p(rfa, C.c_double),
             _p(par, C.c_double), C.c_uint32(len(par)), _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8), _p(v, C.c_double),
             _p(rounds, C.c_int32)))
         return dict(x=x, info=[dict(zip(INFO_KEYS, row.tolist())) for row in info], active=active, v=v,

@@ -174,6 +174,23 @@ def test_lsi_initial_residuals_v0(hip, oracle):
     np.testing.assert_array_equal(d["x"], o["x"])
 
 
+def test_lock_step_batch_with_initial_residuals_v0(hip, oracle):
+    """lexls_lsi_batch_run takes the initial residuals the MEX front end passes to set_v0 (lexlsi.cpp:571-588), one block per instance"""
+    n, dims, batch = 16, [5, 4, 6, 5], 6
+    problems = [P.lsi_problem(1900 + b, n, dims) for b in range(batch)]
+    base = [oracle.lsi_run(n, p) for p in problems]
+    v0 = np.stack([0.5 * np.concatenate(o["v"]) for o in base])
+    x0 = np.stack([0.5 * o["x"] for o in base])
+    pk = lexlsi.pack_batch(n, problems)
+    srv = lexlsi.LsiBatch(n, pk.dims, pk.types, batch)
+    r = srv.run(pk, x0=x0, v0=v0)
+    srv.close()
+    for b in range(batch):
+        o = oracle.lsi_run(n, problems[b], x0=x0[b], v0=np.split(v0[b], np.cumsum(dims)[:-1]))
+        assert r["info"][b] == o["info"], b
+        np.testing.assert_array_equal(r["x"][b], o["x"])
+
+
 def test_matlab_style_front_end(hip, oracle):
     """lexls_amd.frontend mirrors the MEX call shapes lexlse(obj, options) / lexlsi(obj, options, active_set, x0, v0)."""
     from lexls_amd import frontend
