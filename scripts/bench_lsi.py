@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""configs[4] only: lock-step batch of LexLSI problems (n = 40, 5 levels x 12 rows, level 0 simple bounds) on ONE batch object —
+cold start, warm start from the 5 %-perturbed neighbour, warm start tuned to ~30 iterations (perturbation 0.9).
+  python scripts/bench_lsi.py [batch]      (under rocprofv3: `-- python3 scripts/bench_lsi.py 1024`)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lexls_amd import lexlsi, problems as P  # noqa: E402
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n, dims = 40, [12] * 5
+base = lexlsi.pack_batch(n, [P.lsi_problem(20260500 + b, n, dims) for b in range(batch)])
+pert = lexlsi.pack_batch(n, [P.lsi_problem(20260500 + b, n, dims, perturb=0.05) for b in range(batch)])
+pert30 = lexlsi.pack_batch(n, [P.lsi_problem(20260500 + b, n, dims, perturb=0.9) for b in range(batch)])
+srv = lexlsi.LsiBatch(n, base.dims, base.types, batch)
+cold = srv.run(base)  # warm-up of the library and the first launches; also the warm starts' neighbour
+guess = np.where(cold["active"] == 3, 0, cold["active"]).astype(np.uint8)
+out = dict(batch=batch)
+for name, pk, kw in (("cold", base, {}), ("warm", pert, dict(active_guess=guess, x0=cold["x"])), ("warm_30", pert30, dict(active_guess=guess, x0=cold["x"]))):
+    t0 = time.perf_counter()
+    r = srv.run(pk, **kw)
+    dt = time.perf_counter() - t0
+    f = np.array([i["factorizations"] for i in r["info"]])
+    out[name] = dict(seconds=dt, mean_factorizations=float(f.mean()), max=int(f.max()), factorizations_per_s=float(f.sum() / dt),
+                     solved=int(sum(i["status"] == 0 for i in r["info"])), stages=srv.stats())
+srv.close()
+print(json.dumps(out))
