@@ -38,6 +38,13 @@ namespace LexLS
 
             /// which GPU later resize() calls allocate on (default 0)
             void setDevice(int device_) { device = device_; }
+            /// ObjectiveSensitivity(level) goes on through the following levels until one reports a wrong-sign multiplier (one device call
+            /// for the removal search of lexlsi.h:1121-1132); the caller then treats "not found" as final (LexLSI_T::setSensitivityScansAllLevels)
+            void setSensitivityScan(bool on)
+            {
+                sens_scan = on;
+                if (h) check(lexls_lse_set_sensitivity_scan(h, on ? 1 : 0));
+            }
 
             /// lexlse.h:67-103
             void resize(Index nVar_, Index nObj_, Index *maxObjDim)
@@ -64,6 +71,7 @@ namespace LexLS
                 fixed_type.assign(nVar, static_cast<uint8_t>(CTR_ACTIVE_UB));
                 nCtr = TotalRank = 0;
                 check(lexls_lse_set_tolerance(h, parameters.tol_linear_dependence));
+                check(lexls_lse_set_sensitivity_scan(h, sens_scan ? 1 : 0));
             }
 
             /// lexlse.h:1426-1442 (incl. initialize(), :1672-1693)
@@ -317,6 +325,7 @@ namespace LexLS
             Index nVar, nObj, nCtr, cap, nVarFixed, nVarFixedInit, TotalRank;
             int device;
             bool factor_on_host = false;
+            bool sens_scan      = false;
             ParametersLexLSE parameters;
             std::vector<Index> dims, first_row, rank, first_col, fixed_idx;
             std::vector<double> fixed_val, reg_factor;

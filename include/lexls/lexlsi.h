@@ -228,6 +228,7 @@ namespace LexLS
                     lexlse.factorize();
                 }
 
+                OneLevelPerCall one_level(lexlse, sens_scans_all);
                 dMatrixType L_active(nActiveCtr, nObj);
                 Index nMeaningful = lexlse.getFixedVariablesCount();
                 Index CtrIndex2Remove;
@@ -457,7 +458,34 @@ namespace LexLS
                 /// result of checkBlockingConstraints (lexlsi.h:1006-1029) for the iteration whose equality problem was just solved
                 virtual bool blocking(Index &ObjIndex, Index &CtrIndex, ConstraintActivationType &CtrType, RealScalar &alpha) = 0;
             };
+            /// an equality solver that can scan several levels per call (setSensitivityScan) is told to do one level per call while
+            /// the multipliers of every single level are wanted
+            struct OneLevelPerCall
+            {
+                template <class L>
+                static auto set(L &l, bool on, int) -> decltype(l.setSensitivityScan(on), void())
+                {
+                    l.setSensitivityScan(on);
+                }
+                template <class L>
+                static void set(L &, bool, ...)
+                {
+                }
+                OneLevelPerCall(LSE &l, bool active_) : lse(l), active(active_)
+                {
+                    if (active) set(lse, false, 0);
+                }
+                ~OneLevelPerCall()
+                {
+                    if (active) set(lse, true, 0);
+                }
+                LSE &lse;
+                bool active;
+            };
             void setStepHook(StepHook *hook) { step_hook = hook; }
+            /// the equality solver's ObjectiveSensitivity(level) goes on through the following levels by itself until one reports a
+            /// wrong-sign multiplier (a backend that serves the removal search of lexlsi.h:1121-1132 in one call): "not found" is then final
+            void setSensitivityScansAllLevels(bool on) { sens_scans_all = on; }
 
             enum DeviceNeed
             {
@@ -539,7 +567,7 @@ namespace LexLS
                         deactivate(o, CtrIndex2Remove);
                         iteration_finish();
                     }
-                    else if (sens_level + 1 < nObj - nObjOffset)
+                    else if (!sens_scans_all && sens_level + 1 < nObj - nObjOffset)
                     {
                         sens_level++;
                         pending = NEED_SENSITIVITY;
@@ -688,6 +716,7 @@ namespace LexLS
             bool it_normal      = true;
             bool it_hooked      = false; // this iteration's step is formed and applied by step_hook
             StepHook *step_hook = NULL;
+            bool sens_scans_all = false;
 
             /// lexlsi.h:758-793
             void hot_start_related_tests()
@@ -758,6 +787,7 @@ namespace LexLS
             /// lexlsi.h:1063-1105
             bool findActiveCtr2Remove_first(Index &ObjIndex2Remove, Index &CtrIndex2Remove, RealScalar &lambda_wrong_sign)
             {
+                OneLevelPerCall one_level(lexlse, sens_scans_all);
                 std::vector<ConstraintInfo> ctr_wrong_sign;
                 lambda_wrong_sign = 0;
                 bool found        = false;
@@ -794,7 +824,7 @@ namespace LexLS
                 {
                     found = lexlse.ObjectiveSensitivity(k, CtrIndex2Remove, ObjIndex2Remove_int, parameters.tol_wrong_sign_lambda,
                                                         parameters.tol_correct_sign_lambda, lambda_wrong_sign);
-                    if (found) break;
+                    if (found || sens_scans_all) break; // (sens_scans_all: the call above went through the remaining levels itself)
                 }
                 ObjIndex2Remove = static_cast<Index>(ObjIndex2Remove_int + static_cast<int>(nObjOffset));
                 return found;

@@ -154,6 +154,10 @@ int lexls_lse_residual(lexls_lse_t h);
  * h_obj_index: one level per problem (batch values; a negative value skips that problem), or NULL
  * with `obj_index_all` applied to every problem.  Results: lexls_lse_get_sensitivity. */
 int lexls_lse_sensitivity(lexls_lse_t h, const int32_t *h_obj_index, int32_t obj_index_all, double tol_wrong_sign_lambda, double tol_correct_sign_lambda);
+/* While on, lexls_lse_sensitivity(_resident) does what LexLSI's removal search does with one call per level (lexlsi.h:1121-1132): starting
+ * at the given level it goes on to the next ones until a level reports a wrong-sign multiplier or the last level is done — one launch; the
+ * outputs are those of the level it stopped at.  Off by default (= the reference's one-level call). */
+int lexls_lse_set_sensitivity_scan(lexls_lse_t h, int on);
 /* same, with the per-problem objective indices already on the device (the obj_index array of lexls_lse_upload_round) */
 int lexls_lse_sensitivity_resident(lexls_lse_t h, double tol_wrong_sign_lambda, double tol_correct_sign_lambda);
 

@@ -67,6 +67,7 @@ struct lexls_lse_s
     uint32_t reg_cg_iters;
     double reg_variable;
     double *d_reg_factor, *d_reg_scratch;
+    bool sens_scan; // lexls_lse_set_sensitivity_scan
     char *d_round_in, *d_round_out; // the per-round arrays live in two slabs (lexls_lse_round_layout): one copy each way per round
     lexls_round_layout lay;
 
@@ -707,7 +708,14 @@ extern "C"
         {
             return fail(LEXLS_ERR_INVALID, "ObjIndex >= nObj");
         }
-        HIP_TRY(launch_sensitivity(h->args(), d_obj, obj_index_all, tolW, tolC, h->stream));
+        HIP_TRY(launch_sensitivity(h->args(), d_obj, obj_index_all, tolW, tolC, h->stream, h->sens_scan));
+        return LEXLS_OK;
+    }
+
+    int lexls_lse_set_sensitivity_scan(lexls_lse_t h, int on)
+    {
+        CHECK_HANDLE(h);
+        h->sens_scan = on != 0;
         return LEXLS_OK;
     }
 
@@ -715,7 +723,7 @@ extern "C"
     {
         if (int rc = need_factor(h, "lexls_lse_sensitivity_resident")) return rc;
         HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(launch_sensitivity(h->args(), h->d_objidx, 0, tolW, tolC, h->stream));
+        HIP_TRY(launch_sensitivity(h->args(), h->d_objidx, 0, tolW, tolC, h->stream, h->sens_scan));
         return LEXLS_OK;
     }
 

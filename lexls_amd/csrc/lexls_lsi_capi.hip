@@ -852,6 +852,7 @@ struct lexls_lsi_batch_s
             BatchCtx &ctx = *grp[g];
             ctx.create(device, lo[g + 1] - lo[g], nVar, nObj - off, h_dims + off, gather);
             hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between stages
+            hip_check(lexls_lse_set_sensitivity_scan(ctx.h, 1)); // the removal search of an iteration in ONE sensitivity stage (all its levels)
         }
         // the step of an iteration can run on the device when the constraint data is resident
         StepShape sh;
@@ -940,6 +941,7 @@ struct lexls_lsi_batch_s
                        h_v0 ? h_v0 + (size_t)b * total : NULL,
                        h_reg_factors};
             runner::setup(*lsi[b], prob[b], par);
+            lsi[b]->setSensitivityScansAllLevels(true);
             if (run_step)
             {
                 hooks[b].c = grp[g].get();
@@ -1143,6 +1145,8 @@ extern "C"
             runner::LsiProblem p = {nVar, nObj, h_dims, h_types, h_data, h_var_index, h_active_guess, h_x0};
             internal::LexLSI lsi;
             lsi.getLexLSE().setDevice(device);
+            lsi.getLexLSE().setSensitivityScan(true); // the removal search of an iteration in one device call
+            lsi.setSensitivityScansAllLevels(true);
             runner::setup(lsi, p, unpack(h_params9));
             lsi.solve();
             runner::LsiInfo info;
@@ -1168,6 +1172,8 @@ extern "C"
             runner::LsiProblem p = {nVar, nObj, h_dims, h_types, h_data, h_var_index, h_active_guess, h_x0, h_v0, h_reg_factors};
             internal::LexLSI lsi;
             lsi.getLexLSE().setDevice(device);
+            lsi.getLexLSE().setSensitivityScan(true); // the removal search of an iteration in one device call
+            lsi.setSensitivityScansAllLevels(true);
             runner::setup(lsi, p, unpack(h_params, nparams));
             lsi.solve();
             runner::LsiInfo info;
@@ -1193,6 +1199,8 @@ extern "C"
             runner::flatten(h, one_based != 0, use_active_guess != 0, use_x_guess != 0, f);
             internal::LexLSI lsi;
             lsi.getLexLSE().setDevice(device);
+            lsi.getLexLSE().setSensitivityScan(true); // the removal search of an iteration in one device call
+            lsi.setSensitivityScansAllLevels(true);
             runner::setup(lsi, f.problem, ParametersLexLSI());
             lsi.solve();
             runner::LsiInfo info;

@@ -561,7 +561,7 @@ namespace lexls
         }
 
         template <int NT>
-        __global__ __launch_bounds__(NT) void sensitivity_kernel(LseArgs a, const int32_t *obj_index, int32_t obj_all, double tolW, double tolC)
+        __global__ __launch_bounds__(NT) void sensitivity_kernel(LseArgs a, const int32_t *obj_index, int32_t obj_all, double tolW, double tolC, int scan_up)
         {
             extern __shared__ double smem[];
             const uint32_t b = blockIdx.x, tid = threadIdx.x;
@@ -579,7 +579,10 @@ namespace lexls
                 }
                 return;
             }
-            const uint32_t ObjIndex = (uint32_t)oi;
+            // scan_up: what LexLSI's removal search does with one call per level (lexlsi.h:1121-1132) — levels oi, oi+1, ... until one
+            // reports a wrong-sign multiplier or the last one is done — in ONE launch; the marks of a level are in place before the next
+            for (uint32_t ObjIndex = (uint32_t)oi;; ObjIndex++)
+            {
             const double *W  = a.fac + (size_t)b * cap * (n + 1);
             const size_t ld  = cap;
             const double *hh = a.hh + (size_t)b * cap;
@@ -676,6 +679,10 @@ namespace lexls
                 sens[1]     = st->found ? (int32_t)st->ctr : -1;
                 sens[2]     = st->found ? st->obj : -2;
                 a.maxabs[b] = st->maxabs;
+            }
+            const int found = st->found; // (LDS, written before the last barrier)
+            if (!scan_up || found || ObjIndex + 1 >= nObj) break;
+            __syncthreads(); // the next level re-initialises the LDS arrays; its find_descent sees this level's marks (same thread)
             }
         }
 
@@ -1205,13 +1212,13 @@ namespace lexls
         return hipGetLastError();
     }
 
-    hipError_t launch_sensitivity(const LseArgs &a, const int32_t *d_obj_index, int32_t obj_all, double tolW, double tolC, hipStream_t s)
+    hipError_t launch_sensitivity(const LseArgs &a, const int32_t *d_obj_index, int32_t obj_all, double tolW, double tolC, hipStream_t s, bool scan_up)
     {
         const size_t lds = 8 * (2 * (size_t)a.nVar + a.cap + 2) + sizeof(SensState) + 16;
         if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
         hipError_t e = set_lds(sensitivity_kernel<64>, lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((sensitivity_kernel<64>), dim3(a.batch), dim3(64), lds, s, a, d_obj_index, obj_all, tolW, tolC);
+        hipLaunchKernelGGL((sensitivity_kernel<64>), dim3(a.batch), dim3(64), lds, s, a, d_obj_index, obj_all, tolW, tolC, scan_up ? 1 : 0);
         return hipGetLastError();
     }
 

@@ -165,6 +165,11 @@ class BatchedLexLSE:
         """lexlse.h:1138-1213: least-norm solution through the normal equations of the free variables"""
         capi.check(capi.lib().lexls_lse_solve_least_norm_2(self._h))
 
+    def setSensitivityScan(self, on: bool):
+        """while on, ObjectiveSensitivity(level) goes on through the following levels until one reports a wrong-sign multiplier or the last
+        level is done (LexLSI's removal search, lexlsi.h:1121-1132, in one launch); outputs are those of the level it stopped at"""
+        capi.check(capi.lib().lexls_lse_set_sensitivity_scan(self._h, C.c_int(1 if on else 0)))
+
     def ObjectiveSensitivity(self, ObjIndex, tol_wrong_sign_lambda=1e-8, tol_correct_sign_lambda=1e-12):
         """ObjIndex: int (all problems) or per-problem int32 array (negative = skip). Returns (found, ctr, obj, maxAbs)."""
         if np.isscalar(ObjIndex):

@@ -245,6 +245,42 @@ def test_objective_sensitivity(hip, oracle, level):
     np.testing.assert_array_equal(s.getCtrType(), ref["ctr_type_out"])
 
 
+@pytest.mark.parametrize("start", [0, 1])
+def test_sensitivity_scan_equals_level_by_level_calls(hip, oracle, start):
+    """lexls_lse_set_sensitivity_scan: one launch does what LexLSI's removal search does with one ObjectiveSensitivity call per level
+    (lexlsi.h:1121-1132) — stop at the first level that reports a wrong-sign multiplier, carry the CORRECT_SIGN marks along."""
+    n, dims, batch = 15, [5, 5, 5, 5], 16
+    lod = np.stack([P.rank_deficient_problem(900 + b, n, dims, [3, 4, 3, 2]) for b in range(batch)])
+    types = np.zeros((batch, 20), np.uint8)
+    for b in range(batch):
+        types[b] = 1 + (P.uniform(950 + b, 20) * 3).astype(np.uint8)  # LB / UB / EQ
+        if b % 3 == 0:
+            types[b, :10] = 3  # equalities on the first levels: the search has to go further up
+    # reference: the level loop of the driver, problem by problem (each one stops at its own level)
+    sens = np.zeros((batch, 3), np.int32)
+    maxabs, lam, marks = np.zeros(batch), np.zeros((batch, n + 20)), types.copy()
+    stopped = np.zeros(batch, int)
+    for b in range(batch):
+        cur = types[b:b + 1].copy()
+        for level in range(start, len(dims)):
+            ref = oracle.lse_run(lod[b:b + 1], dims, n, ctr_type=cur, sens_obj=level)
+            cur = ref["ctr_type_out"]
+            if ref["sens"][0, 0] or level == len(dims) - 1:
+                sens[b], maxabs[b], lam[b], marks[b], stopped[b] = ref["sens"][0], ref["maxabs"][0], ref["lam"][0], cur[0], level
+                break
+    assert len(set(stopped.tolist())) > 1  # the batch really stops at different levels
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.setProblem(lod)
+    s.setCtrType(types)
+    s.factorize_solve()
+    s.setSensitivityScan(True)
+    found, ctr, obj, mx = s.ObjectiveSensitivity(start)
+    np.testing.assert_array_equal(np.stack([found.astype(np.int32), ctr, obj], 1), sens)
+    np.testing.assert_array_equal(mx, maxabs)
+    np.testing.assert_array_equal(s.getWorkspace(), lam)
+    np.testing.assert_array_equal(s.getCtrType(), marks)
+
+
 def test_sensitivity_with_fixed_variables(hip, oracle):
     n, dims, batch = 12, [4, 4, 6], 6
     lod = P.lse_batch(51, batch, n, dims)
