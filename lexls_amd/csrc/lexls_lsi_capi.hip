@@ -297,11 +297,11 @@ namespace
         std::vector<uint32_t> maxdim, rank, totalrank;
         std::vector<double> x;
         lexls_round_layout lay;
-        Pinned<char> in_block, out_block, types_block; // pinned mirrors of the handle's round slabs: ONE copy each per stage
+        Pinned<char> in_block, out_block; // pinned mirrors of the handle's round slabs: ONE copy each per stage
         View<uint32_t> dims, nfixed, fixed_idx, row_src, row_ld, tr_dl; // row_src/row_ld: B x cap, where each LOD row comes from (device gather)
         View<double> fixed_val, maxabs, x_dl;
         double *lod = NULL; // B x cap x (n+1), PINNED: host-staging fallback, uploaded every active-set round
-        View<uint8_t> fixed_type, ctr_type, skip, ctr_dl, fixed_dl;
+        View<uint8_t> fixed_type, ctr_type, skip;
         View<int32_t> sens, objidx;
         std::vector<double> reg_factor;        // B x nObjL regularization factors (host copy; uploaded when they change)
         int reg_type = 0;                      // LexLS::RegularizationType shared by the batch
@@ -321,6 +321,7 @@ namespace
         std::vector<uint8_t> on_device;            // per instance: x / v / A x live on the device
         std::atomic<bool> handover{false};         // some instance put its state into state_host for the next stage
         bool stage_step = false;
+        bool spec_sens  = false; // every factorization is followed by its removal search in the same stage (results used if the step is not blocked)
         int rounds_fs = 0, rounds_sens = 0, rounds_step = 0;
         double t_enqueue = 0, t_wait = 0; // seconds, reported when LEXLS_LSI_TIMING is set
         static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -343,7 +344,6 @@ namespace
             hip_check(lexls_lse_round_layout(h, &lay));
             in_block.assign(lay.in_bytes, 0);
             out_block.assign(lay.out_bytes, 0);
-            types_block.assign(lay.in_bytes - lay.fixed_type, 0);
             if (!gather) need_staging();
             reset();
         }
@@ -395,8 +395,6 @@ namespace
             tr_dl.bind(out_block.data(), lay.total_rank, B, 0);
             sens.bind(out_block.data(), lay.found, (size_t)B * 3, 0);
             maxabs.bind(out_block.data(), lay.max_abs, B, 0.0);
-            fixed_dl.bind(types_block.data(), 0, (size_t)B * n, 0);
-            ctr_dl.bind(types_block.data(), lay.ctr_type - lay.fixed_type, (size_t)B * cap, 0);
             if (lod) std::memset(lod, 0, 8 * (size_t)B * pstride);
             x.assign((size_t)B * n, 0.0);
             rank.assign((size_t)B * nObjL, 0);
@@ -477,7 +475,7 @@ namespace
             }
             if (serve_sens)
             {
-                if (serve_fs)
+                if (serve_fs && !spec_sens)
                 {
                     // disjoint instances (a problem is either re-factorised or asked for multipliers): the two kernels are both
                     // latency-bound at these batch sizes and share the chip — second stream, joined again before the download
@@ -488,26 +486,26 @@ namespace
                     if (hipEventRecord(ev_sens_done, stream_sens) != hipSuccess || hipStreamWaitEvent(stream, ev_sens_done, 0) != hipSuccess)
                         throw Exception("hipEventRecord / hipStreamWaitEvent failed");
                 }
+                else if (serve_fs)
+                    hip_check(lexls_lse_sensitivity_resident(h, tolW, tolC)); // behind the l-QR kernel: it reads the factors just made
                 else
                     hip_check(lexls_lse_sensitivity(h, objidx.data(), 0, tolW, tolC));
                 rounds_sens++;
             }
-            // x / total rank / sensitivity verdicts in one copy.  ObjectiveSensitivity marks constraints CORRECT_SIGN_OF_LAMBDA on the device
-            // (lexlse.h:866-987) and the marks must survive until the instance re-forms its problem: a later factorize stage uploads the
-            // host arrays for EVERY instance, also for the ones that are still in the middle of their sensitivity sequence — so the host
-            // copy takes the marks over (finish_stage) from the second copy
+            // x / total rank / sensitivity verdicts in one copy.  (The CORRECT_SIGN_OF_LAMBDA marks ObjectiveSensitivity leaves on the
+            // device, lexlse.h:866-987, only matter between the levels of ONE removal search — which is one launch here,
+            // lexls_lse_set_sensitivity_scan — so they never have to come back: the next equality problem sets every row's type anew.)
             if (x_needed || !serve_fs)
-                hip_check(lexls_lse_download_round(h, out_block.data(), serve_sens ? types_block.data() : NULL));
+                hip_check(lexls_lse_download_round(h, out_block.data(), NULL));
             else
             {
                 // every equality solve of this stage feeds a device-side step: x stays on the device, only the tail of the out slab
-                // (total ranks, sensitivity verdicts) and the marks come back
+                // (total ranks, sensitivity verdicts) comes back
                 void *d_out = NULL;
                 hip_check(lexls_lse_device_ptr(h, LEXLS_ARRAY_X, &d_out)); // x is the head of the out slab (lexls_lse_round_layout)
                 if (hipMemcpyAsync(out_block.data() + lay.total_rank, static_cast<char *>(d_out) + lay.total_rank, lay.out_bytes - lay.total_rank, hipMemcpyDeviceToHost,
                                    stream) != hipSuccess)
                     throw Exception("hipMemcpyAsync failed (results without x)");
-                if (serve_sens) hip_check(lexls_lse_download_round(h, NULL, types_block.data()));
             }
             t_enqueue += now() - t0;
         }
@@ -523,11 +521,6 @@ namespace
         {
             std::copy(x_dl.begin() + (size_t)b * n, x_dl.begin() + (size_t)(b + 1) * n, x.begin() + (size_t)b * n);
             totalrank[b] = tr_dl[b];
-        }
-        void take_marks(uint32_t b)
-        {
-            std::copy(ctr_dl.begin() + (size_t)b * cap, ctr_dl.begin() + (size_t)(b + 1) * cap, ctr_type.begin() + (size_t)b * cap);
-            std::copy(fixed_dl.begin() + (size_t)b * n, fixed_dl.begin() + (size_t)(b + 1) * n, fixed_type.begin() + (size_t)b * n);
         }
     };
 
@@ -853,6 +846,10 @@ struct lexls_lsi_batch_s
             ctx.create(device, lo[g + 1] - lo[g], nVar, nObj - off, h_dims + off, gather);
             hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between stages
             hip_check(lexls_lse_set_sensitivity_scan(ctx.h, 1)); // the removal search of an iteration in ONE sensitivity stage (all its levels)
+            // LEXLS_LSI_SPECULATIVE_SENS=1: the removal search runs speculatively behind every factorization (half the stages).  Measured
+            // on MI355X it loses — 1024 instances cold 0.057 s vs 0.050 s: the search is a 50-190 us chain that now lengthens EVERY stage,
+            // also those whose step turns out to be blocked — so it is off by default.
+            if (const char *e = std::getenv("LEXLS_LSI_SPECULATIVE_SENS")) ctx.spec_sens = std::atoi(e) != 0;
         }
         // the step of an iteration can run on the device when the constraint data is resident
         StepShape sh;
@@ -964,18 +961,20 @@ struct lexls_lsi_batch_s
             const double t0 = BatchCtx::now();
             pool.run(lo[g + 1] - lo[g], [&](uint32_t k) {
                 SlotLSI &inst        = *lsi[lo[g] + k];
-                const bool served_fs = ctx.stage_fs && !ctx.skip[k], served_sens = ctx.stage_sens && ctx.objidx[k] >= 0;
+                const bool served_fs = ctx.stage_fs && !ctx.skip[k], served_sens = ctx.stage_sens && ctx.skip[k] && ctx.objidx[k] >= 0;
+                const bool has_spec  = served_fs && ctx.stage_sens && ctx.objidx[k] == 0; // its removal search ran right behind its l-QR
                 if (run_step) ctx.mode()[k] = 0; // (the hook raises it again when the instance posts an iteration's equality problem)
                 if (served_fs) ctx.take_solution(k);
-                if (served_sens) ctx.take_marks(k);
                 if (served_fs || served_sens) inst.advance();
+                if (has_spec && !inst.finished() && inst.need() == SlotLSI::NEED_SENSITIVITY && inst.needLevel() == 0) inst.advance(); // step not blocked: use it
                 const bool alive = !inst.finished();
                 const bool fs    = alive && inst.need() == SlotLSI::NEED_FACTORIZE_SOLVE;
                 const bool se    = alive && inst.need() == SlotLSI::NEED_SENSITIVITY;
+                const bool spec  = fs && ctx.spec_sens;
                 ctx.skip[k]      = fs ? 0 : 1;
-                ctx.objidx[k]    = se ? static_cast<int32_t>(inst.needLevel()) : -1;
+                ctx.objidx[k]    = se ? static_cast<int32_t>(inst.needLevel()) : (spec ? 0 : -1);
                 const bool dstep = run_step && fs && ctx.mode()[k] != 0;
-                const uint32_t w = (alive ? 1u : 0u) | (fs ? 2u : 0u) | (se ? 4u : 0u) | (dstep ? 8u : 0u) | ((fs && !dstep) ? 16u : 0u);
+                const uint32_t w = (alive ? 1u : 0u) | (fs ? 2u : 0u) | ((se || spec) ? 4u : 0u) | (dstep ? 8u : 0u) | ((fs && !dstep) ? 16u : 0u);
                 if (w & ~wants[g].load(std::memory_order_relaxed)) wants[g].fetch_or(w, std::memory_order_relaxed);
             });
             t_host += BatchCtx::now() - t0;

@@ -354,6 +354,25 @@ def test_lock_step_groups_take_turns(hip, oracle, monkeypatch, groups):
         np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
 
 
+def test_speculative_removal_search(hip, oracle, monkeypatch):
+    """LEXLS_LSI_SPECULATIVE_SENS=1: every factorization of a lock-step batch is followed by its removal search in the same stage and the
+    result is used when the step turns out not to be blocked — half the stages, the same trajectories."""
+    n, dims, batch = 16, [5, 4, 6, 5], 12
+    problems = [P.lsi_problem(2100 + b, n, dims) for b in range(batch)]
+    plain = lexlsi.lsi_batch_solve(n, problems)
+    monkeypatch.setenv("LEXLS_LSI_SPECULATIVE_SENS", "1")
+    spec = lexlsi.lsi_batch_solve(n, problems)
+    assert spec["rounds"]["factorize_solve"] <= plain["rounds"]["factorize_solve"] and spec["rounds"]["sensitivity"] >= spec["rounds"]["factorize_solve"]
+    assert spec["info"] == plain["info"]
+    np.testing.assert_array_equal(spec["x"], plain["x"])
+    np.testing.assert_array_equal(spec["v"], plain["v"])
+    np.testing.assert_array_equal(spec["active"], plain["active"])
+    for b in range(0, batch, 5):
+        o = oracle.lsi_run(n, problems[b])
+        assert spec["info"][b] == o["info"]
+        np.testing.assert_array_equal(spec["x"][b], o["x"])
+
+
 def test_lock_step_batch_with_regularization(hip, oracle):
     """lexls_lsi_batch_solve_ex: the damped hierarchies of a batch run lock-step on the generic kernel; every instance ends exactly where
     its stand-alone oracle-backed solve with the same regularization ends."""
