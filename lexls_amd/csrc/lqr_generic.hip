@@ -527,6 +527,37 @@ namespace lexls
             for (uint32_t i = tid; i < cap; i += NT) a.v[(size_t)b * cap + i] = v[i];
         }
 
+        /// One coalesced pass over a problem's stored factor (cap x (nVar+1), column-major) into LDS, odd leading dimension so that
+        /// "thread = row" and "thread = column" walks are conflict-free.  For kernels that walk the factor along dependent chains
+        /// when latency, not occupancy, is what counts (few problems per CU; several levels per launch).
+        template <int NT>
+        __device__ __forceinline__ void stage_factor(const double *__restrict__ G, double *L, uint32_t cap, uint32_t ncol, uint32_t ldl, uint32_t tid)
+        {
+            constexpr uint32_t U = 8; // loads in flight per thread
+            const uint32_t total = cap * ncol;
+            for (uint32_t base = tid; base < total; base += NT * U)
+            {
+                double v[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++)
+                {
+                    const uint32_t e = base + u * NT;
+                    v[u]             = e < total ? G[e] : 0.0;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++)
+                {
+                    const uint32_t e = base + u * NT;
+                    if (e < total)
+                    {
+                        const uint32_t j = e / cap;
+                        L[(e - j * cap) + j * ldl] = v[u];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
         // -----------------------------------------------------------------------------------------
         // ObjectiveSensitivity (lexlse.h:611-762) + findDescentDirection (:935-987)
         // -----------------------------------------------------------------------------------------
@@ -560,7 +591,7 @@ namespace lexls
             }
         }
 
-        template <int NT>
+        template <int NT, bool STAGE>
         __global__ __launch_bounds__(NT) void sensitivity_kernel(LseArgs a, const int32_t *obj_index, int32_t obj_all, double tolW, double tolC, int scan_up)
         {
             extern __shared__ double smem[];
@@ -579,12 +610,22 @@ namespace lexls
                 }
                 return;
             }
+            const double *Wsrc = a.fac + (size_t)b * cap * (n + 1);
+            size_t ldsrc       = cap;
+            if (STAGE) // once per launch, shared by all the levels of a scan
+            {
+                // LDS: [LambdaFixed nVar | Lambda cap | rhs nVar | bcast | state | staged factor]
+                double *Wl = smem + 2 * n + cap + 1 + (sizeof(SensState) + 7) / 8;
+                stage_factor<NT>(Wsrc, Wl, cap, n + 1, cap | 1u, tid);
+                Wsrc  = Wl;
+                ldsrc = cap | 1u;
+            }
             // scan_up: what LexLSI's removal search does with one call per level (lexlsi.h:1121-1132) — levels oi, oi+1, ... until one
             // reports a wrong-sign multiplier or the last one is done — in ONE launch; the marks of a level are in place before the next
             for (uint32_t ObjIndex = (uint32_t)oi;; ObjIndex++)
             {
-            const double *W  = a.fac + (size_t)b * cap * (n + 1);
-            const size_t ld  = cap;
+            const double *W  = Wsrc;
+            const size_t ld  = ldsrc;
             const double *hh = a.hh + (size_t)b * cap;
             const uint32_t *dims = a.dims + (size_t)b * nObj;
             const uint32_t *rk = a.rank + (size_t)b * nObj, *fc = a.fcol + (size_t)b * nObj;
@@ -1216,9 +1257,23 @@ namespace lexls
     {
         const size_t lds = 8 * (2 * (size_t)a.nVar + a.cap + 2) + sizeof(SensState) + 16;
         if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
-        hipError_t e = set_lds(sensitivity_kernel<64>, lds);
+        // Factor staged into LDS when latency is what counts: few problems per CU (a lock-step LSI stage) — with thousands of problems
+        // the 20 KB per workgroup would cost the wavefronts in flight that hide the chains instead (4096 problems: 0.090 -> 0.126 ms)
+        const size_t lds_staged = lds + 8 * (size_t)(a.cap | 1u) * (a.nVar + 1);
+        static int cus          = 0;
+        if (!cus)
+        {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        }
+        if (lds_staged <= 40 * 1024 && a.batch <= 4u * (uint32_t)cus)
+        {
+            hipLaunchKernelGGL((sensitivity_kernel<64, true>), dim3(a.batch), dim3(64), lds_staged, s, a, d_obj_index, obj_all, tolW, tolC, scan_up ? 1 : 0);
+            return hipGetLastError();
+        }
+        hipError_t e = set_lds(sensitivity_kernel<64, false>, lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((sensitivity_kernel<64>), dim3(a.batch), dim3(64), lds, s, a, d_obj_index, obj_all, tolW, tolC, scan_up ? 1 : 0);
+        hipLaunchKernelGGL((sensitivity_kernel<64, false>), dim3(a.batch), dim3(64), lds, s, a, d_obj_index, obj_all, tolW, tolC, scan_up ? 1 : 0);
         return hipGetLastError();
     }
 
