@@ -47,6 +47,7 @@ struct lexls_lse_s
     double *d_norms;
     double tol;
     bool dims_set, has_fixed, factor_valid, factor_in_hbm;
+    uint64_t x_epoch, factor_epoch; // x_epoch == factor_epoch: d_x holds the basic solution of the current factor (lexls_lse_solve has nothing to do)
     const char *last_kernel;
 
     double *d_in_owned;
@@ -607,8 +608,11 @@ extern "C"
         return LEXLS_OK;
     }
 
-    static int run_lqr(lexls_lse_t h, bool write_factor, bool do_solve)
+    /// opportunistic_solve: the caller only asked for the factor; kernels that produce x on the way at no extra launch do (the wave kernels
+    /// always, the generic kernel on request), so that a later lexls_lse_solve of the same factor has nothing left to do
+    static int run_lqr(lexls_lse_t h, bool write_factor, bool do_solve, bool opportunistic_solve = false)
     {
+        bool solved = true;
         CHECK_HANDLE(h);
         if (!h->d_in) return fail(LEXLS_ERR_INVALID, "no problem data: call lexls_lse_set_problem_host/device first");
         HIP_TRY(hipSetDevice(h->device));
@@ -625,20 +629,24 @@ extern "C"
             if (!h->d_norms) HIP_TRY(hipMalloc((void **)&h->d_norms, 8 * (size_t)h->batch * h->nVar));
             HIP_TRY(launch_lqr_large(a, h->level_max.data(), h->max_rows, h->d_large_state, h->d_norms, h->stream));
             if (do_solve) HIP_TRY(launch_solve_generic(a, h->stream));
+            solved       = do_solve;
             variant      = "lqr_large<multi-launch>";
             write_factor = true;
         }
         else
         {
-            HIP_TRY(launch_lqr_generic(a, h->max_rows, write_factor, do_solve, h->stream, &variant));
+            solved = do_solve || opportunistic_solve;
+            HIP_TRY(launch_lqr_generic(a, h->max_rows, write_factor, solved, h->stream, &variant));
         }
         h->last_kernel   = variant;
         h->factor_valid  = true;
+        h->factor_epoch++;
+        if (solved) h->x_epoch = h->factor_epoch;
         h->factor_in_hbm = write_factor || std::strstr(variant, "hbm") != nullptr;
         return LEXLS_OK;
     }
 
-    int lexls_lse_factorize(lexls_lse_t h) { return run_lqr(h, true, false); }
+    int lexls_lse_factorize(lexls_lse_t h) { return run_lqr(h, true, false, true); }
     int lexls_lse_factorize_solve(lexls_lse_t h, int keep_factor) { return run_lqr(h, keep_factor != 0, true); }
 
     static int need_factor(lexls_lse_t h, const char *who)
@@ -651,8 +659,10 @@ extern "C"
     int lexls_lse_solve(lexls_lse_t h)
     {
         if (int rc = need_factor(h, "lexls_lse_solve")) return rc;
+        if (h->x_epoch == h->factor_epoch) return LEXLS_OK; // the factorization kernel left the basic solution in place
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(launch_solve_generic(h->args(), h->stream));
+        h->x_epoch = h->factor_epoch;
         return LEXLS_OK;
     }
 
@@ -662,6 +672,7 @@ extern "C"
         HIP_TRY(hipSetDevice(h->device));
         if (!h->d_scratch) HIP_TRY(hipMalloc((void **)&h->d_scratch, 8 * (size_t)h->batch * 2 * h->nVar * h->nVar));
         HIP_TRY(launch_leastnorm(h->args(), h->stream));
+        h->x_epoch = 0; // d_x now holds a least-norm solution
         return LEXLS_OK;
     }
 
@@ -671,6 +682,7 @@ extern "C"
         HIP_TRY(hipSetDevice(h->device));
         if (!h->d_scratch) HIP_TRY(hipMalloc((void **)&h->d_scratch, 8 * (size_t)h->batch * 2 * h->nVar * h->nVar));
         HIP_TRY(launch_leastnorm2(h->args(), h->stream));
+        h->x_epoch = 0; // d_x now holds a least-norm solution
         return LEXLS_OK;
     }
 
@@ -682,6 +694,7 @@ extern "C"
         HIP_TRY(hipSetDevice(h->device));
         if (!h->d_scratch) HIP_TRY(hipMalloc((void **)&h->d_scratch, 8 * (size_t)h->batch * 2 * h->nVar * h->nVar));
         HIP_TRY(launch_leastnorm3(h->args(), h->stream));
+        h->x_epoch = 0; // d_x now holds a least-norm solution
         return LEXLS_OK;
     }
 
