@@ -830,8 +830,8 @@ struct lexls_lsi_batch_s
         // The instances can be split into groups that take turns: while one group's stage runs on the GPU (its own stream), the host
         // advances the active-set logic of the other one.  Every stage carries fixed costs (one copy each way, launches, one
         // synchronisation) that a split multiplies, so it pays for large batches only.  Measured on MI355X, cold
-        // solve of n = 40, 5 x 12, seconds with 1 / 2 / 3 groups: 256 instances 0.044 / 0.047; 512: 0.050 / 0.043 / 0.056;
-        // 1024: 0.057 / 0.050 / 0.053.  LEXLS_LSI_GROUPS overrides the number.
+        // solve of n = 40, 5 x 12, seconds with 1 / 2 / 3 groups: 512 instances 0.034 / 0.030 / 0.040; 1024: 0.039 / 0.034 / 0.045
+        // (256 instances, an earlier state of the driver: 0.044 / 0.047).  LEXLS_LSI_GROUPS overrides the number.
         nGroups = batch >= 512 ? 2u : 1u;
         if (const char *e = std::getenv("LEXLS_LSI_GROUPS")) nGroups = std::max(1, std::atoi(e));
         nGroups = std::min(nGroups, batch);
