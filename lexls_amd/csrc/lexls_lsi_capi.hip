@@ -1058,6 +1058,7 @@ struct lexls_lsi_batch_s
             h_rounds2[1] = rounds_sens;
         }
         last_stats[0] = rounds_fs, last_stats[1] = rounds_sens, last_stats[2] = rounds_step, last_stats[3] = (int32_t)nGroups;
+        pool.run(batch, [&](uint32_t b) { lsi[b].reset(); }); // a thousand LexLSI objects (dozens of vectors each): freed in parallel, not serially on return
     }
 };
 
