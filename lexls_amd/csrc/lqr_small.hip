@@ -42,7 +42,7 @@ namespace lexls
         const uint32_t nc = a.nVar + 1;
         // left-looking form (lqr_lwave_impl.h): one level block live per wave, 4 waves/SIMD; no fixed variables.  Measured on MI355X
         // (scripts/latency_scan.py, n = 40, 5 x 12): while the batch fits one round of the register-resident kernel (<= 2048 problems)
-        // that kernel has the shorter latency (factor kept: 79-88 us vs 97-101 us; x only: equal); beyond that the left-looking kernel
+        // that kernel has the shorter latency (factor kept: 66-72 us vs 97-101 us; x only: equal); beyond that the left-looking kernel
         // still runs in one round (4096: 115 us vs 158 us).  left_looking: 0 = decide by batch size, > 0 = always, < 0 = never
         const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
         if (lwave_pays && !has_fixed && max_level_dim <= 12 && nc <= 41 && a.nObj <= 8)

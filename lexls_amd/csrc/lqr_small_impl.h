@@ -81,6 +81,8 @@ namespace lexls
             if (lane < 16) ZB[lane] = 0.0;
 
             int pos        = (lane < n) ? lane : (lane == n ? n : 0x3fffffff);
+            int rowlim     = 64; // factor output: rows of this lane's physical column that the row-per-lane image T still owns (all, until it is pivoted)
+            double *fac_out = a.fac + b * pstride;
             int ColIndex   = 0;
             int TotalRank  = 0;
 
@@ -225,6 +227,7 @@ namespace lexls
                             const int lc                = (int)__builtin_ctzll(mc);
                             if (lane == lc) pos = ppos;
                             if (lane == pl) pos = ColIndex;
+                            if (write_factor && lane == pl) rowlim = F + dim; // below this level the column holds Gauss multipliers, stored directly
                         }
 
                         const double c0 = rdlane(hh[counter], pl);
@@ -413,7 +416,9 @@ namespace lexls
 #pragma unroll
                             for (int q = 0; q < MD; q++)
                                 if (q > p2) acc[q] = dfma(-Lv[p2], rrow[q], acc[q]);
-                            if (write_factor) store_reg<NC>(T, pq[p2], Lv[p2], below);
+                            // factor output: the multipliers go straight to their final place (pivot p2 of this level sits at position Fc + p2;
+                            // lanes = consecutive rows: one coalesced store) instead of into T through a dynamic register index
+                            if (write_factor && below) fac_out[lane + (size_t)(Fc + p2) * cap] = Lv[p2];
                         }
                     }
 #pragma unroll
@@ -519,13 +524,13 @@ namespace lexls
             // ---- results ----
             if (write_factor) // get_lexqr layout: column = FINAL position of the physical column
             {
-                double *out = a.fac + b * pstride;
 #pragma unroll
                 for (int j = 0; j < NC; j++)
                     if (j <= n)
                     {
                         const int slot = (j < n) ? __builtin_amdgcn_readlane(pos, j) : n;
-                        if (lane < M) out[lane + (size_t)slot * cap] = T[j];
+                        const int lim  = (j < n) ? __builtin_amdgcn_readlane(rowlim, j) : 64; // (the multipliers below a pivoted column are in place already)
+                        if (lane < M && lane < lim) fac_out[lane + (size_t)slot * cap] = T[j];
                     }
             }
             if (lane < n) a.x[(size_t)b * n + lane] = xs[pos]; // x = P x: variable j sits at position pos[j]
