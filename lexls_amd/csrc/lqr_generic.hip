@@ -98,6 +98,44 @@ namespace lexls
             }
         }
 
+        /// apply_q_block for ONE wavefront and a level of at most 64 rows: lane i keeps v[i] in a register, the ordered dot product of
+        /// a reflector walks the lanes with v_readlane (a few cycles per term instead of a dependent LDS round trip), the update is
+        /// lane-local and there is no barrier inside the sequence.  Same chains, same order, same results.
+        __device__ __forceinline__ void apply_q_wave(const double *W, size_t ld, const double *hh, uint32_t F, uint32_t Fc, uint32_t dim, uint32_t rank, double *v,
+                                                     uint32_t lane)
+        {
+            double vi = lane < dim ? v[lane] : 0.0;
+            for (uint32_t j = rank; j--;)
+            {
+                const uint32_t rows = dim - j;
+                const double tau    = hh[F + j];
+                if (rows == 1)
+                {
+                    if (lane == j) vi *= (1.0 - tau);
+                }
+                else if (tau != 0.0)
+                {
+                    const bool tail = lane > j && lane < dim;
+                    const double e  = tail ? W[(F + lane) + (size_t)(Fc + j) * ld] : 0.0; // essential part: entry of row j + i sits in lane j + i
+                    double t        = 0.0;
+                    for (uint32_t i = 1; i < rows; i++)
+                    {
+                        const int l     = (int)(j + i);
+                        const double ei = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e), l), __builtin_amdgcn_readlane(__double2loint(e), l));
+                        const double xi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(vi), l), __builtin_amdgcn_readlane(__double2loint(vi), l));
+                        t               = dfma(ei, xi, t);
+                    }
+                    t += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(vi), (int)j), __builtin_amdgcn_readlane(__double2loint(vi), (int)j));
+                    if (lane == j)
+                        vi = dfma(-tau, t, vi);
+                    else if (tail)
+                        vi = dfma(-(tau * e), t, vi);
+                }
+            }
+            if (lane < dim) v[lane] = vi;
+            __syncthreads();
+        }
+
         // -----------------------------------------------------------------------------------------
         // factorize (+ solve)
         // -----------------------------------------------------------------------------------------
@@ -610,14 +648,22 @@ namespace lexls
                 }
                 return;
             }
-            const double *Wsrc = a.fac + (size_t)b * cap * (n + 1);
-            size_t ldsrc       = cap;
+            const double *Wsrc  = a.fac + (size_t)b * cap * (n + 1);
+            const double *hhsrc = a.hh + (size_t)b * cap;
+            size_t ldsrc        = cap;
+            uint8_t *types_l    = nullptr; // STAGE: LDS copy of the activation types (find_descent reads and marks one entry after the other)
             if (STAGE) // once per launch, shared by all the levels of a scan
             {
-                // LDS: [LambdaFixed nVar | Lambda cap | rhs nVar | bcast | state | staged factor]
-                double *Wl = smem + 2 * n + cap + 1 + (sizeof(SensState) + 7) / 8;
+                // LDS: [LambdaFixed nVar | Lambda cap | rhs nVar | bcast | state | staged factor | Householder scalars]
+                double *Wl  = smem + 2 * n + cap + 1 + (sizeof(SensState) + 7) / 8;
+                double *hhl = Wl + (size_t)(cap | 1u) * (n + 1);
+                for (uint32_t i = tid; i < cap; i += NT) hhl[i] = hhsrc[i]; // (every reflector of every level starts with its tau)
+                types_l = reinterpret_cast<uint8_t *>(hhl + cap); // activation types: cap constraint rows, then nVar fixed variables
+                for (uint32_t i = tid; i < cap; i += NT) types_l[i] = a.ctr_type[(size_t)b * cap + i];
+                for (uint32_t i = tid; i < n; i += NT) types_l[cap + i] = a.fixed_type[(size_t)b * n + i];
                 stage_factor<NT>(Wsrc, Wl, cap, n + 1, cap | 1u, tid);
                 Wsrc  = Wl;
+                hhsrc = hhl;
                 ldsrc = cap | 1u;
             }
             // scan_up: what LexLSI's removal search does with one call per level (lexlsi.h:1121-1132) — levels oi, oi+1, ... until one
@@ -626,11 +672,12 @@ namespace lexls
             {
             const double *W  = Wsrc;
             const size_t ld  = ldsrc;
-            const double *hh = a.hh + (size_t)b * cap;
+            const double *hh = hhsrc;
             const uint32_t *dims = a.dims + (size_t)b * nObj;
             const uint32_t *rk = a.rank + (size_t)b * nObj, *fc = a.fcol + (size_t)b * nObj;
             const uint32_t nf  = a.nfixed ? a.nfixed[b] : 0;
-            uint8_t *ctr_type  = a.ctr_type + (size_t)b * cap;
+            uint8_t *ctr_type  = STAGE ? types_l : a.ctr_type + (size_t)b * cap;
+            uint8_t *fix_type  = STAGE ? types_l + cap : a.fixed_type + (size_t)b * n;
 
             // LDS: [LambdaFixed nVar | Lambda cap | rhs nVar | bcast | state]
             double *LambdaFixed = smem;
@@ -658,7 +705,10 @@ namespace lexls
             uint32_t F = Fobj, Fc = fc[ObjIndex], dim = dims[ObjIndex], rank = rk[ObjIndex];
             for (uint32_t i = rank + tid; i < dim; i += NT) Lambda[F + i] = -W[F + i + n * ld];
             __syncthreads();
-            apply_q_block<NT>(W, ld, hh, F, Fc, dim, rank, Lambda + F, bcast, tid);
+            if (STAGE && NT == 64 && dim <= 64)
+                apply_q_wave(W, ld, hh, F, Fc, dim, rank, Lambda + F, tid);
+            else
+                apply_q_block<NT>(W, ld, hh, F, Fc, dim, rank, Lambda + F, bcast, tid);
             if (tid == 0) find_descent(ctr_type + F, Lambda + F, dim, tolW, tolC, (int)ObjIndex, st);
 
             if (ObjIndex > 0)
@@ -678,7 +728,10 @@ namespace lexls
                     rank = rk[k];
                     for (uint32_t i = tid; i < rank; i += NT) Lambda[F + i] = rhs[Fc + i];
                     __syncthreads();
-                    apply_q_block<NT>(W, ld, hh, F, Fc, dim, rank, Lambda + F, bcast, tid);
+                    if (STAGE && NT == 64 && dim <= 64)
+                        apply_q_wave(W, ld, hh, F, Fc, dim, rank, Lambda + F, tid);
+                    else
+                        apply_q_block<NT>(W, ld, hh, F, Fc, dim, rank, Lambda + F, bcast, tid);
                     for (uint32_t c = tid; c < Fc; c += NT)
                     {
                         double s = 0.0;
@@ -700,7 +753,7 @@ namespace lexls
                     LambdaFixed[c] = -s;
                 }
                 __syncthreads();
-                if (tid == 0) find_descent(a.fixed_type + (size_t)b * n, LambdaFixed, nf, tolW, tolC, -1, st);
+                if (tid == 0) find_descent(fix_type, LambdaFixed, nf, tolW, tolC, -1, st);
             }
             __syncthreads();
 
@@ -724,6 +777,12 @@ namespace lexls
             const int found = st->found; // (LDS, written before the last barrier)
             if (!scan_up || found || ObjIndex + 1 >= nObj) break;
             __syncthreads(); // the next level re-initialises the LDS arrays; its find_descent sees this level's marks (same thread)
+            }
+            if (STAGE) // the CORRECT_SIGN_OF_LAMBDA marks go back to the arrays lexls_lse_get_ctr_type / _fixed_type read
+            {
+                __syncthreads();
+                for (uint32_t i = tid; i < cap; i += NT) a.ctr_type[(size_t)b * cap + i] = types_l[i];
+                for (uint32_t i = tid; i < n; i += NT) a.fixed_type[(size_t)b * n + i] = types_l[cap + i];
             }
         }
 
@@ -1259,7 +1318,7 @@ namespace lexls
         if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
         // Factor staged into LDS when latency is what counts: few problems per CU (a lock-step LSI stage) — with thousands of problems
         // the 20 KB per workgroup would cost the wavefronts in flight that hide the chains instead (4096 problems: 0.090 -> 0.126 ms)
-        const size_t lds_staged = lds + 8 * (size_t)(a.cap | 1u) * (a.nVar + 1);
+        const size_t lds_staged = lds + 8 * ((size_t)(a.cap | 1u) * (a.nVar + 1) + a.cap) + (((size_t)a.cap + a.nVar + 15) & ~(size_t)15);
         static int cus          = 0;
         if (!cus)
         {
