@@ -847,7 +847,7 @@ struct lexls_lsi_batch_s
             hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between stages
             hip_check(lexls_lse_set_sensitivity_scan(ctx.h, 1)); // the removal search of an iteration in ONE sensitivity stage (all its levels)
             // LEXLS_LSI_SPECULATIVE_SENS=1: the removal search runs speculatively behind every factorization (half the stages).  Measured
-            // on MI355X it loses — 1024 instances cold 0.057 s vs 0.050 s: the search is a 50-190 us chain that now lengthens EVERY stage,
+            // on MI355X it loses — 1024 instances cold 0.040 s vs 0.036 s: the search is an ~80 us chain that then lengthens EVERY stage,
             // also those whose step turns out to be blocked — so it is off by default.
             if (const char *e = std::getenv("LEXLS_LSI_SPECULATIVE_SENS")) ctx.spec_sens = std::atoi(e) != 0;
         }
