@@ -1,0 +1,585 @@
+// FOUR PROBLEMS PER WAVEFRONT, left-looking lexicographic-QR kernel for IK-sized problems (lexlse.h:117-506 + solve() :1015-1045).
+//
+// Same results, bit for bit, as the other kernels (arithmetic contract of oracle/lexlse_oracle.h): every value sees the same
+// ordered fma chain; what changes is the mapping onto the wavefront.  One problem owns one 16-lane DPP row, so
+//   * a value that is uniform per problem travels inside the row with ONE v_mov_b64_dpp row_newbcast:<lane> — no SGPR round trip,
+//     no LDS broadcast: Householder essentials, tau, Gauss multipliers and the back-substituted x are produced in "lane r <-> row r"
+//     form and consumed straight from there;
+//   * the pivot search (first maximum by position) is a butterfly inside the row, the per-pivot bookkeeping of lqr_lwave (position
+//     map, rank test, scalars: one sqrt + one division sequence) is paid once per FOUR problems;
+//   * 4096 problems are 1024 wavefronts = one per SIMD, so a wave may use the whole register file (no occupancy target).
+//
+// Column layout ("position layout").  Slot s of lane l of a row holds the column whose position in the reference's permuted order
+// (lexlse.h:222-232) was P = 16 s + l when the level started; the right-hand side sits at P = n.  A level's rows are loaded from
+// HBM in that layout when the level is reached (left-looking: a row's Gauss update by an earlier level depends only on that row
+// and on [R_q T_q], lexlse.h:431-471), so the pivot columns of all finished levels — whose positions are final — sit in STATIC
+// lanes: pivot c' is lane c' % 16 of slot c' / 16.  The elimination of the level's rows is then one pass over c' = 0 .. Fc-1:
+//       l_r = a[r][c'] * (1 / R_c'c')          in every lane; the row-broadcast of lane c' % 16 hands the 12 multipliers to the row
+//       a[r][P] = fma(-l_r, U[c'][P], a[r][P])  for every column behind c'   (U[c'][P]: this lane's own entry of the LDS image)
+// which is exactly the reference's TRSM + trailing update, per row an ascending chain over the pivots.  The Householder loop only
+// touches the slots that still hold live columns (S0 = Fc / 16 and up).
+//
+// LDS per problem: the compact images [R_q T_q | rhs_q] of the finished levels, row-major, columns kept in CURRENT position order
+// (re-packed when a level ends: a column's entries move with the swaps), so eliminations read U[c'][P] at a computed offset and the
+// back-substitution reads contiguous rows;  + x by position, a 14-double exchange block for the pivot column, byte maps.
+#pragma once
+#include "lqr_wave_common.h"
+
+namespace lexls
+{
+    namespace
+    {
+        extern "C" __device__ double lexls_update_dpp_f64(double, double, int, int, int, bool) __asm("llvm.amdgcn.update.dpp.f64");
+
+        /// value of lane L of this lane's 16-lane row (v_mov_b64_dpp row_newbcast:L)
+        template <int L>
+        __device__ __forceinline__ double gbc(double v)
+        {
+            return lexls_update_dpp_f64(0.0, v, 0x150 + L, 0xf, 0xf, true);
+        }
+        template <int L>
+        __device__ __forceinline__ int gbci(int v)
+        {
+            return __builtin_amdgcn_update_dpp(0, v, 0x150 + L, 0xf, 0xf, true);
+        }
+
+        /// maximum over the 16 lanes of a DPP row, in every lane of the row
+        __device__ __forceinline__ double row_max16(double v)
+        {
+            v = dpp_max<0xB1>(v);  // quad_perm [1,0,3,2]
+            v = dpp_max<0x4E>(v);  // quad_perm [2,3,0,1]
+            v = dpp_max<0x141>(v); // row_half_mirror
+            v = dpp_max<0x140>(v); // row_mirror
+            return v;
+        }
+        template <int CTRL>
+        __device__ __forceinline__ unsigned dpp_minu(unsigned v)
+        {
+            const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+            return o < v ? o : v;
+        }
+        __device__ __forceinline__ unsigned row_min16(unsigned v)
+        {
+            v = dpp_minu<0xB1>(v);
+            v = dpp_minu<0x4E>(v);
+            v = dpp_minu<0x141>(v);
+            v = dpp_minu<0x140>(v);
+            return v;
+        }
+        /// max / min over the four rows of a value that is uniform inside each row
+        __device__ __forceinline__ int rows_max(int v)
+        {
+            const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+            const int ab = a > b ? a : b, cd = c > d ? c : d;
+            return ab > cd ? ab : cd;
+        }
+        __device__ __forceinline__ int rows_min(int v)
+        {
+            const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+            const int ab = a < b ? a : b, cd = c < d ? c : d;
+            return ab < cd ? ab : cd;
+        }
+
+        /// c ? x : y on VALUES (the built-in operator on two lvalues yields an lvalue: a select of addresses, which keeps arrays in memory)
+        template <class T>
+        __device__ __forceinline__ T sel(bool c, T x, T y)
+        {
+            return c ? x : y;
+        }
+
+        __device__ __forceinline__ void quad_lds_fence()
+        {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            asm volatile("" ::: "memory");
+        }
+
+        constexpr int kQuadMaxObj = 16; // levels the per-problem LDS table holds
+
+        template <int NS, int MD, bool WF>
+        __global__ __launch_bounds__(64) void lqr_quad_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes)
+        {
+            static_assert(NS >= 1 && NS <= 4 && MD <= 16 && (MD % 2) == 0, "shape limits of the row layout");
+            static_assert(!WF, "factor output: see lqr_quad_wf (not in this instantiation)");
+            extern __shared__ double smem[];
+            char *const L  = reinterpret_cast<char *>(smem);
+            const int lane = threadIdx.x & 63;
+            const int g    = lane >> 4; // row = problem inside the wave
+            const int gl   = lane & 15;
+            const int n    = (int)a.nVar;
+            const int cap  = (int)a.cap;
+            const int nObj = (int)a.nObj;
+            const uint32_t b  = blockIdx.x * 4u + (uint32_t)g;
+            const uint32_t bb = b < a.batch ? b : a.batch - 1u; // rows beyond the batch idle on a valid address
+            const bool live   = b < a.batch && !(a.skip && a.skip[bb]);
+            const size_t pstride = (size_t)cap * (n + 1);
+            const double *in     = a.in + bb * pstride;
+            const uint32_t *dims = a.dims + (size_t)bb * nObj;
+
+            // ---- LDS carve-up of this row's slice (byte offsets; launch_quad_t computes group_bytes) ----
+            const int o_img  = g * (int)group_bytes;
+            const int o_xs   = o_img + 8 * (int)img_doubles; // 16*NS : x by position
+            const int o_ex   = o_xs + 8 * 16 * NS;           // 2 + 16: [fresh, tail | pivot column] hand-off of a pivot step
+            const int o_phys = o_ex + 8 * 18;                // 64 B  : physical column at each position
+            const int o_perm = o_phys + 64;                  // 64 B  : column_permutations
+            const int o_meta = o_perm + 64;                  // 16 x {first column, rank, image offset, image width}
+            auto D   = [&](int off) -> double & { return *reinterpret_cast<double *>(L + off); };
+            auto D2  = [&](int off) -> double2 & { return *reinterpret_cast<double2 *>(L + off); };
+            auto B8  = [&](int off) -> uint8_t & { return *reinterpret_cast<uint8_t *>(L + off); };
+            auto U32 = [&](int off) -> uint32_t & { return *reinterpret_cast<uint32_t *>(L + off); };
+
+#pragma unroll
+            for (int s = 0; s < NS; s++) B8(o_phys + 16 * s + gl) = (uint8_t)(16 * s + gl);
+
+            double blk[NS][MD]; // the level block, position layout
+            double idgreg[NS];  // slot s, lane l: 1 / R_cc of pivot position c = 16 s + l
+            int rp[NS];         // slot s, lane l: LDS byte address of the (virtual) element U[c][0] of pivot position c
+            int pos[NS];        // current position of the column held in slot s
+            int pc[NS];         // its physical column
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+            {
+                idgreg[s] = 0.0;
+                rp[s]     = 0;
+                pos[s]    = 0;
+                pc[s]     = 0;
+            }
+
+            int ColIndex  = 0; // per row (uniform inside a row), like everything below
+            int TotalRank = 0;
+            int F         = 0;
+            int imgoff    = 0; // doubles
+            bool exh      = false;
+
+            for (int k = 0; k < nObj; k++)
+            {
+                const int dim   = live ? (int)dims[k] : 0;
+                const bool work = dim > 0 && !exh; // x only: once the columns are exhausted nothing below matters
+                const int Fc    = ColIndex;
+                int rank        = 0;
+
+                if (__ballot(work) != 0ull)
+                {
+                    // =====================================================================================
+                    // load the level's rows, position layout
+                    // =====================================================================================
+                    bool aligned = true;
+#pragma unroll
+                    for (int s = 0; s < NS; s++)
+                    {
+                        const int P = 16 * s + gl;
+                        pc[s]       = P < n ? (int)B8(o_phys + P) : n;
+                        pos[s]      = P <= n ? P : 0x3fffffff;
+                        aligned     = aligned && (!(work && P <= n) || (dim == MD && (((F + pc[s] * cap) & 1) == 0)));
+                    }
+                    if (__ballot(!aligned) == 0ull)
+                    {
+#pragma unroll
+                        for (int s = 0; s < NS; s++)
+                        {
+                            const bool ld     = work && (16 * s + gl) <= n;
+                            const double2 *s2 = reinterpret_cast<const double2 *>(in + F + (size_t)pc[s] * cap);
+#pragma unroll
+                            for (int r = 0; r < MD / 2; r++)
+                            {
+                                double2 v = make_double2(0.0, 0.0);
+                                if (ld) v = s2[r];
+                                blk[s][2 * r]     = v.x;
+                                blk[s][2 * r + 1] = v.y;
+                            }
+                        }
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int s = 0; s < NS; s++)
+                        {
+                            const bool ld     = work && (16 * s + gl) <= n;
+                            const double *src = in + F + (size_t)pc[s] * cap;
+#pragma unroll
+                            for (int r = 0; r < MD; r++) blk[s][r] = (ld && r < dim) ? src[r] : 0.0;
+                        }
+                    }
+
+                    // =====================================================================================
+                    // Gauss elimination of these rows by every finished pivot c' (lexlse.h:431-471, left-looking)
+                    // =====================================================================================
+                    const int Fcmax = rows_max(work ? Fc : 0);
+                    for_each_index<0, 16 * NS>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int C  = decltype(cc)::value;
+                        constexpr int sc = C / 16, lc = C % 16;
+                        if (C < Fcmax) // wave-uniform
+                        {
+                            if (work && C < Fc) // uniform inside a row
+                            {
+                                double lr[MD];
+                                for_each_index<0, MD>([&](auto rr) {
+                                    constexpr int r = decltype(rr)::value;
+                                    lr[r]           = -gbc<lc>(blk[sc][r] * idgreg[sc]);
+                                });
+                                const int rowp = gbci<lc>(rp[sc]);
+#pragma unroll
+                                for (int s = sc; s < NS; s++)
+                                {
+                                    int P = 16 * s + gl;
+                                    P     = P > C ? P : C + 1;
+                                    P     = P < n ? P : n;
+                                    const double u = D(rowp + 8 * P);
+#pragma unroll
+                                    for (int r = 0; r < MD; r++) blk[s][r] = dfma(lr[r], u, blk[s][r]);
+                                }
+                            }
+                        }
+                    });
+
+                    // =====================================================================================
+                    // Householder QR with column pivoting of the level (lexlse.h:182-268), slots S0 .. NS-1
+                    // =====================================================================================
+                    auto factor_level = [&](auto s0c) __attribute__((always_inline)) {
+                        constexpr int S0 = decltype(s0c)::value;
+                        double nrm[NS];
+#pragma unroll
+                        for (int s = S0; s < NS; s++)
+                        {
+                            nrm[s] = 0.0;
+#pragma unroll
+                            for (int r = 0; r < MD; r++) nrm[s] = dfma(blk[s][r], blk[s][r], nrm[s]);
+                        }
+                        bool go = work;
+                        for_each_index<0, MD>([&](auto cnt) __attribute__((always_inline)) {
+                            constexpr int counter = decltype(cnt)::value;
+                            bool act              = go && counter < dim;
+                            if (__ballot(act) == 0ull) return;
+
+                            // fresh norm and Householder tail norm of every live column (lexlse.h:210-211, :241); only the pivot's are used
+                            double fr[NS], tl[NS];
+#pragma unroll
+                            for (int s = S0; s < NS; s++)
+                            {
+                                fr[s] = 0.0;
+                                tl[s] = 0.0;
+#pragma unroll
+                                for (int r = counter; r < MD; r++)
+                                {
+                                    fr[s] = dfma(blk[s][r], blk[s][r], fr[s]);
+                                    if (r > counter) tl[s] = dfma(blk[s][r], blk[s][r], tl[s]);
+                                }
+                            }
+                            // pivot: first maximum (by position) of the down-dated norms (lexlse.h:205-206)
+                            bool cand[NS];
+                            double m = -1.0;
+#pragma unroll
+                            for (int s = S0; s < NS; s++)
+                            {
+                                cand[s] = pos[s] >= ColIndex && pos[s] < n;
+                                m       = vmax(m, sel(cand[s], nrm[s], -1.0));
+                            }
+                            m = row_max16(m);
+                            unsigned ik[NS], w = 0x7fffffffu;
+#pragma unroll
+                            for (int s = S0; s < NS; s++)
+                            {
+                                ik[s] = (cand[s] && nrm[s] == m) ? (((unsigned)pos[s] << 8) | (unsigned)(s << 4) | (unsigned)gl) : 0x7fffffffu;
+                                w     = ik[s] < w ? ik[s] : w;
+                            }
+                            w = row_min16(w);
+                            const int ppos = (int)(w >> 8);
+                            bool isp[NS], ispany = false;
+#pragma unroll
+                            for (int s = S0; s < NS; s++)
+                            {
+                                isp[s] = act && ik[s] == w && w != 0x7fffffffu;
+                                ispany = ispany || isp[s];
+                            }
+                            // the pivot's lane hands [fresh, tail | column] to its row through LDS
+                            {
+                                constexpr int ce = counter & ~1;
+                                double frv = fr[S0], tlv = tl[S0], colv[MD];
+#pragma unroll
+                                for (int r = ce; r < MD; r++) colv[r] = blk[S0][r];
+#pragma unroll
+                                for (int s = S0 + 1; s < NS; s++)
+                                {
+                                    frv = sel(isp[s], fr[s], frv);
+                                    tlv = sel(isp[s], tl[s], tlv);
+#pragma unroll
+                                    for (int r = ce; r < MD; r++) colv[r] = sel(isp[s], blk[s][r], colv[r]);
+                                }
+                                if (ispany)
+                                {
+                                    D2(o_ex) = make_double2(frv, tlv);
+#pragma unroll
+                                    for (int r = ce; r < MD; r += 2) D2(o_ex + 16 + 8 * r) = make_double2(colv[r], colv[r + 1]);
+                                }
+                            }
+                            quad_lds_fence();
+                            const double2 ft   = D2(o_ex);
+                            const double fresh = ft.x, tailSq = ft.y;
+                            const double c0     = D(o_ex + 16 + 8 * counter);
+                            const double spread = D(o_ex + 16 + 8 * (gl < MD ? gl : MD - 1));
+                            quad_lds_fence();
+
+                            if (act && fresh < a.tol) // rank test on the squared norm (lexlse.h:214)
+                            {
+                                go  = false;
+                                act = false;
+                            }
+                            if (__ballot(act) == 0ull) return;
+                            if (act)
+                            {
+                                // column "swap": update the position map (lexlse.h:222-232)
+#pragma unroll
+                                for (int s = S0; s < NS; s++)
+                                {
+                                    const bool front = pos[s] == ColIndex;
+                                    pos[s]           = sel(front, ppos, pos[s]);
+                                    pos[s]           = sel(isp[s], ColIndex, pos[s]);
+                                }
+                                if (gl == 0) B8(o_perm + ColIndex) = (uint8_t)ppos;
+
+                                double idgv;
+                                if constexpr (counter < MD - 1)
+                                {
+                                    const bool degenerate = tailSq <= DBL_MIN;
+                                    double beta           = sqrt(dfma(c0, c0, tailSq));
+                                    if (c0 >= 0.0) beta = -beta;
+                                    const double diag   = sel(degenerate, c0, beta);
+                                    const double den    = c0 - beta;
+                                    const bool ess_lane = gl > counter && gl < MD;
+                                    double num          = sel(ess_lane, spread, 1.0);
+                                    double dnm          = sel(ess_lane, den, diag);
+                                    if (gl == 0)
+                                    {
+                                        num = beta - c0;
+                                        dnm = beta;
+                                    }
+                                    const double quo = num / dnm; // lane 0: tau | lanes counter+1 .. MD-1: essential part | the others: 1 / R_jj
+                                    if constexpr (MD < 16)
+                                        idgv = gbc<15>(quo);
+                                    else
+                                        idgv = 1.0 / diag;
+                                    const double tau  = degenerate ? 0.0 : gbc<0>(quo);
+                                    const double qe   = (degenerate || !ess_lane) ? 0.0 : quo; // lane r: essential entry of row r
+                                    const double ntau = -tau;
+                                    const double et   = qe * ntau;
+                                    if (tau != 0.0) // uniform inside a row; H = I otherwise (lexlse.h:239)
+                                    {
+                                        // x only: H is applied to every column of the live slots — the non-trailing ones hold nothing
+                                        // that is read again (multipliers / essentials of finished pivots)
+                                        double e[MD], ett[MD];
+                                        for_each_index<counter + 1, MD>([&](auto rr) {
+                                            constexpr int r = decltype(rr)::value;
+                                            e[r]            = gbc<r>(qe);
+                                            ett[r]          = gbc<r>(et);
+                                        });
+#pragma unroll
+                                        for (int s = S0; s < NS; s++)
+                                        {
+                                            double tmp = 0.0;
+#pragma unroll
+                                            for (int r = counter + 1; r < MD; r++) tmp = dfma(e[r], blk[s][r], tmp);
+                                            tmp += blk[s][counter];
+                                            blk[s][counter] = dfma(ntau, tmp, blk[s][counter]);
+#pragma unroll
+                                            for (int r = counter + 1; r < MD; r++) blk[s][r] = dfma(ett[r], tmp, blk[s][r]);
+                                        }
+                                    }
+#pragma unroll
+                                    for (int s = S0; s < NS; s++) blk[s][counter] = sel(isp[s], diag, blk[s][counter]);
+                                }
+                                else
+                                {
+                                    idgv = 1.0 / c0; // last row of a full level: RemainingRows == 1, no reflector (lexlse.h:239)
+                                }
+#pragma unroll
+                                for (int s = S0; s < NS; s++) idgreg[s] = sel(16 * s + gl == ColIndex, idgv, idgreg[s]);
+
+                                ColIndex++;
+                                rank++;
+                                if (ColIndex == n)
+                                {
+                                    exh = true;
+                                    go  = false;
+                                }
+                                else
+                                {
+#pragma unroll
+                                    for (int s = S0; s < NS; s++)
+                                        if (pos[s] >= ColIndex && pos[s] < n) nrm[s] = dfma(-blk[s][counter], blk[s][counter], nrm[s]); // lexlse.h:262-266
+                                }
+                            }
+                        });
+                    };
+                    {
+                        const int s0 = rows_min(work ? Fc : 0x3fffffff) >> 4;
+                        if (NS > 3 && s0 >= 3)
+                            factor_level(std::integral_constant<int, (NS > 3 ? 3 : 0)>{});
+                        else if (NS > 2 && s0 >= 2)
+                            factor_level(std::integral_constant<int, (NS > 2 ? 2 : 0)>{});
+                        else if (NS > 1 && s0 >= 1)
+                            factor_level(std::integral_constant<int, (NS > 1 ? 1 : 0)>{});
+                        else
+                            factor_level(std::integral_constant<int, 0>{});
+                    }
+
+                    // =====================================================================================
+                    // level end: image [R_k T_k | rhs_k] in end-of-level position order, older images re-packed, maps
+                    // =====================================================================================
+                    const int wk = n + 1 - Fc;
+#pragma unroll
+                    for (int s = 0; s < NS; s++)
+                    {
+                        const int P0  = 16 * s + gl;
+                        const bool mv = work && P0 <= n && P0 >= Fc; // columns that were live in this level (the RHS included)
+                        if (mv)
+                        {
+#pragma unroll
+                            for (int p = 0; p < MD; p++)
+                                if (p < rank) D(o_img + 8 * (imgoff + p * wk + (pos[s] - Fc))) = blk[s][p];
+                            if (P0 < n) B8(o_phys + pos[s]) = (uint8_t)pc[s];
+                        }
+                        // pivot position P0 of this level: where its image row starts (as if the row began at position 0)
+                        if (work && P0 >= Fc && P0 < Fc + rank) rp[s] = o_img + 8 * (imgoff + (P0 - Fc) * wk - Fc);
+                    }
+                    for (int q = 0; q < k; q++)
+                    {
+                        const int rq = (int)U32(o_meta + 16 * q + 4);
+                        if (__ballot(work && rq > 0) == 0ull) continue;
+                        const int Fq = (int)U32(o_meta + 16 * q), oq = (int)U32(o_meta + 16 * q + 8), wq = (int)U32(o_meta + 16 * q + 12);
+                        double t[NS][MD];
+#pragma unroll
+                        for (int s = 0; s < NS; s++)
+                        {
+                            const int P0  = 16 * s + gl;
+                            const bool mv = work && P0 <= n && P0 >= Fc && pos[s] != P0;
+#pragma unroll
+                            for (int p = 0; p < MD; p++) t[s][p] = (mv && p < rq) ? D(o_img + 8 * (oq + p * wq + (P0 - Fq))) : 0.0;
+                        }
+#pragma unroll
+                        for (int s = 0; s < NS; s++)
+                        {
+                            const int P0  = 16 * s + gl;
+                            const bool mv = work && P0 <= n && P0 >= Fc && pos[s] != P0;
+#pragma unroll
+                            for (int p = 0; p < MD; p++)
+                                if (mv && p < rq) D(o_img + 8 * (oq + p * wq + (pos[s] - Fq))) = t[s][p];
+                        }
+                    }
+                }
+                if (gl == 0)
+                {
+                    U32(o_meta + 16 * k)      = (uint32_t)Fc;
+                    U32(o_meta + 16 * k + 4)  = (uint32_t)rank;
+                    U32(o_meta + 16 * k + 8)  = (uint32_t)imgoff;
+                    U32(o_meta + 16 * k + 12) = (uint32_t)(n + 1 - Fc);
+                }
+                quad_lds_fence();
+                imgoff += (n + 1 - Fc) * rank;
+                TotalRank += rank;
+                F += dim;
+            }
+
+            // ---- solve(): block back-substitution on the images (lexlse.h:1015-1045); lane p <-> row p of a level ----
+#pragma unroll
+            for (int s = 0; s < NS; s++) D(o_xs + 8 * (16 * s + gl)) = 0.0;
+            quad_lds_fence();
+            for (int k = nObj; k--;)
+            {
+                const int rank = live ? (int)U32(o_meta + 16 * k + 4) : 0;
+                const int rmax = rows_max(rank);
+                if (rmax == 0) continue;
+                const int Fc = (int)U32(o_meta + 16 * k), ok = (int)U32(o_meta + 16 * k + 8), wk = (int)U32(o_meta + 16 * k + 12);
+                const int c0   = Fc + rank;
+                const int acc  = rank > 0 ? TotalRank - c0 : 0;
+                const int amax = rows_max(acc);
+                const int row  = o_img + 8 * (ok + (gl < rank ? gl : 0) * wk);
+                double col[MD];
+#pragma unroll
+                for (int j = 0; j < MD; j++) col[j] = (j < rank && gl < j) ? D(row + 8 * j) : 0.0;
+                const double dg = rank > 0 ? D(row + 8 * (gl < rank ? gl : 0)) : 1.0;
+                double sv       = rank > 0 ? D(row + 8 * (n - Fc)) : 0.0;
+                for (int j = 0; j < amax; j++)
+                {
+                    if (j < acc) sv = dfma(-D(row + 8 * (rank + j)), D(o_xs + 8 * (c0 + j)), sv);
+                }
+                for_each_index<0, MD>([&](auto jj) {
+                    constexpr int j = MD - 1 - decltype(jj)::value;
+                    if (j < rmax)
+                    {
+                        const double xj = gbc<j>(sv) / gbc<j>(dg);
+                        if (j < rank)
+                        {
+                            if (gl == j) sv = xj;
+                            if (gl < j) sv = dfma(-col[j], xj, sv);
+                        }
+                    }
+                });
+                if (gl < rank) D(o_xs + 8 * (Fc + gl)) = sv;
+                quad_lds_fence();
+            }
+
+            // ---- results ----
+            if (live)
+            {
+#pragma unroll
+                for (int s = 0; s < NS; s++)
+                {
+                    const int P = 16 * s + gl;
+                    if (P < n)
+                    {
+                        a.x[(size_t)b * n + B8(o_phys + P)] = D(o_xs + 8 * P); // x = P x: the variable at position P (lexlse.h:1044)
+                        a.perm[(size_t)b * n + P]           = (P < TotalRank) ? (uint32_t)B8(o_perm + P) : (uint32_t)P;
+                    }
+                }
+                if (gl < nObj)
+                {
+                    a.fcol[(size_t)b * nObj + gl] = U32(o_meta + 16 * gl);
+                    a.rank[(size_t)b * nObj + gl] = U32(o_meta + 16 * gl + 4);
+                }
+                if (gl == 0) a.totalrank[b] = (uint32_t)TotalRank;
+            }
+        }
+    } // namespace
+
+    namespace
+    {
+        /// exact worst case of sum_k (n+1-Fc_k) * rank_k over rank distributions with rank_k <= md
+        inline uint32_t quad_image_doubles(uint32_t n, uint32_t nObj, uint32_t md)
+        {
+            uint32_t fc = 0, total = 0;
+            for (uint32_t k = 0; k < nObj && fc < n; k++)
+            {
+                const uint32_t r = md < n - fc ? md : n - fc;
+                total += (n + 1 - fc) * r;
+                fc += r;
+            }
+            return (total + 1) & ~1u;
+        }
+
+        template <int NS>
+        inline size_t quad_group_bytes(uint32_t n, uint32_t nObj, uint32_t md)
+        {
+            return (8 * ((size_t)quad_image_doubles(n, nObj, md) + 16 * NS + 18) + 64 + 64 + 16 * kQuadMaxObj + 15) & ~(size_t)15;
+        }
+
+        template <int NS, int MD, bool WF>
+        hipError_t launch_quad_t(const LseArgs &a, hipStream_t s)
+        {
+            const uint32_t img = quad_image_doubles(a.nVar, a.nObj, MD);
+            const size_t gbytes = quad_group_bytes<NS>(a.nVar, a.nObj, MD);
+            const size_t lds    = 4 * gbytes;
+            if (lds > kMaxLdsBytes || a.nObj > (uint32_t)kQuadMaxObj || a.nVar + 1 > 16u * NS) return hipErrorInvalidValue;
+            if (lds > 64 * 1024)
+            {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_quad_kernel<NS, MD, WF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            const uint32_t blocks = (a.batch + 3u) / 4u;
+            hipLaunchKernelGGL((lqr_quad_kernel<NS, MD, WF>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes);
+            return hipGetLastError();
+        }
+    } // namespace
+} // namespace lexls
+
+// One translation unit per instantiation (parallel builds): LEXLS_QUAD_INSTANCE(name, NS, MD, WF)
+#define LEXLS_QUAD_INSTANCE(NAME, NS, MD, WF) \
+    namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_quad_t<NS, MD, WF>(a, s); } }

@@ -17,6 +17,8 @@ namespace lexls
     hipError_t launch_lwave_41x12_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_lwave_41x12_f(const LseArgs &a, hipStream_t s);
 
+    hipError_t launch_quad_3x12_x(const LseArgs &a, hipStream_t s);
+
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed)
     {
         (void)has_fixed; // fixed variables are handled in-kernel
@@ -45,6 +47,14 @@ namespace lexls
         // that kernel has the shorter latency (factor kept: 66-72 us vs 97-101 us; x only: equal); beyond that the left-looking kernel
         // still runs in one round (4096: 115 us vs 158 us).  left_looking: 0 = decide by batch size, > 0 = always, < 0 = never
         const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
+        // four problems per wavefront (lqr_quad_impl.h): x-only, no fixed variables; one wave per SIMD serves 4 x 4 x CUs problems per round.
+        // left_looking == 2 forces it (parity tests), automatic dispatch takes it wherever the left-looking kernel would have been taken
+        const bool quad_ok = !write_factor && !has_fixed && max_level_dim <= 12 && nc <= 48 && a.nObj <= 16;
+        if (quad_ok && (left_looking == 2 || (left_looking == 0 && lwave_pays)))
+        {
+            *variant = "lqr_quad<3,12>";
+            return launch_quad_3x12_x(a, s);
+        }
         if (lwave_pays && !has_fixed && max_level_dim <= 12 && nc <= 41 && a.nObj <= 8)
         {
             if (nc == 41)
