@@ -55,7 +55,7 @@ namespace lexls
         template <int CTRL>
         __device__ __forceinline__ unsigned dpp_minu(unsigned v)
         {
-            const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+            const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); // folds into v_min_u32_dpp
             return o < v ? o : v;
         }
         __device__ __forceinline__ unsigned row_min16(unsigned v)
@@ -93,7 +93,7 @@ namespace lexls
             asm volatile("" ::: "memory");
         }
 
-        constexpr int kQuadMaxObj = 16; // levels the per-problem LDS table holds
+        constexpr int kQuadMaxObj = 8; // levels: one byte per level in a column's 64-bit image-index word
 
         template <int NS, int MD, bool WF>
         __global__ __launch_bounds__(64) void lqr_quad_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes)
@@ -121,7 +121,9 @@ namespace lexls
             const int o_ex   = o_xs + 8 * 16 * NS;           // 2 + 16: [fresh, tail | pivot column] hand-off of a pivot step
             const int o_phys = o_ex + 8 * 18;                // 64 B  : physical column at each position
             const int o_perm = o_phys + 64;                  // 64 B  : column_permutations
-            const int o_meta = o_perm + 64;                  // 16 x {first column, rank, image offset, image width}
+            const int o_meta = o_perm + 64;                  // kQuadMaxObj x {first column, rank, image offset, image width}
+            const int o_emap = o_meta + 16 * kQuadMaxObj;    // 64 x 8 B: byte k of entry j = column index of PHYSICAL column j in the image of level k
+            const int o_dims = o_emap + 512;                 // kQuadMaxObj x u32: this problem's level dimensions
             auto D   = [&](int off) -> double & { return *reinterpret_cast<double *>(L + off); };
             auto D2  = [&](int off) -> double2 & { return *reinterpret_cast<double2 *>(L + off); };
             auto B8  = [&](int off) -> uint8_t & { return *reinterpret_cast<uint8_t *>(L + off); };
@@ -129,10 +131,27 @@ namespace lexls
 
 #pragma unroll
             for (int s = 0; s < NS; s++) B8(o_phys + 16 * s + gl) = (uint8_t)(16 * s + gl);
+#pragma unroll
+            for (int i = 0; i < 4; i++) D(o_emap + 8 * (16 * i + gl)) = 0.0;
+            if (gl < kQuadMaxObj) U32(o_dims + 4 * gl) = (live && gl < nObj) ? dims[gl] : 0u; // one global read; a level's dim then costs an LDS read
+            quad_lds_fence();
+
+            // The four waves of a CU (one per SIMD) would reach every level's loads together and queue behind each other in the CU's
+            // one address unit (a column-per-lane load touches 64 lines); started a little apart they take turns instead
+#ifndef LEXLS_QUAD_STAGGER
+#define LEXLS_QUAD_STAGGER 20
+#endif
+            if (LEXLS_QUAD_STAGGER > 0)
+            {
+                const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | ((2 - 1) << 11)); // HW_REG_HW_ID, bits [5:4] = SIMD
+                for (unsigned i = 0; i < hwid; i++) __builtin_amdgcn_s_sleep(LEXLS_QUAD_STAGGER);
+            }
 
             double blk[NS][MD]; // the level block, position layout
             double idgreg[NS];  // slot s, lane l: 1 / R_cc of pivot position c = 16 s + l
-            int rp[NS];         // slot s, lane l: LDS byte address of the (virtual) element U[c][0] of pivot position c
+            int rp[NS];         // slot s, lane l: LDS byte address of the image row of pivot position c
+            int rq[NS];         // slot s, lane l: v_perm selector that picks the byte of pivot position c's LEVEL out of a column's index word
+            unsigned long long em[NS]; // the index word of the column held in slot s
             int pos[NS];        // current position of the column held in slot s
             int pc[NS];         // its physical column
 #pragma unroll
@@ -140,6 +159,8 @@ namespace lexls
             {
                 idgreg[s] = 0.0;
                 rp[s]     = 0;
+                rq[s]     = 0x0c0c0c00;
+                em[s]     = 0ull;
                 pos[s]    = 0;
                 pc[s]     = 0;
             }
@@ -149,10 +170,12 @@ namespace lexls
             int F         = 0;
             int imgoff    = 0; // doubles
             bool exh      = false;
+            STAMP_DECL
+            STAMP(0)
 
             for (int k = 0; k < nObj; k++)
             {
-                const int dim   = live ? (int)dims[k] : 0;
+                const int dim   = (int)U32(o_dims + 4 * k);
                 const bool work = dim > 0 && !exh; // x only: once the columns are exhausted nothing below matters
                 const int Fc    = ColIndex;
                 int rank        = 0;
@@ -169,6 +192,7 @@ namespace lexls
                         const int P = 16 * s + gl;
                         pc[s]       = P < n ? (int)B8(o_phys + P) : n;
                         pos[s]      = P <= n ? P : 0x3fffffff;
+                        em[s]       = *reinterpret_cast<const unsigned long long *>(L + o_emap + 8 * pc[s]);
                         aligned     = aligned && (!(work && P <= n) || (dim == MD && (((F + pc[s] * cap) & 1) == 0)));
                     }
                     if (__ballot(!aligned) == 0ull)
@@ -179,12 +203,16 @@ namespace lexls
                             const bool ld     = work && (16 * s + gl) <= n;
                             const double2 *s2 = reinterpret_cast<const double2 *>(in + F + (size_t)pc[s] * cap);
 #pragma unroll
-                            for (int r = 0; r < MD / 2; r++)
+                            for (int r = 0; r < MD; r++) blk[s][r] = 0.0;
+                            if (ld)
                             {
-                                double2 v = make_double2(0.0, 0.0);
-                                if (ld) v = s2[r];
-                                blk[s][2 * r]     = v.x;
-                                blk[s][2 * r + 1] = v.y;
+#pragma unroll
+                                for (int r = 0; r < MD / 2; r++)
+                                {
+                                    const double2 v   = s2[r];
+                                    blk[s][2 * r]     = v.x;
+                                    blk[s][2 * r + 1] = v.y;
+                                }
                             }
                         }
                     }
@@ -200,39 +228,81 @@ namespace lexls
                         }
                     }
 
+                    STAMP(1)
+#ifdef LEXLS_WAVE_STAMPS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    STAMP(8)
+#endif
                     // =====================================================================================
                     // Gauss elimination of these rows by every finished pivot c' (lexlse.h:431-471, left-looking)
                     // =====================================================================================
                     const int Fcmax = rows_max(work ? Fc : 0);
-                    for_each_index<0, 16 * NS>([&](auto cc) __attribute__((always_inline)) {
-                        constexpr int C  = decltype(cc)::value;
-                        constexpr int sc = C / 16, lc = C % 16;
-                        if (C < Fcmax) // wave-uniform
-                        {
-                            if (work && C < Fc) // uniform inside a row
+                    // Rows that take part all have Fc == Fcmax in a batch of equally shaped, full-rank problems: the pivots then run without
+                    // any per-row predicate (a row that does not work in this level may compute garbage, nothing of it is kept).  A divergent
+                    // region around the block update would make the compiler copy the whole block at every pivot.
+                    const bool elim_uniform = rows_min(work ? Fc : 0x3fffffff) == Fcmax;
+                    auto eliminate = [&](auto masked_c) __attribute__((always_inline)) {
+                        constexpr bool MASKED = decltype(masked_c)::value;
+                        // U[c'][P] of this lane's columns is fetched one pivot ahead of its use (the read depends on a row-broadcast address)
+                        auto fetch_u = [&](auto cc, double (&u)[NS]) __attribute__((always_inline)) {
+                            constexpr int C  = decltype(cc)::value;
+                            constexpr int sc = C / 16, lc = C % 16;
+                            const int rowp   = gbci<lc>(rp[sc]);
+                            const int selq   = gbci<lc>(rq[sc]);
+#pragma unroll
+                            for (int s = sc; s < NS; s++)
                             {
-                                double lr[MD];
-                                for_each_index<0, MD>([&](auto rr) {
-                                    constexpr int r = decltype(rr)::value;
-                                    lr[r]           = -gbc<lc>(blk[sc][r] * idgreg[sc]);
-                                });
-                                const int rowp = gbci<lc>(rp[sc]);
-#pragma unroll
-                                for (int s = sc; s < NS; s++)
-                                {
-                                    int P = 16 * s + gl;
-                                    P     = P > C ? P : C + 1;
-                                    P     = P < n ? P : n;
-                                    const double u = D(rowp + 8 * P);
-#pragma unroll
-                                    for (int r = 0; r < MD; r++) blk[s][r] = dfma(lr[r], u, blk[s][r]);
-                                }
+                                const unsigned e = __builtin_amdgcn_perm((unsigned)(em[s] >> 32), (unsigned)em[s], (unsigned)selq);
+                                u[s]             = D(rowp + 8 * (int)e);
                             }
-                        }
-                    });
+                        };
+                        double ucur[NS], unext[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; s++) ucur[s] = unext[s] = 0.0;
+                        if (Fcmax > 0) fetch_u(std::integral_constant<int, 0>{}, ucur);
+                        for_each_index<0, 16 * NS>([&](auto cc) __attribute__((always_inline)) {
+                            constexpr int C  = decltype(cc)::value;
+                            constexpr int sc = C / 16, lc = C % 16;
+                            if (C < Fcmax) // wave-uniform
+                            {
+                                if constexpr (C + 1 < 16 * NS)
+                                {
+                                    if (C + 1 < Fcmax) fetch_u(std::integral_constant<int, C + 1>{}, unext);
+                                }
+                                auto body = [&]() __attribute__((always_inline)) {
+                                    double lr[MD];
+                                    for_each_index<0, MD>([&](auto rr) {
+                                        constexpr int r = decltype(rr)::value;
+                                        lr[r]           = -gbc<lc>(blk[sc][r] * idgreg[sc]);
+                                    });
+#pragma unroll
+                                    for (int s = sc; s < NS; s++)
+                                    {
+#pragma unroll
+                                        for (int r = 0; r < MD; r++) blk[s][r] = dfma(lr[r], ucur[s], blk[s][r]);
+                                    }
+                                };
+                                if constexpr (MASKED)
+                                {
+                                    if (work && C < Fc) body(); // uniform inside a row
+                                }
+                                else
+                                    body();
+#pragma unroll
+                                for (int s = 0; s < NS; s++) ucur[s] = unext[s];
+                            }
+                        });
+                    };
+                    if (elim_uniform)
+                        eliminate(std::false_type{});
+                    else
+                        eliminate(std::true_type{});
 
+                    STAMP(7)
                     // =====================================================================================
-                    // Householder QR with column pivoting of the level (lexlse.h:182-268), slots S0 .. NS-1
+                    // Householder QR with column pivoting of the level (lexlse.h:182-268), slots S0 .. NS-1.
+                    // Straight-line per pivot: a row that has stopped (rank found, fewer rows, no work) keeps executing on data nobody reads
+                    // again (x only: rows at and below its rank) while its bookkeeping is frozen by selects.
                     // =====================================================================================
                     auto factor_level = [&](auto s0c) __attribute__((always_inline)) {
                         constexpr int S0 = decltype(s0c)::value;
@@ -247,22 +317,23 @@ namespace lexls
                         bool go = work;
                         for_each_index<0, MD>([&](auto cnt) __attribute__((always_inline)) {
                             constexpr int counter = decltype(cnt)::value;
-                            bool act              = go && counter < dim;
+                            const bool act        = go && counter < dim;
                             if (__ballot(act) == 0ull) return;
 
-                            // fresh norm and Householder tail norm of every live column (lexlse.h:210-211, :241); only the pivot's are used
-                            double fr[NS], tl[NS];
-#pragma unroll
-                            for (int s = S0; s < NS; s++)
+                            // fresh norm and Householder tail norm (lexlse.h:210-211, :241) are only needed for the pivot column.  One live slot:
+                            // computed for every column up front — the chains fill the latency of the search; several live slots: computed on
+                            // the selected column after the search (a third of the fma's, ~100 cycles more latency)
+                            constexpr bool spec_norms = (NS - S0) == 1;
+                            double fr0 = 0.0, tl0 = 0.0;
+                            if constexpr (spec_norms)
                             {
-                                fr[s] = 0.0;
-                                tl[s] = 0.0;
 #pragma unroll
                                 for (int r = counter; r < MD; r++)
                                 {
-                                    fr[s] = dfma(blk[s][r], blk[s][r], fr[s]);
-                                    if (r > counter) tl[s] = dfma(blk[s][r], blk[s][r], tl[s]);
+                                    fr0 = dfma(blk[S0][r], blk[S0][r], fr0);
+                                    if (r > counter) tl0 = dfma(blk[S0][r], blk[S0][r], tl0);
                                 }
+                                asm volatile("" : "+v"(fr0), "+v"(tl0)); // stay in front of the search
                             }
                             // pivot: first maximum (by position) of the down-dated norms (lexlse.h:205-206)
                             bool cand[NS];
@@ -287,22 +358,30 @@ namespace lexls
 #pragma unroll
                             for (int s = S0; s < NS; s++)
                             {
-                                isp[s] = act && ik[s] == w && w != 0x7fffffffu;
+                                isp[s] = ik[s] == w && w != 0x7fffffffu;
                                 ispany = ispany || isp[s];
                             }
                             // the pivot's lane hands [fresh, tail | column] to its row through LDS
                             {
                                 constexpr int ce = counter & ~1;
-                                double frv = fr[S0], tlv = tl[S0], colv[MD];
+                                double colv[MD];
 #pragma unroll
                                 for (int r = ce; r < MD; r++) colv[r] = blk[S0][r];
 #pragma unroll
                                 for (int s = S0 + 1; s < NS; s++)
                                 {
-                                    frv = sel(isp[s], fr[s], frv);
-                                    tlv = sel(isp[s], tl[s], tlv);
 #pragma unroll
                                     for (int r = ce; r < MD; r++) colv[r] = sel(isp[s], blk[s][r], colv[r]);
+                                }
+                                double frv = fr0, tlv = tl0;
+                                if constexpr (!spec_norms)
+                                {
+#pragma unroll
+                                    for (int r = counter; r < MD; r++)
+                                    {
+                                        frv = dfma(colv[r], colv[r], frv);
+                                        if (r > counter) tlv = dfma(colv[r], colv[r], tlv);
+                                    }
                                 }
                                 if (ispany)
                                 {
@@ -311,6 +390,7 @@ namespace lexls
                                     for (int r = ce; r < MD; r += 2) D2(o_ex + 16 + 8 * r) = make_double2(colv[r], colv[r + 1]);
                                 }
                             }
+                            STAMP(2)
                             quad_lds_fence();
                             const double2 ft   = D2(o_ex);
                             const double fresh = ft.x, tailSq = ft.y;
@@ -318,95 +398,102 @@ namespace lexls
                             const double spread = D(o_ex + 16 + 8 * (gl < MD ? gl : MD - 1));
                             quad_lds_fence();
 
-                            if (act && fresh < a.tol) // rank test on the squared norm (lexlse.h:214)
+                            STAMP(3)
+                            const bool cont = act && !(fresh < a.tol); // rank test on the squared norm (lexlse.h:214)
+                            go              = sel(act, cont, go);
+                            if (__ballot(cont) == 0ull) return;
+
+                            // column "swap": update the position map (lexlse.h:222-232)
+#pragma unroll
+                            for (int s = S0; s < NS; s++)
                             {
-                                go  = false;
-                                act = false;
+                                const bool front = cont && pos[s] == ColIndex;
+                                pos[s]           = sel(front, ppos, pos[s]);
+                                pos[s]           = sel(cont && isp[s], ColIndex, pos[s]);
                             }
-                            if (__ballot(act) == 0ull) return;
-                            if (act)
+                            if (cont && gl == 0) B8(o_perm + ColIndex) = (uint8_t)ppos;
+
+                            double idgv;
+                            if constexpr (counter < MD - 1)
                             {
-                                // column "swap": update the position map (lexlse.h:222-232)
-#pragma unroll
-                                for (int s = S0; s < NS; s++)
+                                const bool degenerate = tailSq <= DBL_MIN;
+                                double beta           = sqrt(dfma(c0, c0, tailSq));
+                                if (c0 >= 0.0) beta = -beta;
+                                const double diag   = sel(degenerate, c0, beta);
+                                const double den    = c0 - beta;
+                                const bool ess_lane = gl > counter && gl < MD;
+                                double num          = sel(ess_lane, spread, 1.0);
+                                double dnm          = sel(ess_lane, den, diag);
+                                if (gl == 0)
                                 {
-                                    const bool front = pos[s] == ColIndex;
-                                    pos[s]           = sel(front, ppos, pos[s]);
-                                    pos[s]           = sel(isp[s], ColIndex, pos[s]);
+                                    num = beta - c0;
+                                    dnm = beta;
                                 }
-                                if (gl == 0) B8(o_perm + ColIndex) = (uint8_t)ppos;
-
-                                double idgv;
-                                if constexpr (counter < MD - 1)
-                                {
-                                    const bool degenerate = tailSq <= DBL_MIN;
-                                    double beta           = sqrt(dfma(c0, c0, tailSq));
-                                    if (c0 >= 0.0) beta = -beta;
-                                    const double diag   = sel(degenerate, c0, beta);
-                                    const double den    = c0 - beta;
-                                    const bool ess_lane = gl > counter && gl < MD;
-                                    double num          = sel(ess_lane, spread, 1.0);
-                                    double dnm          = sel(ess_lane, den, diag);
-                                    if (gl == 0)
-                                    {
-                                        num = beta - c0;
-                                        dnm = beta;
-                                    }
-                                    const double quo = num / dnm; // lane 0: tau | lanes counter+1 .. MD-1: essential part | the others: 1 / R_jj
-                                    if constexpr (MD < 16)
-                                        idgv = gbc<15>(quo);
-                                    else
-                                        idgv = 1.0 / diag;
-                                    const double tau  = degenerate ? 0.0 : gbc<0>(quo);
-                                    const double qe   = (degenerate || !ess_lane) ? 0.0 : quo; // lane r: essential entry of row r
-                                    const double ntau = -tau;
-                                    const double et   = qe * ntau;
-                                    if (tau != 0.0) // uniform inside a row; H = I otherwise (lexlse.h:239)
-                                    {
-                                        // x only: H is applied to every column of the live slots — the non-trailing ones hold nothing
-                                        // that is read again (multipliers / essentials of finished pivots)
-                                        double e[MD], ett[MD];
-                                        for_each_index<counter + 1, MD>([&](auto rr) {
-                                            constexpr int r = decltype(rr)::value;
-                                            e[r]            = gbc<r>(qe);
-                                            ett[r]          = gbc<r>(et);
-                                        });
-#pragma unroll
-                                        for (int s = S0; s < NS; s++)
-                                        {
-                                            double tmp = 0.0;
-#pragma unroll
-                                            for (int r = counter + 1; r < MD; r++) tmp = dfma(e[r], blk[s][r], tmp);
-                                            tmp += blk[s][counter];
-                                            blk[s][counter] = dfma(ntau, tmp, blk[s][counter]);
-#pragma unroll
-                                            for (int r = counter + 1; r < MD; r++) blk[s][r] = dfma(ett[r], tmp, blk[s][r]);
-                                        }
-                                    }
-#pragma unroll
-                                    for (int s = S0; s < NS; s++) blk[s][counter] = sel(isp[s], diag, blk[s][counter]);
-                                }
+                                const double quo = num / dnm; // lane 0: tau | lanes counter+1 .. MD-1: essential part | the others: 1 / R_jj
+                                if constexpr (MD < 16)
+                                    idgv = gbc<15>(quo);
                                 else
-                                {
-                                    idgv = 1.0 / c0; // last row of a full level: RemainingRows == 1, no reflector (lexlse.h:239)
-                                }
-#pragma unroll
-                                for (int s = S0; s < NS; s++) idgreg[s] = sel(16 * s + gl == ColIndex, idgv, idgreg[s]);
-
-                                ColIndex++;
-                                rank++;
-                                if (ColIndex == n)
-                                {
-                                    exh = true;
-                                    go  = false;
-                                }
-                                else
+                                    idgv = 1.0 / diag;
+                                const double tau  = sel(degenerate, 0.0, gbc<0>(quo));
+                                const double qe   = sel(degenerate || !ess_lane, 0.0, quo); // lane r: essential entry of row r
+                                const double ntau = -tau;
+                                const double et   = qe * ntau;
+                                STAMP(4)
+                                // x only: H is applied to every column of the live slots — the non-trailing ones hold nothing that is read
+                                // again (multipliers / essentials of finished pivots)
+                                double e[MD], ett[MD];
+                                for_each_index<counter + 1, MD>([&](auto rr) {
+                                    constexpr int r = decltype(rr)::value;
+                                    e[r]            = gbc<r>(qe);
+                                    ett[r]          = gbc<r>(et);
+                                });
+                                if (__ballot(cont && tau == 0.0) == 0ull)
                                 {
 #pragma unroll
                                     for (int s = S0; s < NS; s++)
-                                        if (pos[s] >= ColIndex && pos[s] < n) nrm[s] = dfma(-blk[s][counter], blk[s][counter], nrm[s]); // lexlse.h:262-266
+                                    {
+                                        double tmp = 0.0;
+#pragma unroll
+                                        for (int r = counter + 1; r < MD; r++) tmp = dfma(e[r], blk[s][r], tmp);
+                                        tmp += blk[s][counter];
+                                        blk[s][counter] = dfma(ntau, tmp, blk[s][counter]);
+#pragma unroll
+                                        for (int r = counter + 1; r < MD; r++) blk[s][r] = dfma(ett[r], tmp, blk[s][r]);
+                                    }
                                 }
+                                else // some row has H = I (lexlse.h:239): there the block must come through bit for bit
+                                {
+                                    const bool app = tau != 0.0;
+#pragma unroll
+                                    for (int s = S0; s < NS; s++)
+                                    {
+                                        double tmp = 0.0;
+#pragma unroll
+                                        for (int r = counter + 1; r < MD; r++) tmp = dfma(e[r], blk[s][r], tmp);
+                                        tmp += blk[s][counter];
+                                        blk[s][counter] = sel(app, dfma(ntau, tmp, blk[s][counter]), blk[s][counter]);
+#pragma unroll
+                                        for (int r = counter + 1; r < MD; r++) blk[s][r] = sel(app, dfma(ett[r], tmp, blk[s][r]), blk[s][r]);
+                                    }
+                                }
+#pragma unroll
+                                for (int s = S0; s < NS; s++) blk[s][counter] = sel(isp[s], diag, blk[s][counter]);
                             }
+                            else
+                            {
+                                idgv = 1.0 / c0; // last row of a full level: RemainingRows == 1, no reflector (lexlse.h:239)
+                            }
+#pragma unroll
+                            for (int s = S0; s < NS; s++) idgreg[s] = sel(cont && 16 * s + gl == ColIndex, idgv, idgreg[s]);
+
+                            ColIndex += cont ? 1 : 0;
+                            rank += cont ? 1 : 0;
+                            const bool full = cont && ColIndex == n;
+                            exh             = exh || full;
+                            go              = go && !full;
+#pragma unroll
+                            for (int s = S0; s < NS; s++) nrm[s] = dfma(-blk[s][counter], blk[s][counter], nrm[s]); // lexlse.h:262-266
+                            STAMP(5)
                         });
                     };
                     {
@@ -425,6 +512,8 @@ namespace lexls
                     // level end: image [R_k T_k | rhs_k] in end-of-level position order, older images re-packed, maps
                     // =====================================================================================
                     const int wk = n + 1 - Fc;
+                    // stores that do not apply go to a dump slot (the hand-off block is idle here): no divergent regions
+                    const int dump = o_ex;
 #pragma unroll
                     for (int s = 0; s < NS; s++)
                     {
@@ -432,39 +521,20 @@ namespace lexls
                         const bool mv = work && P0 <= n && P0 >= Fc; // columns that were live in this level (the RHS included)
                         if (mv)
                         {
+                            const int e    = pos[s] - Fc; // index of this column in the level's image: end-of-level position order
+                            const int base = o_img + 8 * (imgoff + e);
 #pragma unroll
-                            for (int p = 0; p < MD; p++)
-                                if (p < rank) D(o_img + 8 * (imgoff + p * wk + (pos[s] - Fc))) = blk[s][p];
+                            for (int p = 0; p < MD; p++) D(sel(p < rank, base + 8 * p * wk, dump)) = blk[s][p];
+                            B8(o_emap + 8 * pc[s] + k) = (uint8_t)e;
                             if (P0 < n) B8(o_phys + pos[s]) = (uint8_t)pc[s];
                         }
-                        // pivot position P0 of this level: where its image row starts (as if the row began at position 0)
-                        if (work && P0 >= Fc && P0 < Fc + rank) rp[s] = o_img + 8 * (imgoff + (P0 - Fc) * wk - Fc);
-                    }
-                    for (int q = 0; q < k; q++)
-                    {
-                        const int rq = (int)U32(o_meta + 16 * q + 4);
-                        if (__ballot(work && rq > 0) == 0ull) continue;
-                        const int Fq = (int)U32(o_meta + 16 * q), oq = (int)U32(o_meta + 16 * q + 8), wq = (int)U32(o_meta + 16 * q + 12);
-                        double t[NS][MD];
-#pragma unroll
-                        for (int s = 0; s < NS; s++)
-                        {
-                            const int P0  = 16 * s + gl;
-                            const bool mv = work && P0 <= n && P0 >= Fc && pos[s] != P0;
-#pragma unroll
-                            for (int p = 0; p < MD; p++) t[s][p] = (mv && p < rq) ? D(o_img + 8 * (oq + p * wq + (P0 - Fq))) : 0.0;
-                        }
-#pragma unroll
-                        for (int s = 0; s < NS; s++)
-                        {
-                            const int P0  = 16 * s + gl;
-                            const bool mv = work && P0 <= n && P0 >= Fc && pos[s] != P0;
-#pragma unroll
-                            for (int p = 0; p < MD; p++)
-                                if (mv && p < rq) D(o_img + 8 * (oq + p * wq + (pos[s] - Fq))) = t[s][p];
-                        }
+                        // pivot position P0 of this level: its image row and the selector of this level's index byte
+                        const bool piv = work && P0 >= Fc && P0 < Fc + rank;
+                        rp[s]          = sel(piv, o_img + 8 * (imgoff + (P0 - Fc) * wk), rp[s]);
+                        rq[s]          = sel(piv, 0x0c0c0c00 | k, rq[s]);
                     }
                 }
+                STAMP(6)
                 if (gl == 0)
                 {
                     U32(o_meta + 16 * k)      = (uint32_t)Fc;
@@ -497,9 +567,21 @@ namespace lexls
                 for (int j = 0; j < MD; j++) col[j] = (j < rank && gl < j) ? D(row + 8 * j) : 0.0;
                 const double dg = rank > 0 ? D(row + 8 * (gl < rank ? gl : 0)) : 1.0;
                 double sv       = rank > 0 ? D(row + 8 * (n - Fc)) : 0.0;
-                for (int j = 0; j < amax; j++)
+                // rhs_k - T_k x_later (lexlse.h:1029-1033): the column at final position c sits at its level-k index inside the image;
+                // sixteen solved positions per trip — lane j looks up index and x of position c0 + base + j, the row-broadcast hands them out
+                for (int base = 0; base < amax; base += 16)
                 {
-                    if (j < acc) sv = dfma(-D(row + 8 * (rank + j)), D(o_xs + 8 * (c0 + j)), sv);
+                    const int c     = c0 + base + gl;
+                    const bool have = base + gl < acc;
+                    const int ph    = have ? (int)B8(o_phys + c) : 0;
+                    const int offv  = have ? (int)B8(o_emap + 8 * ph + k) : 0;
+                    const double xv = have ? D(o_xs + 8 * c) : 0.0;
+                    for_each_index<0, 16>([&](auto jj) {
+                        constexpr int j   = decltype(jj)::value;
+                        const double uj   = D(row + 8 * gbci<j>(offv));
+                        const double tnew = dfma(-uj, gbc<j>(xv), sv);
+                        sv                = sel(base + j < acc, tnew, sv);
+                    });
                 }
                 for_each_index<0, MD>([&](auto jj) {
                     constexpr int j = MD - 1 - decltype(jj)::value;
@@ -517,6 +599,7 @@ namespace lexls
                 quad_lds_fence();
             }
 
+            STAMP(9)
             // ---- results ----
             if (live)
             {
@@ -537,6 +620,8 @@ namespace lexls
                 }
                 if (gl == 0) a.totalrank[b] = (uint32_t)TotalRank;
             }
+            STAMP(10)
+            STAMP_WRITE
         }
     } // namespace
 
@@ -558,7 +643,7 @@ namespace lexls
         template <int NS>
         inline size_t quad_group_bytes(uint32_t n, uint32_t nObj, uint32_t md)
         {
-            return (8 * ((size_t)quad_image_doubles(n, nObj, md) + 16 * NS + 18) + 64 + 64 + 16 * kQuadMaxObj + 15) & ~(size_t)15;
+            return (8 * ((size_t)quad_image_doubles(n, nObj, md) + 16 * NS + 18) + 64 + 64 + 16 * kQuadMaxObj + 512 + 4 * kQuadMaxObj + 15) & ~(size_t)15;
         }
 
         template <int NS, int MD, bool WF>
@@ -567,7 +652,7 @@ namespace lexls
             const uint32_t img = quad_image_doubles(a.nVar, a.nObj, MD);
             const size_t gbytes = quad_group_bytes<NS>(a.nVar, a.nObj, MD);
             const size_t lds    = 4 * gbytes;
-            if (lds > kMaxLdsBytes || a.nObj > (uint32_t)kQuadMaxObj || a.nVar + 1 > 16u * NS) return hipErrorInvalidValue;
+            if (lds > kMaxLdsBytes || a.nObj > (uint32_t)kQuadMaxObj || a.nVar + 1 > 16u * NS || a.nVar > 63u) return hipErrorInvalidValue;
             if (lds > 64 * 1024)
             {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_quad_kernel<NS, MD, WF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

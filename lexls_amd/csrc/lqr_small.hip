@@ -49,7 +49,7 @@ namespace lexls
         const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
         // four problems per wavefront (lqr_quad_impl.h): x-only, no fixed variables; one wave per SIMD serves 4 x 4 x CUs problems per round.
         // left_looking == 2 forces it (parity tests), automatic dispatch takes it wherever the left-looking kernel would have been taken
-        const bool quad_ok = !write_factor && !has_fixed && max_level_dim <= 12 && nc <= 48 && a.nObj <= 16;
+        const bool quad_ok = !write_factor && !has_fixed && max_level_dim <= 12 && nc <= 48 && a.nObj <= 8;
         if (quad_ok && (left_looking == 2 || (left_looking == 0 && lwave_pays)))
         {
             *variant = "lqr_quad<3,12>";

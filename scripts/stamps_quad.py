@@ -1,0 +1,16 @@
+"""Diagnostic: per-phase shader-clock shares of lqr_quad (needs a -DLEXLS_WAVE_STAMPS build via LEXLS_HIP_LIB)."""
+import os, sys; sys.path.insert(0, '.')
+import numpy as np
+import lexls_amd
+from lexls_amd import problems as P
+n, dims, batch = 40, [12]*5, int(os.environ.get('STAMP_BATCH', '4096'))
+lod = P.lse_batch_fast(20260100, batch, n, dims)
+s = lexls_amd.BatchedLexLSE(batch, n, dims); s.setProblem(lod)
+s.set_kernel_policy(4)
+for _ in range(3): s.factorize_solve(False)
+s.synchronize()
+lam = s.getWorkspace()[::4, :11]
+names = ["init", "level load", "search+select+EX write", "EX round trip", "scalars (sqrt, div)", "apply+downdate", "level end (image, repack)", "eliminate", "load wait (vmcnt)", "solve", "output"]
+med = np.median(lam, axis=0); tot = med.sum()
+for nm, v in zip(names, med): print(f"{nm:28s} {v:10.0f} cycles  {100*v/tot:5.1f}%")
+print("batch", batch, "total", tot, "cycles/wave (median); kernel", s.last_kernel())

@@ -43,7 +43,8 @@ def assert_factor_equal(s, ref, dims, nvar):
 
 # kernel policy (include/lexls_hip.h): 0 = automatic dispatch (small shapes: register-resident wave kernel up to one round of it, left-looking
 # beyond), 1 = generic kernel only, 2 = never the left-looking wave kernel, 3 = the left-looking wave kernel whenever the shape allows
-BOTH_PATHS = pytest.mark.parametrize("force_generic", [0, 1, 2, 3], ids=["automatic", "generic", "register-resident", "left-looking"])
+# 4 = the four-problems-per-wavefront kernel (x-only solves of shapes it serves; anything else falls through to the automatic choice)
+BOTH_PATHS = pytest.mark.parametrize("force_generic", [0, 1, 2, 3, 4], ids=["automatic", "generic", "register-resident", "left-looking", "quad"])
 
 
 @BOTH_PATHS
@@ -54,7 +55,7 @@ def test_ik_batch_bit_exact(hip, oracle, force_generic):
     assert (ref["rank"] == [12, 12, 12, 4, 0]).all()
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
-    assert s.last_kernel() == {0: "lqr_wave<41,12,exact>", 1: "lqr_generic<64,lds>", 2: "lqr_wave<41,12,exact>", 3: "lqr_lwave<41,12,exact>"}[force_generic]
+    assert s.last_kernel() == {0: "lqr_wave<41,12,exact>", 1: "lqr_generic<64,lds>", 2: "lqr_wave<41,12,exact>", 3: "lqr_lwave<41,12,exact>", 4: "lqr_wave<41,12,exact>"}[force_generic]
 
 
 @BOTH_PATHS
@@ -64,6 +65,9 @@ def test_x_only_variant_matches(hip, oracle, force_generic):
     s, ref = run_both(hip, oracle, lod, dims, n, keep_factor=False, force_generic=force_generic)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
     np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    if force_generic == 4:
+        assert s.last_kernel() == "lqr_quad<3,12>"
     with pytest.raises(Exception):
         s.get_lexqr()  # factor was not kept: the library must refuse, not return stale data
 
@@ -115,6 +119,61 @@ def test_wave_kernel_shapes(hip, oracle, n, dims, policy):
         assert s.last_kernel().startswith("lqr_lwave")
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
+
+
+def _quad_x_only(hip, oracle, lod, dims, n, maxdim=None):
+    """x-only solve on the four-problems-per-wavefront kernel: x, ranks, first columns and pivots bit for bit against the oracle"""
+    s, ref = run_both(hip, oracle, lod, dims, n, maxdim=maxdim, keep_factor=False, force_generic=4)
+    assert s.last_kernel() == "lqr_quad<3,12>"
+    r, fc, tr = s.getRanks()
+    np.testing.assert_array_equal(r, ref["rank"])
+    np.testing.assert_array_equal(fc, ref["fcol"])
+    np.testing.assert_array_equal(tr, ref["totalrank"])
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    return s, ref
+
+
+@pytest.mark.parametrize("n,dims", [(47, [12, 12, 12, 12]), (30, [9, 12, 5]), (40, [6] * 5), (5, [12, 12]), (40, [12, 0, 12, 12, 12]), (12, [1] * 8),
+                                    (33, [11, 7, 12, 3]), (16, [12, 12]), (15, [8, 8]), (32, [12, 12, 12])])
+@pytest.mark.parametrize("batch", [13, 4, 1])
+def test_quad_kernel_shapes(hip, oracle, n, dims, batch):
+    """shapes around the 16-column slot boundaries, batches that leave rows of the last wavefront idle"""
+    _quad_x_only(hip, oracle, P.lse_batch(2000 + n, batch, n, dims), dims, n)
+
+
+def test_quad_kernel_rank_deficient_and_ragged(hip, oracle):
+    """rows of one wavefront stop at different pivots / have different level sizes: the masked elimination path and the frozen bookkeeping"""
+    n, dims, ranks = 15, [5, 5, 5, 5], [3, 3, 3, 3]
+    lod = np.stack([P.rank_deficient_problem(100 + b, n, dims, ranks) for b in range(24)])
+    _, ref = _quad_x_only(hip, oracle, lod, dims, n)
+    assert (ref["rank"] == ranks).all()
+    # a wavefront that mixes full-rank and rank-deficient problems
+    mixed = np.stack([P.rank_deficient_problem(300 + b, n, dims, [5, 5, 5, 0] if b % 3 else [2, 4, 1, 5]) for b in range(10)])
+    _quad_x_only(hip, oracle, mixed, dims, n)
+    n3, cap3 = 20, [8, 8, 8]
+    rd = np.array([[8, 8, 8], [3, 0, 5], [1, 8, 2], [0, 0, 4], [8, 1, 0], [5, 5, 5], [2, 2, 2], [7, 3, 8]], np.uint32)
+    full = np.zeros((8, n3 + 1, 24))
+    for b in range(8):
+        m = int(rd[b].sum())
+        full[b, :, :m] = P.lse_problem(900 + b, n3, rd[b])
+    _quad_x_only(hip, oracle, full, rd, n3, maxdim=np.array(cap3, np.uint32))
+
+
+def test_quad_kernel_tied_norms_and_degenerate_reflectors(hip, oracle):
+    """exact ties resolve to the first position; columns with a single non-zero give H = I (tau = 0) in some rows of a wavefront only"""
+    n, dims = 10, [4, 4, 4]
+    lod = P.lse_batch(77, 7, n, dims)
+    lod[:, 3, :] = lod[:, 1, :]
+    lod[:, 7, :] = lod[:, 1, :]
+    lod[:, 5, :] = -lod[:, 2, :]
+    _quad_x_only(hip, oracle, lod, dims, n)
+    n2, dims2 = 12, [6, 6]
+    lod2 = P.lse_batch(78, 9, n2, dims2)
+    lod2[::2, :n2, :6] = 0.0
+    for j in range(6):
+        lod2[::2, 2 * j, j] = 3.0 + j  # identity-like level in every other problem: degenerate reflectors next to regular ones
+    _quad_x_only(hip, oracle, lod2, dims2, n2)
 
 
 @pytest.mark.parametrize("policy", [3, 2], ids=["left-looking", "register-resident"])
@@ -472,7 +531,7 @@ def test_full_size_batch_4096(hip, oracle):
     s = hip.BatchedLexLSE(batch, n, dims)
     s.setProblem(lod)
     s.factorize_solve(keep_factor=False)
-    assert s.last_kernel() == "lqr_lwave<41,12,exact>"  # more problems than one round of the register-resident kernel holds
+    assert s.last_kernel() == "lqr_quad<3,12>"  # more problems than one round of the register-resident kernel holds: four per wavefront
     np.testing.assert_array_equal(s.get_x(), ref["x"])
     np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
     small = hip.BatchedLexLSE(1024, n, dims)
