@@ -4,7 +4,9 @@
 Workload (BASELINE.json configs[2] per GPU, configs[3] at 8 GPUs): 4096 IK-sized problems per GPU
 (n=40 variables, 5 levels x 12 rows, iid N(0,1), seed 20260100 + global problem id), resident in HBM
 before the timed region.  One "step" = one pass of the hot path (lexls_lse_factorize_solve, x-only
-traffic variant) over the rank's batch.  Multi-GPU: problems are independent, so the batch is sharded
+traffic variant) over ONE batch of 4096 problems; successive steps walk through --resident-batches (default 4)
+DIFFERENT resident batches, 322 MB in total — more than the 256 MiB Infinity Cache, so a step's reads are HBM
+reads, not re-reads of a cached batch (MI355X_MICROARCH.md, Infinity Cache).  Multi-GPU: problems are independent, so the batch is sharded
 by contiguous index blocks, one process per GPU, no data-path collective (weak scaling); the process
 group (RCCL) is used for the barriers around the timed region, the max-over-ranks of the elapsed time
 and a final all-gather of per-shard solution checksums.
@@ -25,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 NVAR, DIMS, PER_GPU_BATCH, SEED0 = 40, [12] * 5, 4096, 20260100
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz (the fp64 MFMA rate is the same)
+MIN_WARMUP = 20  # launches before the timed region, whatever --warmup says: clocks and caches in steady state
 
 
 def main():
@@ -34,6 +38,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="problems per GPU")
     ap.add_argument("--keep-factor", action="store_true", help="also write the factor to HBM (40,360 B/problem variant)")
+    ap.add_argument("--resident-batches", type=int, default=4, help="distinct batches resident in HBM that the steps rotate through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlapped", action="store_true", help="N=1: also time two half batches on two streams (extra field, never `value`); off by default so that\n                    the default command launches the bench kernel only as the timed step does (profiles/ hold rocprofv3 summaries of it)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -69,6 +74,10 @@ def main():
     first_id = rank * batch
     lod_host = P.lse_batch(SEED0 + first_id, batch, NVAR, DIMS)  # problem id -> seed 20260100 + id
     lod_dev = torch.from_numpy(lod_host).cuda()
+    # the other resident batches of this rank: same shape, fresh problem ids beyond the global batch of every rank
+    nres = max(1, args.resident_batches)
+    resident = [lod_dev] + [torch.from_numpy(P.lse_batch_fast(SEED0 + (j * world + rank) * batch + 7919 * j, batch, NVAR, DIMS)).cuda() for j in range(1, nres)]
+    ptrs = [t.data_ptr() for t in resident]
 
     stream = torch.cuda.Stream()
     solver = lexls_amd.BatchedLexLSE(batch, NVAR, DIMS, device=device_index)
@@ -80,19 +89,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step(i):
+        solver.setProblemDevice(ptrs[i % nres])  # zero-copy: the next resident batch becomes the problem data
+        solver.factorize_solve(keep_factor=args.keep_factor)
+
     with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            solver.factorize_solve(keep_factor=args.keep_factor)
+        for i in range(max(args.warmup, MIN_WARMUP)):
+            step(i)
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
-        for _ in range(args.steps):
-            solver.factorize_solve(keep_factor=args.keep_factor)
+        for i in range(args.steps):
+            step(i)
         ev1.record(stream)
         barrier()
         elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream: average launch duration
+    if (args.steps - 1) % nres != 0:  # leave the solutions of batch 0 behind for the guard and the scatter/gather check below
+        with torch.cuda.stream(stream):
+            step(0)
+        torch.cuda.synchronize()
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
@@ -101,7 +118,7 @@ def main():
 
     # correctness guard outside the timed region: solution checksum per shard, gathered on every rank
     x = solver.get_x()
-    ranks_ok = bool((solver.getRanks()[0] == np.array([12, 12, 12, 4, 0])).all())
+    ranks_ok = bool((solver.getRanks()[0] == np.array([12, 12, 12, 4, 0])).all())  # every problem of the batch
     checksum = torch.tensor([float(np.abs(x).sum()), float(ranks_ok)], dtype=torch.float64, device=coll_device)
     if world > 1:
         gathered = [torch.zeros_like(checksum) for _ in range(world)]
@@ -187,6 +204,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "warmup_run": max(args.warmup, MIN_WARMUP),
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
@@ -198,8 +216,13 @@ def main():
                        "variant": "factor kept in HBM" if args.keep_factor else "x-only", "kernel": solver.last_kernel()},
             "gflops_fp64": value * flops_per / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": _committed_traffic(args.keep_factor), "algorithmic_bytes_per_launch": bytes_per * batch,
-                         "kernel_ms": kernel_ms},
+                         "traffic": _committed_traffic(args.keep_factor), "traffic_source": "profiles/pmc_summary.json (committed rocprofv3 PMC passes of this command, corrected as the summary states)",
+                         "algorithmic_bytes_per_launch": bytes_per * batch, "kernel_ms": kernel_ms, "resident_batches": nres,
+                         "resident_bytes": int(nres * lod_host.nbytes)},
+            # the same launch against the fp64 vector peak (the path is issue-bound, not byte-bound: DESIGN.md section 5)
+            "roofline_fp64": {"bound": "fp64 vector", "achieved": flops_per * batch / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": flops_per * batch / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                              "flops_per_problem": flops_per},
         }
         if scatter_gather is not None:
             line["scatter_gather"] = scatter_gather
@@ -232,11 +255,14 @@ def cpu_baseline(lod_host, target_seconds):
     from oracle import oracle_ctypes as oc
     threads = max(1, oc.hardware_threads())
     sample = lod_host[:min(len(lod_host), 4096)]
-    t1, _ = oc.lse_time(sample, DIMS, NVAR, threads, 1)
-    repeats = int(max(1, min(2000, target_seconds / max(t1, 1e-6))))
+    t1, _ = oc.lse_time(sample, DIMS, NVAR, threads, 2)  # threads are started once per call and loop over their block (oracle_capi.cpp)
+    repeats = int(max(2, min(20000, 2 * target_seconds / max(t1, 1e-6))))
     t, _ = oc.lse_time(sample, DIMS, NVAR, threads, repeats)
+    ts, _ = oc.lse_time(sample[:256], DIMS, NVAR, 1, 8)  # one thread alone, for the per-thread rate without contention
     return {"value": len(sample) * repeats / t, "unit": "factorizations/s", "cores": threads, "kind": "port",
-            "sample": f"{repeats} passes over {len(sample)} problems of the bench batch ({t:.1f} s, g++ -O3 scalar restatement, {threads} std::threads)"}
+            "per_thread": len(sample) * repeats / t / threads, "single_thread_alone": 256 * 8 / ts,
+            "sample": f"{repeats} passes over {len(sample)} problems of the bench batch ({t:.1f} s, g++ -O3 scalar restatement, {threads} std::threads started once, "
+                      f"one solver object per thread)"}
 
 
 if __name__ == "__main__":

@@ -44,6 +44,8 @@ struct lexls_lse_s
     int force_generic;
     std::vector<uint32_t> maxdim, level_max;
     void *d_large_state;
+    void *d_large_ws; // work space of the fast large path
+    size_t large_ws_bytes;
     double *d_norms;
     double tol;
     bool dims_set, has_fixed, factor_valid, factor_in_hbm;
@@ -246,7 +248,7 @@ extern "C"
         if (!h) return LEXLS_OK;
         (void)hipSetDevice(h->device);
         void *ptrs[] = {h->d_in_owned, h->d_fac, h->d_hh, h->d_v, h->d_lambda, h->d_scratch, h->d_perm, h->d_rank, h->d_fcol, h->d_round_in, h->d_round_out,
-                        h->d_large_state, h->d_norms, h->d_cdata, h->d_reg_factor, h->d_reg_scratch};
+                        h->d_large_state, h->d_large_ws, h->d_norms, h->d_cdata, h->d_reg_factor, h->d_reg_scratch};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (h->h_dims_pinned) (void)hipHostFree(h->h_dims_pinned);
@@ -323,6 +325,7 @@ extern "C"
     int lexls_lse_set_tolerance(lexls_lse_t h, double tol)
     {
         CHECK_HANDLE(h);
+        if (tol != h->tol) h->factor_valid = false; // a factor / solution computed with the old tolerance must not be served any more
         h->tol = tol;
         return LEXLS_OK;
     }
@@ -625,12 +628,30 @@ extern "C"
         }
         else if (shape_kernels && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
         {
-            if (!h->d_large_state) HIP_TRY(hipMalloc(&h->d_large_state, large_state_bytes(h->batch)));
-            if (!h->d_norms) HIP_TRY(hipMalloc((void **)&h->d_norms, 8 * (size_t)h->batch * h->nVar));
-            HIP_TRY(launch_lqr_large(a, h->level_max.data(), h->max_rows, h->d_large_state, h->d_norms, h->stream));
+            if (h->force_generic == 5) // the bit-exact multi-launch path (ordered chains: parity tests, reference for the fast path)
+            {
+                if (!h->d_large_state) HIP_TRY(hipMalloc(&h->d_large_state, large_state_bytes(h->batch)));
+                if (!h->d_norms) HIP_TRY(hipMalloc((void **)&h->d_norms, 8 * (size_t)h->batch * h->nVar));
+                HIP_TRY(launch_lqr_large(a, h->level_max.data(), h->max_rows, h->d_large_state, h->d_norms, h->stream));
+                variant = "lqr_large<multi-launch>";
+            }
+            else
+            {
+                uint32_t md = 0;
+                for (uint32_t v : h->level_max) md = v > md ? v : md;
+                const size_t need = large_fast_workspace_bytes(h->batch, h->nVar, h->cap, md);
+                if (need > h->large_ws_bytes)
+                {
+                    if (h->d_large_ws) HIP_TRY(hipFree(h->d_large_ws));
+                    h->d_large_ws = nullptr;
+                    HIP_TRY(hipMalloc(&h->d_large_ws, need));
+                    h->large_ws_bytes = need;
+                }
+                HIP_TRY(launch_lqr_large_fast(a, h->level_max.data(), h->max_rows, h->d_large_ws, h->stream));
+                variant = "lqr_large<step-per-pivot,mfma>";
+            }
             if (do_solve) HIP_TRY(launch_solve_generic(a, h->stream));
             solved       = do_solve;
-            variant      = "lqr_large<multi-launch>";
             write_factor = true;
         }
         else

@@ -31,4 +31,6 @@ namespace lexls
     bool large_kernel_supports(const LseArgs &a, uint32_t max_level_dim, bool has_fixed);
     size_t large_state_bytes(uint32_t batch);
     hipError_t launch_lqr_large(const LseArgs &a, const uint32_t *h_level_max, uint32_t h_rows_max, void *d_state, double *d_norms, hipStream_t s);
+    size_t large_fast_workspace_bytes(uint32_t batch, uint32_t n, uint32_t cap, uint32_t maxdim);
+    hipError_t launch_lqr_large_fast(const LseArgs &a, const uint32_t *h_level_max, uint32_t h_rows_max, void *d_workspace, hipStream_t s);
 } // namespace lexls

@@ -501,12 +501,460 @@ namespace lexls
         }
     } // namespace
 
+    // =================================================================================================================
+    // FAST large path (default for problems beyond one CU's LDS; the multi-launch path above stays as the bit-exact reference
+    // behind lexls_lse_set_kernel_policy(h, 5)).
+    //
+    // north_star's contract for this path: pivots / ranks exact, x and residuals within 1e-10 — the 256-deep ORDERED chains of
+    // the bit-exact path (one per pivot for the fresh norm, one per trailing column for the reflector's dot product: ~1 us each,
+    // two dependent launches per pivot) are what costs 6.6 ms on configs[1].  Here
+    //   * ONE launch per pivot: every workgroup finds the pivot itself (first maximum of the down-dated norms by position — 4 KB of
+    //     L2 reads and a wave-level reduction, the same in every workgroup), forms the reflector from the pivot column with tree
+    //     sums, applies it to its own tile of trailing columns (two columns per wavefront, rows across lanes) and down-dates
+    //     their norms.  Nothing a launch reads is written by the same launch: norms, the position map and the state record are
+    //     double-buffered by step parity; the pivot column (beta, essential part) goes to a side buffer.
+    //   * columns are not moved during a level (position map, like the wave kernels); when the level ends ONE pass writes the
+    //     whole matrix in the level's final column order into the second factor buffer (the reference swaps whole columns,
+    //     lexlse.h:225) together with beta / the essential parts, so the Gauss step sees the layout of lexlse.h:431-471.
+    //   * Gauss step: the column-per-thread TRSM above, then the trailing update  T -= L U  on the matrix cores
+    //     (v_mfma_f64_16x16x4_f64, LDS-staged 64 x 64 x 16 tiles).  The instruction accumulates its four products in ascending
+    //     k as fused multiply-adds starting from C (scripts/ubench/mfma_order.hip), i.e. exactly the contract's chain: this
+    //     kernel is bit-identical to large_gemm and serves the bit-exact path as well.
+    // =================================================================================================================
+    namespace
+    {
+        typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+        template <int CTRL>
+        __device__ __forceinline__ double dpp_add(double v)
+        {
+            const int lo2 = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+            const int hi2 = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+            return v + __hiloint2double(hi2, lo2);
+        }
+        /// sum over the 64 lanes in a FIXED tree order (the same in every workgroup), wave-uniform result
+        __device__ __forceinline__ double wave_sum(double v)
+        {
+            v = dpp_add<0xB1>(v);
+            v = dpp_add<0x4E>(v);
+            v = dpp_add<0x141>(v);
+            v = dpp_add<0x140>(v);
+            return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+        }
+
+        constexpr int FTC = 8;         // columns per workgroup of the step kernel (two per wavefront)
+        constexpr int FRC = 4;         // rows a lane keeps in registers between the dot product and the update (R <= 64 * FRC)
+
+        struct FastBuffers
+        {
+            double *W[2];          // factor-sized work buffers, W[0] == a.fac
+            double *norms[2];      // batch x n
+            uint32_t *pos[2];      // batch x (n + 1): position of each physical column (entry n = RHS)
+            LargeState *st[2];     // batch
+            double *E;             // batch x eld x eld: essential parts, row q = pivot q of the level
+            uint32_t eld;          // largest level dimension of the batch
+            double *D;             // batch x n: beta by pivot position
+        };
+
+        __global__ __launch_bounds__(256) void fast_level_begin(LseArgs a, FastBuffers fb, uint32_t cur, uint32_t pp, uint32_t level)
+        {
+            const uint32_t b = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+            if (skipped(a, b)) return;
+            const uint32_t n = a.nVar, cap = a.cap;
+            const uint32_t *dims = a.dims + (size_t)b * a.nObj;
+            uint32_t F = 0;
+            for (uint32_t k = 0; k < level; k++) F += dims[k];
+            const uint32_t dim = dims[level];
+            LargeState *s      = fb.st[pp] + b;
+            const uint32_t c0  = s->ColIndex;
+            const double *W    = fb.W[cur] + (size_t)b * cap * (n + 1);
+            const uint32_t k   = blockIdx.x * 4 + wave; // one column per wavefront
+            if (k <= n)
+            {
+                if (lane == 0) fb.pos[pp][(size_t)b * (n + 1) + k] = k; // the buffer is in position order when a level starts
+                if (k < n && k >= c0 && !s->exhausted)
+                {
+                    double acc = 0.0;
+                    for (uint32_t i = lane; i < dim; i += 64)
+                    {
+                        const double w = W[F + i + (size_t)k * cap];
+                        acc            = dfma(w, w, acc);
+                    }
+                    acc = wave_sum(acc);
+                    if (lane == 0) fb.norms[pp][(size_t)b * n + k] = acc;
+                }
+            }
+            __syncthreads(); // the state record is read above by every thread of this workgroup before thread 0 of block 0 rewrites it
+            if (blockIdx.x == 0 && tid == 0)
+            {
+                s->F          = F;
+                s->dim        = dim;
+                s->Fc         = c0;
+                s->rank       = 0;
+                s->stop_level = 0;
+            }
+        }
+
+        /// one pivot of the level: search, reflector, application to this workgroup's tile, norm down-date
+        __global__ __launch_bounds__(256) void fast_step(LseArgs a, FastBuffers fb, uint32_t cur, uint32_t pin, uint32_t counter)
+        {
+            extern __shared__ double smem[];
+            __shared__ double red_v[4];
+            __shared__ uint32_t red_p[4], red_i[4];
+            __shared__ double sums[8];
+            const uint32_t b = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+            if (skipped(a, b)) return;
+            const uint32_t pout = pin ^ 1u;
+            const LargeState s  = fb.st[pin][b];
+            LargeState *so      = fb.st[pout] + b;
+            const bool owner    = blockIdx.x == 0;
+            if (s.exhausted || s.stop_level || counter >= s.dim)
+            {
+                if (owner && tid == 0) *so = s;
+                return;
+            }
+            const uint32_t n = a.nVar, cap = a.cap;
+            double *W              = fb.W[cur] + (size_t)b * cap * (n + 1);
+            const double *norms_in = fb.norms[pin] + (size_t)b * n;
+            double *norms_out      = fb.norms[pout] + (size_t)b * n;
+            const uint32_t *pos_in = fb.pos[pin] + (size_t)b * (n + 1);
+            uint32_t *pos_out      = fb.pos[pout] + (size_t)b * (n + 1);
+            const uint32_t c = s.ColIndex, row = s.F + counter, R = s.dim - counter;
+            double *colv = smem;     // R: the pivot column
+            double *es   = smem + R; // R: essential part (es[i], i >= 1)
+
+            // ---- first maximum, by position, of the down-dated norms (lexlse.h:205-206): every workgroup for itself ----
+            double bv   = -1.0;
+            uint32_t bp = 0xffffffffu, bi = 0;
+            for (uint32_t k = tid; k < n; k += 256)
+            {
+                const uint32_t p = pos_in[k];
+                if (p >= c)
+                {
+                    const double v = norms_in[k];
+                    if (v > bv || (v == bv && p < bp))
+                    {
+                        bv = v;
+                        bp = p;
+                        bi = k;
+                    }
+                }
+            }
+            {
+                const double wm         = wave_max(bv);
+                unsigned long long tied = __ballot(bv == wm && bp != 0xffffffffu);
+                uint32_t bestp = 0xffffffffu, besti = 0;
+                while (tied) // more than one lane only on exact ties
+                {
+                    const int l = (int)__builtin_ctzll(tied);
+                    tied &= tied - 1;
+                    const uint32_t p2 = (uint32_t)__builtin_amdgcn_readlane((int)bp, l);
+                    const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane((int)bi, l);
+                    if (p2 < bestp)
+                    {
+                        bestp = p2;
+                        besti = i2;
+                    }
+                }
+                if (lane == 0)
+                {
+                    red_v[wave] = wm;
+                    red_p[wave] = bestp;
+                    red_i[wave] = besti;
+                }
+            }
+            __syncthreads();
+            double v0   = red_v[0];
+            uint32_t p0 = red_p[0], piv = red_i[0];
+#pragma unroll
+            for (int w = 1; w < 4; w++)
+            {
+                const double v2   = red_v[w];
+                const uint32_t p2 = red_p[w];
+                if (p2 != 0xffffffffu && (p0 == 0xffffffffu || v2 > v0 || (v2 == v0 && p2 < p0)))
+                {
+                    v0  = v2;
+                    p0  = p2;
+                    piv = red_i[w];
+                }
+            }
+            const uint32_t ppos = p0; // position of the pivot column before the swap = column_permutations entry
+
+            // ---- the pivot column, its fresh norm and tail norm (lexlse.h:210-211, :241) ----
+            double fr = 0.0, tl = 0.0;
+            for (uint32_t i = tid; i < R; i += 256)
+            {
+                const double w = W[row + i + (size_t)piv * cap];
+                colv[i]        = w;
+                fr             = dfma(w, w, fr);
+                if (i > 0) tl = dfma(w, w, tl);
+            }
+            fr = wave_sum(fr);
+            tl = wave_sum(tl);
+            if (lane == 0)
+            {
+                sums[wave]     = fr;
+                sums[4 + wave] = tl;
+            }
+            __syncthreads();
+            const double fresh  = (sums[0] + sums[1]) + (sums[2] + sums[3]);
+            const double tailSq = (sums[4] + sums[5]) + (sums[6] + sums[7]);
+            if (fresh < a.tol) // rank test on the squared norm (lexlse.h:214): the level ends here
+            {
+                if (owner && tid == 0)
+                {
+                    *so            = s;
+                    so->stop_level = 1;
+                }
+                return;
+            }
+            const double c0v = colv[0];
+            double tau = 0.0, diag = c0v, den = 1.0;
+            bool degenerate = true;
+            if (R > 1 && !(tailSq <= DBL_MIN))
+            {
+                degenerate  = false;
+                double beta = sqrt(dfma(c0v, c0v, tailSq));
+                if (c0v >= 0.0) beta = -beta;
+                diag = beta;
+                den  = c0v - beta;
+                tau  = (beta - c0v) / beta;
+            }
+            for (uint32_t i = 1 + tid; i < R; i += 256) es[i] = degenerate ? 0.0 : colv[i] / den;
+            __syncthreads();
+
+            // ---- this workgroup's tile: two columns per wavefront, rows across the lanes ----
+            const uint32_t posf = pos_in[piv]; // == ppos
+#pragma unroll
+            for (int h = 0; h < FTC / 4; h++)
+            {
+                const uint32_t j = blockIdx.x * FTC + wave * (FTC / 4) + h;
+                if (j > n) continue; // wave-uniform
+                uint32_t pj = (j == n) ? n : pos_in[j];
+                // the swap of lexlse.h:222-232 on the position map
+                uint32_t pnew = pj;
+                if (j < n)
+                {
+                    if (j == piv)
+                        pnew = c;
+                    else if (pj == c)
+                        pnew = posf;
+                }
+                if (lane == 0 && j <= n) pos_out[j] = pnew;
+                const bool trailing = (j == n) || pnew > c;
+                if (!trailing)
+                {
+                    if (lane == 0 && j < n) norms_out[j] = norms_in[j];
+                    continue;
+                }
+                double *col = W + row + (size_t)j * cap;
+                double a0n;
+                if (tau != 0.0)
+                {
+                    double keep[FRC];
+                    double part = 0.0;
+#pragma unroll
+                    for (int u = 0; u < FRC; u++)
+                    {
+                        const uint32_t i = lane + 64u * u;
+                        keep[u]          = (i < R) ? col[i] : 0.0;
+                        if (i >= 1 && i < R) part = dfma(es[i], keep[u], part);
+                    }
+                    for (uint32_t i = lane + 64u * FRC; i < R; i += 64) part = dfma(es[i], col[i], part);
+                    const double a0  = rdlane(keep[0], 0);
+                    const double tmp = wave_sum(part) + a0; // applyHouseholderOnTheLeft (lexlse.h:243-246)
+                    const double nt  = -tau;
+                    a0n              = dfma(nt, tmp, a0);
+#pragma unroll
+                    for (int u = 0; u < FRC; u++)
+                    {
+                        const uint32_t i = lane + 64u * u;
+                        if (i < R) col[i] = (i == 0) ? a0n : dfma(es[i] * nt, tmp, keep[u]);
+                    }
+                    for (uint32_t i = lane + 64u * FRC; i < R; i += 64) col[i] = dfma(es[i] * nt, tmp, col[i]);
+                }
+                else
+                    a0n = col[0];
+                if (lane == 0 && j < n) norms_out[j] = dfma(-a0n, a0n, norms_in[j]); // lexlse.h:262-266
+            }
+
+            // ---- bookkeeping of the pivot: one workgroup ----
+            if (owner)
+            {
+                double *E = fb.E + ((size_t)b * fb.eld + counter) * fb.eld; // row `counter` of this level's essential parts
+                for (uint32_t i = 1 + tid; i < R; i += 256) E[i] = es[i];
+                if (tid == 0)
+                {
+                    fb.D[(size_t)b * n + c]     = diag;
+                    a.perm[(size_t)b * n + c]   = ppos;
+                    if (R > 1) a.hh[(size_t)b * cap + row] = tau;
+                    *so            = s;
+                    so->ColIndex   = c + 1;
+                    so->rank       = s.rank + 1;
+                    so->exhausted  = (c + 1 == n) ? 1u : 0u;
+                }
+            }
+        }
+
+        /// level end: rank / first column, then the whole matrix in the level's final column order -> the other work buffer
+        __global__ __launch_bounds__(256) void fast_level_end(LseArgs a, FastBuffers fb, uint32_t cur, uint32_t pp, uint32_t level)
+        {
+            const uint32_t b = blockIdx.z;
+            if (skipped(a, b)) return;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            uint32_t M           = 0;
+            for (uint32_t k = 0; k < nObj; k++) M += dims[k];
+            const LargeState *s = fb.st[pp] + b;
+            const uint32_t F = s->F, dim = s->dim, Fc = s->Fc, rank = s->rank;
+            const uint32_t j = blockIdx.y; // physical column
+            const uint32_t p = (j == n) ? n : fb.pos[pp][(size_t)b * (n + 1) + j];
+            const double *src = fb.W[cur] + (size_t)b * cap * (n + 1) + (size_t)j * cap;
+            double *dst       = fb.W[cur ^ 1u] + (size_t)b * cap * (n + 1) + (size_t)p * cap;
+            const bool pivcol = j < n && p >= Fc && p < Fc + rank;
+            const uint32_t q  = p - Fc; // pivot index inside the level (pivot q was made at step q)
+            const double *E   = fb.E + ((size_t)b * fb.eld + (pivcol ? q : 0)) * fb.eld;
+            for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256)
+            {
+                double v = src[i];
+                if (pivcol && i >= F + q && i < F + dim)
+                    v = (i == F + q) ? fb.D[(size_t)b * n + p] : E[i - (F + q)];
+                dst[i] = v;
+            }
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+            {
+                a.rank[(size_t)b * nObj + level] = rank;
+                a.fcol[(size_t)b * nObj + level] = Fc;
+            }
+        }
+
+        __global__ void fast_level_commit(LseArgs a, FastBuffers fb, uint32_t pp)
+        {
+            const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+            if (b >= a.batch || skipped(a, b)) return;
+            LargeState *s = fb.st[pp] + b;
+            s->totalrank += s->rank;
+            s->stop_level  = 0;
+            a.totalrank[b] = s->totalrank;
+        }
+
+        __global__ __launch_bounds__(256) void fast_copy_back(LseArgs a, FastBuffers fb, uint32_t cur)
+        {
+            const uint32_t b = blockIdx.y;
+            if (skipped(a, b)) return;
+            const size_t ps   = (size_t)a.cap * (a.nVar + 1);
+            const double *src = fb.W[cur] + b * ps;
+            double *dst       = fb.W[0] + b * ps;
+            for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < ps; e += (size_t)gridDim.x * 256) dst[e] = src[e];
+        }
+
+        /// Trailing -= L * Up (lexlse.h:454-469) on the matrix cores: 64 x 64 output block per workgroup, K in steps of 16 through LDS.
+        /// acc = C, then for p ascending acc = fma(-L[i][p], U[p][j], acc): v_mfma_f64_16x16x4_f64 does exactly that for four p at a time.
+        constexpr int GBM = 64, GBN = 64, GBK = 16;
+        __global__ __launch_bounds__(256) void large_gemm_mfma(LseArgs a, const LargeState *st, uint32_t level)
+        {
+            __shared__ double As[GBK * GBM]; // As[k][i] = -L[i][k]
+            __shared__ double Bs[GBK * GBN]; // Bs[k][j] =  U[k][j]
+            const uint32_t b = blockIdx.z, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+            if (skipped(a, b)) return;
+            const LargeState *s = st + b;
+            const uint32_t rank = s->rank;
+            if (rank == 0 || level + 1 >= a.nObj) return;
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            uint32_t M           = 0;
+            for (uint32_t k = 0; k < nObj; k++) M += dims[k];
+            const uint32_t F = s->F, Fc = s->Fc, Fn = F + s->dim, c = s->ColIndex;
+            const uint32_t gi0 = Fn + blockIdx.x * GBM; // first row of the block
+            const uint32_t j0  = c + blockIdx.y * GBN;  // first column of the block
+            if (gi0 >= M || j0 > n) return;            // uniform per workgroup
+            double *W = a.fac + (size_t)b * cap * (n + 1);
+
+            // accumulators: tile t = columns j0 + 16 t .. +15, rows gi0 + 16 wave .. +15; lane l, entry r: row (l / 16) + 4 r, column l % 16
+            const uint32_t ri = gi0 + 16 * wave + (lane >> 4);
+            v4f64 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+            {
+                const uint32_t j = j0 + 16 * t + (lane & 15u);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[t][r] = (j <= n && ri + 4 * r < M) ? W[ri + 4 * r + (size_t)j * cap] : 0.0;
+            }
+            const uint32_t K4 = rank & ~3u;
+            for (uint32_t k0 = 0; k0 < K4; k0 += GBK)
+            {
+                __syncthreads();
+                // stage: 256 threads, 4 elements each per operand (coalesced along the rows of W)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    const uint32_t i = tid & 63u, k = (tid >> 6) + 4 * u; // A: 64 rows x 16 k
+                    As[k * GBM + i]  = (gi0 + i < M && k0 + k < K4) ? -W[gi0 + i + (size_t)(Fc + k0 + k) * cap] : 0.0;
+                    const uint32_t kb = tid & 15u, jb = (tid >> 4) + 16 * u; // B: 16 k x 64 columns
+                    Bs[kb * GBN + jb] = (j0 + jb <= n && k0 + kb < K4) ? W[F + k0 + kb + (size_t)(j0 + jb) * cap] : 0.0;
+                }
+                __syncthreads();
+                const uint32_t ksteps = (K4 - k0 < (uint32_t)GBK ? K4 - k0 : (uint32_t)GBK) / 4;
+                for (uint32_t ks = 0; ks < ksteps; ks++)
+                {
+                    const double af = As[(4 * ks + (lane >> 4)) * GBM + 16 * wave + (lane & 15u)];
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                    {
+                        const double bf = Bs[(4 * ks + (lane >> 4)) * GBN + 16 * t + (lane & 15u)];
+                        acc[t]          = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            // the last rank % 4 pivots: plain fma's on the accumulator layout
+            for (uint32_t p = K4; p < rank; p++)
+            {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                {
+                    const uint32_t j = j0 + 16 * t + (lane & 15u);
+                    const double u   = (j <= n) ? W[F + p + (size_t)j * cap] : 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                    {
+                        const double l = (ri + 4 * r < M) ? W[ri + 4 * r + (size_t)(Fc + p) * cap] : 0.0;
+                        acc[t][r]      = dfma(-l, u, acc[t][r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+            {
+                const uint32_t j = j0 + 16 * t + (lane & 15u);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (j <= n && ri + 4 * r < M) W[ri + 4 * r + (size_t)j * cap] = acc[t][r];
+            }
+        }
+    } // namespace
+
+    namespace
+    {
+        /// dynamic LDS of the three kernels that stage in LDS, for the largest level dimension of the batch (ONE formula for the
+        /// dispatcher's question "does it fit" and for the launch)
+        struct LargeLds
+        {
+            size_t piv, app, trsm;
+        };
+        inline LargeLds large_lds_bytes(uint32_t n, uint32_t maxdim)
+        {
+            LargeLds l;
+            l.piv  = 8 * ((size_t)((maxdim + 1) & ~1u) + 1024 + 16) + 4 * 1024;
+            l.app  = 8 * ((size_t)TC * (maxdim | 1u) + maxdim + TC + 2);
+            l.trsm = 8 * (size_t)((n < maxdim) ? n : maxdim) * 65;
+            return l;
+        }
+    } // namespace
+
     bool large_kernel_supports(const LseArgs &a, uint32_t max_level_dim, bool has_fixed)
     {
-        const size_t trsm_lds = 8 * (size_t)((a.nVar < max_level_dim) ? a.nVar : max_level_dim) * 65;
-        const size_t piv_lds  = 8 * ((size_t)max_level_dim + 2 + 1024 + 16) + 4 * 1024;
-        const size_t app_lds  = 8 * ((size_t)TC * (max_level_dim | 1u) + max_level_dim);
-        return !has_fixed && trsm_lds <= kMaxLdsBytes && piv_lds <= kMaxLdsBytes && app_lds <= kMaxLdsBytes && max_level_dim < 65536 && a.nObj < 65536;
+        const LargeLds l = large_lds_bytes(a.nVar, max_level_dim);
+        return !has_fixed && l.trsm <= kMaxLdsBytes && l.piv <= kMaxLdsBytes && l.app <= kMaxLdsBytes && max_level_dim < 65536 && a.nObj < 65536;
     }
 
     size_t large_state_bytes(uint32_t batch) { return sizeof(LargeState) * (size_t)batch; }
@@ -522,9 +970,8 @@ namespace lexls
         };
         uint32_t maxdim = 0;
         for (uint32_t k = 0; k < a.nObj; k++) maxdim = h_level_max[k] > maxdim ? h_level_max[k] : maxdim;
-        const size_t piv_lds  = 8 * ((size_t)((maxdim + 1) & ~1u) + 1024 + 16) + 4 * 1024;
-        const size_t app_lds  = 8 * ((size_t)TC * (maxdim | 1u) + maxdim + TC + 2);
-        const size_t trsm_lds = 8 * (size_t)((n < maxdim) ? n : maxdim) * 65;
+        const LargeLds lds    = large_lds_bytes(n, maxdim);
+        const size_t piv_lds = lds.piv, app_lds = lds.app, trsm_lds = lds.trsm;
         set_lds(reinterpret_cast<const void *>(large_pivot), piv_lds);
         set_lds(reinterpret_cast<const void *>(large_apply), app_lds);
         set_lds(reinterpret_cast<const void *>(large_trsm), trsm_lds);
@@ -533,7 +980,6 @@ namespace lexls
         hipLaunchKernelGGL(large_init, dim3(64, B), dim3(256), 0, s, a, st);
         std::vector<LargeState> host(B);
         bool all_exhausted = false;
-        uint32_t rows_seen = 0;
         for (uint32_t level = 0; level < a.nObj; level++)
         {
             hipLaunchKernelGGL(large_level_begin, dim3((n + 63) / 64, B), dim3(64), 0, s, a, st, d_norms, level);
@@ -544,15 +990,16 @@ namespace lexls
                     hipLaunchKernelGGL(large_apply, dim3((n + TC) / TC, B), dim3(256), app_lds, s, a, st, d_norms, level, counter);
                 }
             hipLaunchKernelGGL(large_level_end, dim3((B + 63) / 64), dim3(64), 0, s, a, st, level);
-            rows_seen += h_level_max[level];
-            const uint32_t below = h_rows_max > rows_seen ? h_rows_max - rows_seen : 0;
+            // rows below the level: a ragged batch may hold a problem with small early levels and many rows below — the grid spans the
+            // largest row count of the batch, workgroups beyond a problem's own rows return at once (r0 >= M)
+            const uint32_t below = h_rows_max;
             if (level + 1 < a.nObj && below > 0)
             {
                 if (h_level_max[level] <= 1024)
                     hipLaunchKernelGGL(large_trsm_cols, dim3((below + TRB - 1) / TRB, B), dim3(((h_level_max[level] + 63) / 64) * 64), 0, s, a, st, level);
                 else
                     hipLaunchKernelGGL(large_trsm, dim3((below + 63) / 64, B), dim3(64), trsm_lds, s, a, st, level);
-                hipLaunchKernelGGL(large_gemm, dim3((below + 63) / 64, (n + TJ) / TJ, B), dim3(64), 0, s, a, st, level);
+                hipLaunchKernelGGL(large_gemm_mfma, dim3((below + GBM - 1) / GBM, (n + GBN) / GBN, B), dim3(256), 0, s, a, st, level); // bit-identical to large_gemm
             }
             e = hipGetLastError();
             if (e != hipSuccess) return e;
@@ -568,6 +1015,92 @@ namespace lexls
             }
         }
         hipLaunchKernelGGL(large_finish, dim3((B + 63) / 64), dim3(64), 0, s, a, st);
+        return hipGetLastError();
+    }
+    size_t large_fast_workspace_bytes(uint32_t batch, uint32_t n, uint32_t cap, uint32_t maxdim)
+    {
+        const size_t ps = (size_t)cap * (n + 1);
+        return 8 * ((size_t)batch * ps + 3 * (size_t)batch * n + (size_t)batch * maxdim * maxdim) + 4 * 2 * (size_t)batch * (n + 1) + 2 * sizeof(LargeState) * (size_t)batch + 256;
+    }
+
+    /// the fast large path (see the comment above fast_level_begin); gemm_only_mfma: the bit-exact multi-launch path with its trailing update on the matrix cores
+    hipError_t launch_lqr_large_fast(const LseArgs &a, const uint32_t *h_level_max, uint32_t h_rows_max, void *d_ws, hipStream_t s)
+    {
+        const uint32_t B = a.batch, n = a.nVar, cap = a.cap;
+        uint32_t maxdim  = 0;
+        for (uint32_t k = 0; k < a.nObj; k++) maxdim = h_level_max[k] > maxdim ? h_level_max[k] : maxdim;
+        const size_t ps = (size_t)cap * (n + 1);
+        FastBuffers fb;
+        char *w      = static_cast<char *>(d_ws);
+        fb.W[0]      = a.fac;
+        fb.W[1]      = reinterpret_cast<double *>(w);
+        w += 8 * (size_t)B * ps;
+        fb.norms[0] = reinterpret_cast<double *>(w);
+        w += 8 * (size_t)B * n;
+        fb.norms[1] = reinterpret_cast<double *>(w);
+        w += 8 * (size_t)B * n;
+        fb.D = reinterpret_cast<double *>(w);
+        w += 8 * (size_t)B * n;
+        fb.E = reinterpret_cast<double *>(w);
+        w += 8 * (size_t)B * maxdim * maxdim;
+        fb.eld   = maxdim;
+        fb.st[0] = reinterpret_cast<LargeState *>(w);
+        w += sizeof(LargeState) * (size_t)B;
+        fb.st[1] = reinterpret_cast<LargeState *>(w);
+        w += sizeof(LargeState) * (size_t)B;
+        fb.pos[0] = reinterpret_cast<uint32_t *>(w);
+        w += 4 * (size_t)B * (n + 1);
+        fb.pos[1] = reinterpret_cast<uint32_t *>(w);
+
+        hipError_t e         = hipSuccess;
+        const size_t step_lds = 16 * (size_t)maxdim;
+        const LargeLds lds    = large_lds_bytes(n, maxdim);
+        if (step_lds > kMaxLdsBytes) return hipErrorInvalidValue;
+        if (step_lds > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(fast_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds);
+        if (e == hipSuccess && lds.trsm > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(large_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.trsm);
+        if (e != hipSuccess) return e;
+
+        hipLaunchKernelGGL(large_init, dim3(64, B), dim3(256), 0, s, a, fb.st[0]);
+        std::vector<LargeState> host(B);
+        bool all_exhausted = false;
+        uint32_t cur = 0, pp = 0;
+        for (uint32_t level = 0; level < a.nObj; level++)
+        {
+            hipLaunchKernelGGL(fast_level_begin, dim3((n + 4) / 4, B), dim3(256), 0, s, a, fb, cur, pp, level);
+            if (!all_exhausted)
+                for (uint32_t counter = 0; counter < h_level_max[level]; counter++)
+                {
+                    hipLaunchKernelGGL(fast_step, dim3((n + FTC) / FTC, B), dim3(256), step_lds, s, a, fb, cur, pp, counter);
+                    pp ^= 1u;
+                }
+            hipLaunchKernelGGL(fast_level_end, dim3((h_rows_max + 1023) / 1024, n + 1, B), dim3(256), 0, s, a, fb, cur, pp, level);
+            cur ^= 1u;
+            hipLaunchKernelGGL(fast_level_commit, dim3((B + 63) / 64), dim3(64), 0, s, a, fb, pp);
+            if (level + 1 < a.nObj && h_rows_max > 0)
+            {
+                LseArgs ac = a;
+                ac.fac     = fb.W[cur];
+                if (h_level_max[level] <= 1024)
+                    hipLaunchKernelGGL(large_trsm_cols, dim3((h_rows_max + TRB - 1) / TRB, B), dim3(((h_level_max[level] + 63) / 64) * 64), 0, s, ac, fb.st[pp], level);
+                else
+                    hipLaunchKernelGGL(large_trsm, dim3((h_rows_max + 63) / 64, B), dim3(64), lds.trsm, s, ac, fb.st[pp], level);
+                hipLaunchKernelGGL(large_gemm_mfma, dim3((h_rows_max + GBM - 1) / GBM, (n + GBN) / GBN, B), dim3(256), 0, s, ac, fb.st[pp], level);
+            }
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            if (!all_exhausted && level + 1 < a.nObj)
+            {
+                e = hipMemcpyAsync(host.data(), fb.st[pp], sizeof(LargeState) * B, hipMemcpyDeviceToHost, s);
+                if (e != hipSuccess) return e;
+                e = hipStreamSynchronize(s);
+                if (e != hipSuccess) return e;
+                all_exhausted = (a.skip == nullptr);
+                for (uint32_t b = 0; b < B && all_exhausted; b++)
+                    if (!host[b].exhausted) all_exhausted = false;
+            }
+        }
+        if (cur != 0) hipLaunchKernelGGL(fast_copy_back, dim3(64, B), dim3(256), 0, s, a, fb, cur);
+        hipLaunchKernelGGL(large_finish, dim3((B + 63) / 64), dim3(64), 0, s, a, fb.st[pp]);
         return hipGetLastError();
     }
 } // namespace lexls

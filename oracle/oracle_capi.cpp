@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdint>
 #include <lexls/lsi_runner.h>
+#include <atomic>
 #include <thread>
 
 using namespace LexLS;
@@ -195,14 +196,42 @@ extern "C"
         }
     }
 
-    /// wall-clock seconds for `repeats` passes of factorize+solve over the batch (x written to `x`)
+    /// wall-clock seconds for `repeats` passes of factorize+solve over the batch (x written to `x`).  The threads are started ONCE: each
+    /// allocates its solver once and loops over its block of problems `repeats` times (a pass per spawn would time thread creation and
+    /// the allocations of resize(), not the factorizations); the clock starts when every thread is ready and stops when the last one is done
     double oracle_lse_time(uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *maxdim, const uint32_t *dims, const double *lod, double tol,
                            double *x, int nthreads, int repeats)
     {
+        LseBatchArgs a = {batch, nVar, nObj, maxdim, dims, lod, tol, NULL, NULL, NULL, NULL, NULL, 0, -1, 0, 0, x, NULL, NULL, NULL, NULL, NULL, NULL, NULL,
+                          NULL, NULL, NULL, NULL};
+        if (nthreads < 1) nthreads = 1;
+        if ((uint32_t)nthreads > batch) nthreads = (int)batch;
+        std::atomic<int> ready(0);
+        std::atomic<bool> go(false);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++)
+        {
+            const uint32_t b0 = static_cast<uint32_t>(static_cast<uint64_t>(batch) * t / nthreads);
+            const uint32_t b1 = static_cast<uint32_t>(static_cast<uint64_t>(batch) * (t + 1) / nthreads);
+            th.emplace_back([&a, &ready, &go, b0, b1, repeats]() {
+                std::vector<Index> md(a.maxdim, a.maxdim + a.nObj);
+                uint32_t cap = 0;
+                for (uint32_t k = 0; k < a.nObj; k++) cap += md[k];
+                OLSE lse;
+                lse.resize(a.nVar, a.nObj, md.data());
+                ParametersLexLSE p;
+                p.tol_linear_dependence = a.tol;
+                lse.setParameters(p);
+                ready.fetch_add(1);
+                while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+                for (int r = 0; r < repeats; r++)
+                    for (uint32_t b = b0; b < b1; b++) run_one(a, b, lse, cap);
+            });
+        }
+        while (ready.load() < nthreads) std::this_thread::yield();
         const auto t0 = std::chrono::steady_clock::now();
-        for (int r = 0; r < repeats; r++)
-            oracle_lse_run(batch, nVar, nObj, maxdim, dims, lod, tol, NULL, NULL, NULL, NULL, NULL, 0, -1, 0, 0, x, NULL, NULL, NULL, NULL, NULL, NULL, NULL,
-                           NULL, NULL, NULL, NULL, nthreads);
+        go.store(true, std::memory_order_release);
+        for (auto &t : th) t.join();
         return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
 

@@ -198,7 +198,7 @@ def test_random_large_path_sweep(hip, oracle, chunk):
         if rng.random() < 0.5:
             i, j = rng.integers(0, cap, 2)
             lod[0, :, i] = lod[0, :, j]
-        policy = int(rng.choice([0, 0, 1]))
+        policy = int(rng.choice([0, 5, 1]))
         ref = oracle.lse_run(lod, dims, n)
         s = hip.BatchedLexLSE(1, n, dims)
         s.set_kernel_policy(policy)
@@ -208,6 +208,10 @@ def test_random_large_path_sweep(hip, oracle, chunk):
         ctx = f"chunk {chunk} case {case}: n={n} dims={dims.tolist()} policy={policy} kernel={s.last_kernel()}"
         np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"], err_msg=ctx)
         np.testing.assert_array_equal(s.getRanks()[0], ref["rank"], err_msg=ctx)
-        np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
-        assert_factor_equal(s, ref, dims, n)
+        if "step-per-pivot" in s.last_kernel():  # tree sums: pivots / ranks exact (above), values within north_star's 1e-10
+            assert np.abs(s.get_x() - ref["x"]).max() <= 1e-10, ctx
+            assert np.abs(s.get_lexqr()[0, :, :cap] - ref["factor"][0, :, :cap]).max() <= 1e-10, ctx
+        else:
+            np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
+            assert_factor_equal(s, ref, dims, n)
     assert any("large" in k for k in seen), seen
