@@ -1,3 +1,24 @@
+/*
+ * Derived work: this header restates, for a different equality-solver back end, host-side interface and control flow of
+ * jrl-umi3218/lexls (include/lexls/lexlsi.h), whose notice is retained as its BSD 3-clause licence requires:
+ *
+ * Copyright 2013-2021 INRIA
+ *
+ * Redistribution and use in source and binary forms, with or without modification, are permitted provided that the following
+ * conditions are met:
+ * 1. Redistributions of source code must retain the above copyright notice, this list of conditions and the following disclaimer.
+ * 2. Redistributions in binary form must reproduce the above copyright notice, this list of conditions and the following disclaimer
+ *    in the documentation and/or other materials provided with the distribution.
+ * 3. Neither the name of the copyright holder nor the names of its contributors may be used to endorse or promote products derived
+ *    from this software without specific prior written permission.
+ *
+ * THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED WARRANTIES, INCLUDING, BUT
+ * NOT LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE DISCLAIMED. IN NO EVENT SHALL
+ * THE COPYRIGHT HOLDER OR CONTRIBUTORS BE LIABLE FOR ANY DIRECT, INDIRECT, INCIDENTAL, SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES
+ * (INCLUDING, BUT NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES; LOSS OF USE, DATA, OR PROFITS; OR BUSINESS
+ * INTERRUPTION) HOWEVER CAUSED AND ON ANY THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT (INCLUDING NEGLIGENCE
+ * OR OTHERWISE) ARISING IN ANY WAY OUT OF THE USE OF THIS SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
+ */
 // Primal active-set driver for lexicographic least-squares with inequalities (host side).
 //
 // North star: "LexLSI's outer active-set loop is kept on the host"; the equality solver it calls
@@ -94,24 +115,13 @@ namespace LexLS
                 nDeactivations++;
             }
 
-            /// lexlsi.h:205-246
+            /// lexlsi.h:205-246.  ONE form of the driver: the resumable state machine below (begin / advance), which cuts an iteration
+            /// (the reference's verifyWorkingSet, lexlsi.h:1144-1265) at the points where the equality solver is used; a stand-alone
+            /// equality solver computes on the spot there, a lock-step batch serves the pending requests of all its instances first.
             TerminationStatus solve()
             {
-                if (parameters.use_phase1_v0)
-                    phase1_v0();
-                else
-                    phase1();
-
-                while (true)
-                {
-                    verifyWorkingSet();
-                    if (status == PROBLEM_SOLVED || status == PROBLEM_SOLVED_CYCLING_HANDLING) break;
-                    if (nFactorizations >= parameters.max_number_of_factorizations)
-                    {
-                        status = MAX_NUMBER_OF_FACTORIZATIONS_EXCEEDED;
-                        break;
-                    }
-                }
+                begin();
+                while (!finished()) advance();
                 return status;
             }
 
@@ -365,82 +375,10 @@ namespace LexLS
                 for (Index k = 0; k < nObj; k++) objectives[k].formStep(dx);
             }
 
-            /// lexlsi.h:1144-1265: one iteration of the active-set method
-            OperationType verifyWorkingSet()
-            {
-                Index ObjIndex2Manipulate = 0, CtrIndex2Manipulate = 0;
-                ConstraintActivationType CtrType2Manipulate = CTR_INACTIVE;
-                bool normalIteration                        = true;
-                OperationType operation                     = OPERATION_UNDEFINED;
-                ConstraintIdentifier constraint_identifier(0, 0, CTR_INACTIVE, 0);
-                RealScalar alpha;
-                bool cycling_detected;
-
-                if (nIterations != 0)
-                {
-                    formLexLSE();
-                    lexlse.factorize();
-                    lexlse.solve();
-                    lexlse_rank = getTotalRank();
-                    formStep();
-                    nFactorizations++;
-                }
-                else if (parameters.use_phase1_v0)
-                {
-                    normalIteration = false;
-                }
-
-                if (checkBlockingConstraints(ObjIndex2Manipulate, CtrIndex2Manipulate, CtrType2Manipulate, alpha))
-                {
-                    if (parameters.cycling_handling_enabled) constraint_identifier.set(ObjIndex2Manipulate, CtrIndex2Manipulate, CtrType2Manipulate);
-                    if (parameters.log_working_set_enabled)
-                        working_set_log.push_back(WorkingSetLogEntry(ObjIndex2Manipulate, CtrIndex2Manipulate, CtrType2Manipulate, alpha, lexlse_rank));
-                    operation = OPERATION_ADD;
-                    activate(ObjIndex2Manipulate, CtrIndex2Manipulate, CtrType2Manipulate);
-                }
-                else if (normalIteration)
-                {
-                    RealScalar lambda_wrong_sign;
-                    if (findActiveCtr2Remove(ObjIndex2Manipulate, CtrIndex2Manipulate, lambda_wrong_sign))
-                    {
-                        if (parameters.cycling_handling_enabled)
-                            constraint_identifier.set(ObjIndex2Manipulate, objectives[ObjIndex2Manipulate].getActiveCtrIndex(CtrIndex2Manipulate),
-                                                      objectives[ObjIndex2Manipulate].getActiveCtrType(CtrIndex2Manipulate));
-                        if (parameters.log_working_set_enabled)
-                            working_set_log.push_back(WorkingSetLogEntry(ObjIndex2Manipulate,
-                                                                         objectives[ObjIndex2Manipulate].getActiveCtrIndex(CtrIndex2Manipulate),
-                                                                         CTR_INACTIVE, lambda_wrong_sign, lexlse_rank));
-                        operation = OPERATION_REMOVE;
-                        deactivate(ObjIndex2Manipulate, CtrIndex2Manipulate);
-                    }
-                    else
-                    {
-                        status = PROBLEM_SOLVED;
-                    }
-                }
-
-                step_length = (operation == OPERATION_ADD) ? alpha : -1;
-
-                if (alpha > 0)
-                {
-                    for (Index i = 0; i < nVar; i++) x(i) += alpha * dx(i);
-                    for (Index k = 0; k < nObj; k++) objectives[k].step(alpha);
-                }
-
-                if (parameters.cycling_handling_enabled && operation != OPERATION_UNDEFINED)
-                {
-                    status = cycling_handler.update(operation, constraint_identifier, objectives, cycling_detected);
-                    if (parameters.log_working_set_enabled) working_set_log.back().cycling_detected = cycling_detected;
-                }
-
-                nIterations++;
-                return operation;
-            }
-
             // -------------------------------------------------------------------------------------
             // Resumable form of solve() for LOCK-STEP BATCHES (config 5: many LexLSI instances whose equality
-            // solves are served by ONE batched device call per round).  Same statements as phase1() +
-            // verifyWorkingSet() above, cut at the points where the equality solver is used:
+            // solves are served by ONE batched device call per round).  Same statements as the reference's phase1() +
+            // verifyWorkingSet() (lexlsi.h:1144-1265), cut at the points where the equality solver is used:
             //     begin();  while (!finished()) { <serve need()> ; advance(); }
             // advance() itself calls lexlse.factorize()/solve()/ObjectiveSensitivity(); an LSE whose results
             // were pre-computed by a batch call implements them as look-ups (lexls_amd/csrc/lexls_lsi_capi.hip),
@@ -555,8 +493,19 @@ namespace LexLS
                     Index CtrIndex2Remove = 0;
                     int ObjIndex2Remove   = 0;
                     RealScalar lambda_wrong_sign;
-                    const bool found = lexlse.ObjectiveSensitivity(sens_level, CtrIndex2Remove, ObjIndex2Remove, parameters.tol_wrong_sign_lambda,
-                                                                   parameters.tol_correct_sign_lambda, lambda_wrong_sign);
+                    bool found;
+                    if (parameters.deactivate_first_wrong_sign)
+                    {
+                        // lexlsi.h:1063-1105: collects every wrong-sign multiplier level by level on the spot (not batchable: the lock-step
+                        // driver rejects this option); the objective index comes back absolute
+                        Index o_abs = 0;
+                        found       = findActiveCtr2Remove_first(o_abs, CtrIndex2Remove, lambda_wrong_sign);
+                        ObjIndex2Remove = static_cast<int>(o_abs) - static_cast<int>(nObjOffset);
+                        sens_level      = nObj - nObjOffset; // every level has been looked at
+                    }
+                    else
+                        found = lexlse.ObjectiveSensitivity(sens_level, CtrIndex2Remove, ObjIndex2Remove, parameters.tol_wrong_sign_lambda,
+                                                            parameters.tol_correct_sign_lambda, lambda_wrong_sign);
                     if (found)
                     {
                         const Index o = static_cast<Index>(ObjIndex2Remove + static_cast<int>(nObjOffset));
@@ -584,14 +533,8 @@ namespace LexLS
                 }
             }
 
-            /// solve() expressed through the resumable form (used to check that both forms agree)
-            TerminationStatus solve_resumable()
-            {
-                if (parameters.deactivate_first_wrong_sign) throw Exception("solve_resumable: deactivate_first_wrong_sign is not supported");
-                begin();
-                while (!finished()) advance();
-                return status;
-            }
+            /// kept for callers of the earlier two-form interface
+            TerminationStatus solve_resumable() { return solve(); }
 
         private:
             enum ProgramCounter

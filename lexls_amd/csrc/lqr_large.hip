@@ -592,6 +592,7 @@ namespace lexls
                 s->Fc         = c0;
                 s->rank       = 0;
                 s->stop_level = 0;
+                s->last_id    = pp; // which of the two position maps is current (steps that find nothing to do do not copy the maps forward)
             }
         }
 
@@ -605,28 +606,65 @@ namespace lexls
             const uint32_t b = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
             if (skipped(a, b)) return;
             const uint32_t pout = pin ^ 1u;
-            const LargeState s  = fb.st[pin][b];
-            LargeState *so      = fb.st[pout] + b;
-            const bool owner    = blockIdx.x == 0;
+            const uint32_t n = a.nVar, cap = a.cap;
+            const double *norms_in = fb.norms[pin] + (size_t)b * n;
+            double *norms_out      = fb.norms[pout] + (size_t)b * n;
+            const uint32_t *pos_in = fb.pos[pin] + (size_t)b * (n + 1);
+            uint32_t *pos_out      = fb.pos[pout] + (size_t)b * (n + 1);
+            // Everything whose ADDRESS does not depend on the pivot is requested up front, so that a step is two dependent round trips to
+            // L2 / memory (state + norms + positions + own tile, then the pivot column) instead of four: the search candidates of this thread
+            constexpr int NCAND = 4; // candidates per thread in registers (n <= 1024); beyond that the loop below reads again
+            double cv[NCAND];
+            uint32_t cp[NCAND];
+#pragma unroll
+            for (int u = 0; u < NCAND; u++)
+            {
+                const uint32_t k = tid + 256u * u;
+                cv[u]            = (k < n) ? norms_in[k] : -1.0;
+                cp[u]            = (k < n) ? pos_in[k] : 0u;
+            }
+            const LargeState s = fb.st[pin][b];
+            LargeState *so     = fb.st[pout] + b;
+            const bool owner   = blockIdx.x == 0;
             if (s.exhausted || s.stop_level || counter >= s.dim)
             {
                 if (owner && tid == 0) *so = s;
                 return;
             }
-            const uint32_t n = a.nVar, cap = a.cap;
-            double *W              = fb.W[cur] + (size_t)b * cap * (n + 1);
-            const double *norms_in = fb.norms[pin] + (size_t)b * n;
-            double *norms_out      = fb.norms[pout] + (size_t)b * n;
-            const uint32_t *pos_in = fb.pos[pin] + (size_t)b * (n + 1);
-            uint32_t *pos_out      = fb.pos[pout] + (size_t)b * (n + 1);
+            double *W        = fb.W[cur] + (size_t)b * cap * (n + 1);
             const uint32_t c = s.ColIndex, row = s.F + counter, R = s.dim - counter;
             double *colv = smem;     // R: the pivot column
             double *es   = smem + R; // R: essential part (es[i], i >= 1)
 
+            // ... and this wavefront's two columns of the tile (rows across the lanes)
+            double keep[FTC / 4][FRC];
+#pragma unroll
+            for (int h = 0; h < FTC / 4; h++)
+            {
+                const uint32_t j = blockIdx.x * FTC + wave * (FTC / 4) + h;
+#pragma unroll
+                for (int u = 0; u < FRC; u++)
+                {
+                    const uint32_t i = lane + 64u * u;
+                    keep[h][u]       = (j <= n && i < R) ? W[row + i + (size_t)j * cap] : 0.0;
+                }
+            }
+
             // ---- first maximum, by position, of the down-dated norms (lexlse.h:205-206): every workgroup for itself ----
             double bv   = -1.0;
             uint32_t bp = 0xffffffffu, bi = 0;
-            for (uint32_t k = tid; k < n; k += 256)
+#pragma unroll
+            for (int u = 0; u < NCAND; u++)
+            {
+                const uint32_t k = tid + 256u * u;
+                if (k < n && cp[u] >= c && (cv[u] > bv || (cv[u] == bv && cp[u] < bp)))
+                {
+                    bv = cv[u];
+                    bp = cp[u];
+                    bi = k;
+                }
+            }
+            for (uint32_t k = tid + 256u * NCAND; k < n; k += 256)
             {
                 const uint32_t p = pos_in[k];
                 if (p >= c)
@@ -724,7 +762,7 @@ namespace lexls
             __syncthreads();
 
             // ---- this workgroup's tile: two columns per wavefront, rows across the lanes ----
-            const uint32_t posf = pos_in[piv]; // == ppos
+            const uint32_t posf = ppos;
 #pragma unroll
             for (int h = 0; h < FTC / 4; h++)
             {
@@ -740,7 +778,7 @@ namespace lexls
                     else if (pj == c)
                         pnew = posf;
                 }
-                if (lane == 0 && j <= n) pos_out[j] = pnew;
+                if (lane == 0) pos_out[j] = pnew;
                 const bool trailing = (j == n) || pnew > c;
                 if (!trailing)
                 {
@@ -749,19 +787,17 @@ namespace lexls
                 }
                 double *col = W + row + (size_t)j * cap;
                 double a0n;
+                const double a0 = rdlane(keep[h][0], 0);
                 if (tau != 0.0)
                 {
-                    double keep[FRC];
                     double part = 0.0;
 #pragma unroll
                     for (int u = 0; u < FRC; u++)
                     {
                         const uint32_t i = lane + 64u * u;
-                        keep[u]          = (i < R) ? col[i] : 0.0;
-                        if (i >= 1 && i < R) part = dfma(es[i], keep[u], part);
+                        if (i >= 1 && i < R) part = dfma(es[i], keep[h][u], part);
                     }
                     for (uint32_t i = lane + 64u * FRC; i < R; i += 64) part = dfma(es[i], col[i], part);
-                    const double a0  = rdlane(keep[0], 0);
                     const double tmp = wave_sum(part) + a0; // applyHouseholderOnTheLeft (lexlse.h:243-246)
                     const double nt  = -tau;
                     a0n              = dfma(nt, tmp, a0);
@@ -769,12 +805,12 @@ namespace lexls
                     for (int u = 0; u < FRC; u++)
                     {
                         const uint32_t i = lane + 64u * u;
-                        if (i < R) col[i] = (i == 0) ? a0n : dfma(es[i] * nt, tmp, keep[u]);
+                        if (i < R) col[i] = (i == 0) ? a0n : dfma(es[i] * nt, tmp, keep[h][u]);
                     }
                     for (uint32_t i = lane + 64u * FRC; i < R; i += 64) col[i] = dfma(es[i] * nt, tmp, col[i]);
                 }
                 else
-                    a0n = col[0];
+                    a0n = a0;
                 if (lane == 0 && j < n) norms_out[j] = dfma(-a0n, a0n, norms_in[j]); // lexlse.h:262-266
             }
 
@@ -789,6 +825,7 @@ namespace lexls
                     a.perm[(size_t)b * n + c]   = ppos;
                     if (R > 1) a.hh[(size_t)b * cap + row] = tau;
                     *so            = s;
+                    so->last_id    = pout;
                     so->ColIndex   = c + 1;
                     so->rank       = s.rank + 1;
                     so->exhausted  = (c + 1 == n) ? 1u : 0u;
@@ -808,7 +845,7 @@ namespace lexls
             const LargeState *s = fb.st[pp] + b;
             const uint32_t F = s->F, dim = s->dim, Fc = s->Fc, rank = s->rank;
             const uint32_t j = blockIdx.y; // physical column
-            const uint32_t p = (j == n) ? n : fb.pos[pp][(size_t)b * (n + 1) + j];
+            const uint32_t p = (j == n) ? n : fb.pos[s->last_id & 1u][(size_t)b * (n + 1) + j];
             const double *src = fb.W[cur] + (size_t)b * cap * (n + 1) + (size_t)j * cap;
             double *dst       = fb.W[cur ^ 1u] + (size_t)b * cap * (n + 1) + (size_t)p * cap;
             const bool pivcol = j < n && p >= Fc && p < Fc + rank;

@@ -55,6 +55,20 @@ def flatten(nvar: int, objectives):
     return np.array(dims, np.uint32), np.array(types, np.int32), np.ascontiguousarray(data), np.ascontiguousarray(var_index)
 
 
+def unflatten(nvar: int, dims, types, data, var_index=None):
+    """inverse of flatten() for ONE problem: the flat column-major layout -> list of objective dicts"""
+    objs, off = [], 0
+    for d, t in zip(np.asarray(dims, int), np.asarray(types, int)):
+        w = 2 if t == 1 else nvar + 2
+        m = np.asarray(data[off:off + d * w], float).reshape(w, d).T  # column-major d x w
+        off += d * w
+        if t == 1:
+            objs.append(dict(var=np.asarray(var_index, np.uint32)[:d].copy(), lb=m[:, 0].copy(), ub=m[:, 1].copy()))
+        else:
+            objs.append(dict(A=m[:, :nvar].copy(), lb=m[:, nvar].copy(), ub=m[:, nvar + 1].copy()))
+    return objs
+
+
 def _p(a, t):
     return None if a is None else a.ctypes.data_as(C.POINTER(t))
 

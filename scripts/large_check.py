@@ -1,6 +1,6 @@
 """Development check + timing of the large path (BASELINE configs[1]).  Usage: python scripts/large_check.py [policy]"""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 import lexls_amd as hip
 from lexls_amd import problems as P

@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 import lexls_amd as hip
 from lexls_amd import problems as P

@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import lexls_amd as hip  # noqa: E402
 from lexls_amd import problems as P  # noqa: E402
 from oracle import oracle_ctypes as oracle  # noqa: E402

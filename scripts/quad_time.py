@@ -1,6 +1,6 @@
 """Wall time of the 4096-problem IK batch on the policy-4 kernel (for A/B builds via LEXLS_HIP_LIB)."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 import lexls_amd as hip
 from lexls_amd import problems as P

@@ -1,5 +1,5 @@
 """Diagnostic: per-phase shader-clock shares of lqr_quad (needs a -DLEXLS_WAVE_STAMPS build via LEXLS_HIP_LIB)."""
-import os, sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 import lexls_amd
 from lexls_amd import problems as P
