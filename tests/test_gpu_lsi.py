@@ -21,7 +21,7 @@ def test_reference_fixture_test_01(hip, oracle, use_as, use_x):
     d = lexlsi.lsi_solve_dat(DAT, 88, one_based=True, use_active_guess=bool(use_as), use_x_guess=bool(use_x))
     o = oracle.lsi_run_dat(DAT, True, bool(use_as), bool(use_x))
     assert d["info"]["status"] == 0
-    assert np.abs(d["x"] - d["solution"]).max() < 1e-9          # the reference's stored answer
+    assert np.abs(d["x"] - d["solution"]).max() < 1e-10         # the reference's stored answer (north_star: x* within 1e-10; measured 7e-13)
     assert d["info"] == o["info"]                                # same trajectory as the oracle-backed driver
     np.testing.assert_array_equal(d["x"], o["x"])
 
@@ -387,3 +387,62 @@ def test_lock_step_batch_with_regularization(hip, oracle):
         assert r["info"][b] == o["info"], b
         np.testing.assert_array_equal(r["x"][b], o["x"])
         np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
+
+
+def test_removal_path_closed_form_on_the_device(hip, oracle):
+    """tests/test_oracle_golden.py::removal_kat: wrongly active bounds must leave the working set, most negative multiplier first
+    (ObjectiveSensitivity -> REMOVE, lexlsi.h:1204-1225) — closed-form x and working set, same trajectory as the oracle-backed driver"""
+    from test_oracle_golden import removal_kat
+    objs, guess, c, lam, expect_x, removed = removal_kat()
+    d = lexlsi.lsi_solve(4, objs, active_guess=guess)
+    o = oracle.lsi_run(4, objs, active_guess=guess)
+    assert d["info"]["status"] == 0 and d["info"]["deactivations"] == 2 and d["info"]["activations"] == 0
+    assert d["info"] == o["info"]
+    np.testing.assert_allclose(d["x"], expect_x, atol=1e-14)
+    np.testing.assert_array_equal(d["x"], o["x"])
+    assert d["active"][0].tolist() == [0, 2, 0, 2]
+    # the removal search itself on the equality solver: bounds active at UB, objective 1's multipliers, first candidate = most negative
+    lod = np.zeros((1, 5, 8))
+    lod[0, :4, :4] = np.eye(4)
+    lod[0, 4, :4] = c
+    lod[0, :4, 4:] = np.diag(np.arange(1.0, 5))
+    lod[0, 4, 4:] = 1.0
+    s = hip.BatchedLexLSE(1, 4, [4, 4])
+    s.setProblem(lod)
+    s.setCtrType(np.array([[2, 2, 2, 2, 3, 3, 3, 3]], np.uint8))
+    s.factorize_solve()
+    found, ctr, obj, maxabs = s.ObjectiveSensitivity(1)
+    assert bool(found[0]) and int(obj[0]) == 0 and int(ctr[0]) == removed[0]
+    assert abs(abs(float(maxabs[0])) - abs(lam[removed[0]])) < 1e-13
+    np.testing.assert_allclose(np.abs(s.getWorkspace()[0, :4]), np.abs(lam), atol=1e-13)
+
+
+def test_config5_full_size_lock_step_batch(hip, oracle):
+    """BASELINE.json configs[4] at full size: 1024 instances (n = 40, 5 x 12, level 0 simple bounds) in ONE lock-step batch object with the
+    automatic group split, warm-started from the unperturbed neighbour with right-hand sides perturbed by 0.9 N(0,1) (~30 factorizations
+    per instance).  Every instance solved; 64 sampled instances equal the oracle-backed driver bit for bit (x, v, working set, counters)."""
+    n, dims, batch = 40, [12] * 5, 1024
+    base = lexlsi.pack_batch(n, [P.lsi_problem(20260500 + b, n, dims) for b in range(batch)])
+    pert = lexlsi.pack_batch(n, [P.lsi_problem(20260500 + b, n, dims, perturb=0.9) for b in range(batch)])
+    srv = lexlsi.LsiBatch(n, base.dims, base.types, batch)
+    try:
+        cold = srv.run(base)
+        assert all(i["status"] == 0 for i in cold["info"])
+        guess = np.where(cold["active"] == 3, 0, cold["active"]).astype(np.uint8)
+        warm = srv.run(pert, active_guess=guess, x0=cold["x"])
+        stats = srv.stats()
+    finally:
+        srv.close()
+    assert all(i["status"] == 0 for i in warm["info"])
+    assert stats["groups"] >= 2  # batches from 512 instances on take turns in groups
+    f = np.array([i["factorizations"] for i in warm["info"]])
+    assert 20.0 <= f.mean() <= 40.0, f.mean()  # the workload BASELINE.md C5 describes: ~30 factorizations per instance
+    assert sum(i["deactivations"] for i in warm["info"]) > batch  # the removal path is exercised throughout
+    cuts = np.cumsum(base.dims)[:-1]
+    for b in range(0, batch, 16):  # 64 sampled instances against the oracle-backed driver
+        objs = P.lsi_problem(20260500 + b, n, dims, perturb=0.9)
+        o = oracle.lsi_run(n, objs, active_guess=np.split(guess[b], cuts), x0=cold["x"][b])
+        assert warm["info"][b] == o["info"], b
+        np.testing.assert_array_equal(warm["x"][b], o["x"], err_msg=str(b))
+        np.testing.assert_array_equal(warm["active"][b], np.concatenate(o["active"]), err_msg=str(b))
+        np.testing.assert_array_equal(warm["v"][b], np.concatenate(o["v"]), err_msg=str(b))

@@ -150,10 +150,10 @@ def test_wave_kernel_shapes(hip, oracle, n, dims, policy):
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
-def _quad_x_only(hip, oracle, lod, dims, n, maxdim=None):
+def _quad_x_only(hip, oracle, lod, dims, n, maxdim=None, kernel="lqr_quad<3,12>"):
     """x-only solve on the four-problems-per-wavefront kernel: x, ranks, first columns and pivots bit for bit against the oracle"""
     s, ref = run_both(hip, oracle, lod, dims, n, maxdim=maxdim, keep_factor=False, force_generic=4)
-    assert s.last_kernel() == "lqr_quad<3,12>"
+    assert s.last_kernel() == kernel
     r, fc, tr = s.getRanks()
     np.testing.assert_array_equal(r, ref["rank"])
     np.testing.assert_array_equal(fc, ref["fcol"])
@@ -169,6 +169,12 @@ def _quad_x_only(hip, oracle, lod, dims, n, maxdim=None):
 def test_quad_kernel_shapes(hip, oracle, n, dims, batch):
     """shapes around the 16-column slot boundaries, batches that leave rows of the last wavefront idle"""
     _quad_x_only(hip, oracle, P.lse_batch(2000 + n, batch, n, dims), dims, n)
+
+
+@pytest.mark.parametrize("n,dims", [(63, [16, 16, 16, 16]), (30, [14, 9, 16]), (48, [12, 12, 12, 12]), (55, [16, 8, 16, 16]), (40, [16] * 3), (20, [15, 13])])
+def test_quad_kernel_wide_shapes(hip, oracle, n, dims):
+    """the <4 slots, 16 rows> instantiation: n + 1 <= 64, level dims <= 16 (the IK families beyond 47 variables / 12 rows per level)"""
+    _quad_x_only(hip, oracle, P.lse_batch(3000 + n, 7, n, dims), dims, n, kernel="lqr_quad<4,16>")
 
 
 def test_quad_kernel_rank_deficient_and_ragged(hip, oracle):

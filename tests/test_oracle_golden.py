@@ -23,7 +23,7 @@ def test_reference_fixture_test_01_solution(oracle, use_as, use_x):
     d = oracle.lsi_run_dat(DAT, one_based=True, use_active_guess=bool(use_as), use_x_guess=bool(use_x))
     assert d["header"].tolist() == [88, 5, 210, 1]
     assert d["info"]["status"] == 0  # PROBLEM_SOLVED
-    assert np.abs(d["x"] - d["solution"]).max() < 1e-9
+    assert np.abs(d["x"] - d["solution"]).max() < 1e-10  # north_star's tolerance; measured 7e-13
     if use_as:  # the stored active set is optimal: one factorization, nothing added or removed
         assert d["info"]["factorizations"] == 1 and d["info"]["activations"] == 0 and d["info"]["deactivations"] == 0
 
@@ -219,3 +219,37 @@ def test_regularization_cg_variants_converge_to_the_direct_ones(oracle):
     x6 = oracle.lse_run(lod, dims, n, reg_type=6, reg_factors=fac, cg_iters=300)["x"]
     assert np.abs(x1 - x2).max() < 1e-9 and np.abs(x5 - x6).max() < 1e-9
     assert np.abs(oracle.lse_run(lod, dims, n, reg_type=2, reg_factors=fac)["x"] - x1).max() < 1e-6
+
+
+def removal_kat(n=4):
+    """lambda_test.m-style hierarchy with inequalities that FORCE removals (the reference's fixture never deactivates):
+         level 0:  x_k <= c_k               (general rows, all guessed ACTIVE at the upper bound)
+         level 1:  k x_k = 1                (targets 1/k)
+    With every bound active x = c and the multiplier of objective 1 for bound k is -k (k c_k - 1) (stationarity of
+    1/2 sum (k x_k - 1)^2 + sum lambda_k (x_k - c_k)): negative exactly where c_k > 1/k — those bounds are wrongly active and must be
+    removed, most negative first (lexlse.h:976-981); the others stay.  Closed form: x_k = min(c_k, 1/k)."""
+    c = np.array([2.0, 0.25, 1.0, 0.1][:n])            # bounds 1 and 3 are slack at the optimum, 2 and 4 bind
+    objs = [dict(A=np.eye(n), lb=np.full(n, -1e10), ub=c.copy())]
+    objs.append(dict(A=np.diag(np.arange(1.0, n + 1)), lb=np.ones(n), ub=np.ones(n)))
+    guess = [np.full(n, 2, np.uint8), np.zeros(n, np.uint8)]  # CTR_ACTIVE_UB on level 0
+    k = np.arange(1.0, n + 1)
+    lam = -k * (k * c - 1.0)
+    expect_x = np.minimum(c, 1.0 / k)
+    removed = [int(i) for i in np.argsort(lam) if lam[i] < 0]  # order of removal: most negative multiplier first
+    return objs, guess, c, lam, expect_x, removed
+
+
+def test_removal_path_closed_form(oracle):
+    objs, guess, c, lam, expect_x, removed = removal_kat()
+    r = oracle.lsi_run(4, objs, active_guess=guess)
+    assert r["info"]["status"] == 0
+    assert r["info"]["deactivations"] == len(removed) == 2 and r["info"]["activations"] == 0
+    np.testing.assert_allclose(r["x"], expect_x, atol=1e-14)
+    assert r["active"][0].tolist() == [0, 2, 0, 2]  # the slack bounds left the working set, the binding ones stayed at their upper bound
+    # the multipliers themselves, at the first iteration (all bounds active): equality hierarchy  x = c  >  k x_k = 1
+    eq = [dict(A=np.eye(4), lb=c, ub=c), dict(A=np.diag(np.arange(1.0, 5)), lb=np.ones(4), ub=np.ones(4))]
+    x, L = oracle.lsi_lambda(4, eq)
+    np.testing.assert_allclose(x, c, atol=1e-15)
+    # column of objective 1: [multipliers of level 0; residual of level 1]; sign convention of the reference: lambda = -(stationarity multiplier)
+    np.testing.assert_allclose(np.abs(L[:4, 1]), np.abs(lam), atol=1e-13)
+    assert (np.sign(L[:4, 1]) == np.sign(L[0, 1]) * np.sign(lam) * np.sign(lam[0])).all()
