@@ -1,5 +1,5 @@
 #include "lqr_quad_impl.h"
-LEXLS_QUAD_INSTANCE(launch_quad_4x16_x, 4, 16, false)
+LEXLS_QUAD_INSTANCE(launch_quad_4x16_x, 4, 16, false, 0)
 namespace lexls
 {
     /// dynamic LDS one wavefront (four problems) of the four-per-wavefront kernel asks for; 0 = the shape is not served

@@ -95,7 +95,10 @@ namespace lexls
 
         constexpr int kQuadMaxObj = 8; // levels: one byte per level in a column's 64-bit image-index word
 
-        template <int NS, int MD, bool WF>
+        /// SIG: position P sits in slot (P + SIG) / 16, lane (P + SIG) % 16.  With SIG = 16 NS - (n + 1) the right-hand side is the last lane of
+        /// the last slot, so the live columns of a level fill the UPPER slots completely and the lower ones drop out of the Householder
+        /// loop as early as possible (n = 40: 3, 2, 2, 1 live slots instead of 3, 3, 2, 1); SIG = 0 serves every n <= 16 NS - 1
+        template <int NS, int MD, bool WF, int SIG>
         __global__ __launch_bounds__(64) void lqr_quad_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes)
         {
             static_assert(NS >= 1 && NS <= 4 && MD <= 16 && (MD % 2) == 0, "shape limits of the row layout");
@@ -130,7 +133,7 @@ namespace lexls
             auto U32 = [&](int off) -> uint32_t & { return *reinterpret_cast<uint32_t *>(L + off); };
 
 #pragma unroll
-            for (int s = 0; s < NS; s++) B8(o_phys + 16 * s + gl) = (uint8_t)(16 * s + gl);
+            for (int s = 0; s < 4; s++) B8(o_phys + 16 * s + gl) = (uint8_t)(16 * s + gl);
 #pragma unroll
             for (int i = 0; i < 4; i++) D(o_emap + 8 * (16 * i + gl)) = 0.0;
             if (gl < kQuadMaxObj) U32(o_dims + 4 * gl) = (live && gl < nObj) ? dims[gl] : 0u; // one global read; a level's dim then costs an LDS read
@@ -189,18 +192,18 @@ namespace lexls
 #pragma unroll
                     for (int s = 0; s < NS; s++)
                     {
-                        const int P = 16 * s + gl;
-                        pc[s]       = P < n ? (int)B8(o_phys + P) : n;
-                        pos[s]      = P <= n ? P : 0x3fffffff;
+                        const int P = 16 * s + gl - SIG;
+                        pc[s]       = (P >= 0 && P < n) ? (int)B8(o_phys + P) : n;
+                        pos[s]      = (P >= 0 && P <= n) ? P : 0x3fffffff;
                         em[s]       = *reinterpret_cast<const unsigned long long *>(L + o_emap + 8 * pc[s]);
-                        aligned     = aligned && (!(work && P <= n) || (dim == MD && (((F + pc[s] * cap) & 1) == 0)));
+                        aligned     = aligned && (!(work && P >= 0 && P <= n) || (dim == MD && (((F + pc[s] * cap) & 1) == 0)));
                     }
                     if (__ballot(!aligned) == 0ull)
                     {
 #pragma unroll
                         for (int s = 0; s < NS; s++)
                         {
-                            const bool ld     = work && (16 * s + gl) <= n;
+                            const bool ld     = work && (16 * s + gl - SIG) >= 0 && (16 * s + gl - SIG) <= n;
                             const double2 *s2 = reinterpret_cast<const double2 *>(in + F + (size_t)pc[s] * cap);
 #pragma unroll
                             for (int r = 0; r < MD; r++) blk[s][r] = 0.0;
@@ -221,7 +224,7 @@ namespace lexls
 #pragma unroll
                         for (int s = 0; s < NS; s++)
                         {
-                            const bool ld     = work && (16 * s + gl) <= n;
+                            const bool ld     = work && (16 * s + gl - SIG) >= 0 && (16 * s + gl - SIG) <= n;
                             const double *src = in + F + (size_t)pc[s] * cap;
 #pragma unroll
                             for (int r = 0; r < MD; r++) blk[s][r] = (ld && r < dim) ? src[r] : 0.0;
@@ -246,7 +249,7 @@ namespace lexls
                         // U[c'][P] of this lane's columns is fetched one pivot ahead of its use (the read depends on a row-broadcast address)
                         auto fetch_u = [&](auto cc, double (&u)[NS]) __attribute__((always_inline)) {
                             constexpr int C  = decltype(cc)::value;
-                            constexpr int sc = C / 16, lc = C % 16;
+                            constexpr int sc = (C + SIG) / 16, lc = (C + SIG) % 16;
                             const int rowp   = gbci<lc>(rp[sc]);
                             const int selq   = gbci<lc>(rq[sc]);
 #pragma unroll
@@ -260,12 +263,12 @@ namespace lexls
 #pragma unroll
                         for (int s = 0; s < NS; s++) ucur[s] = unext[s] = 0.0;
                         if (Fcmax > 0) fetch_u(std::integral_constant<int, 0>{}, ucur);
-                        for_each_index<0, 16 * NS>([&](auto cc) __attribute__((always_inline)) {
+                        for_each_index<0, 16 * NS - SIG>([&](auto cc) __attribute__((always_inline)) {
                             constexpr int C  = decltype(cc)::value;
-                            constexpr int sc = C / 16, lc = C % 16;
+                            constexpr int sc = (C + SIG) / 16, lc = (C + SIG) % 16;
                             if (C < Fcmax) // wave-uniform
                             {
-                                if constexpr (C + 1 < 16 * NS)
+                                if constexpr (C + 1 < 16 * NS - SIG)
                                 {
                                     if (C + 1 < Fcmax) fetch_u(std::integral_constant<int, C + 1>{}, unext);
                                 }
@@ -484,7 +487,7 @@ namespace lexls
                                 idgv = 1.0 / c0; // last row of a full level: RemainingRows == 1, no reflector (lexlse.h:239)
                             }
 #pragma unroll
-                            for (int s = S0; s < NS; s++) idgreg[s] = sel(cont && 16 * s + gl == ColIndex, idgv, idgreg[s]);
+                            for (int s = S0; s < NS; s++) idgreg[s] = sel(cont && 16 * s + gl - SIG == ColIndex, idgv, idgreg[s]);
 
                             ColIndex += cont ? 1 : 0;
                             rank += cont ? 1 : 0;
@@ -497,7 +500,7 @@ namespace lexls
                         });
                     };
                     {
-                        const int s0 = rows_min(work ? Fc : 0x3fffffff) >> 4;
+                        const int s0 = (rows_min(work ? Fc : 0x3fffffff) + SIG) >> 4;
                         if (NS > 3 && s0 >= 3)
                             factor_level(std::integral_constant<int, (NS > 3 ? 3 : 0)>{});
                         else if (NS > 2 && s0 >= 2)
@@ -517,7 +520,7 @@ namespace lexls
 #pragma unroll
                     for (int s = 0; s < NS; s++)
                     {
-                        const int P0  = 16 * s + gl;
+                        const int P0  = 16 * s + gl - SIG;
                         const bool mv = work && P0 <= n && P0 >= Fc; // columns that were live in this level (the RHS included)
                         if (mv)
                         {
@@ -550,7 +553,7 @@ namespace lexls
 
             // ---- solve(): block back-substitution on the images (lexlse.h:1015-1045); lane p <-> row p of a level ----
 #pragma unroll
-            for (int s = 0; s < NS; s++) D(o_xs + 8 * (16 * s + gl)) = 0.0;
+            for (int s = 0; s < NS; s++) D(o_xs + 8 * (16 * s + gl)) = 0.0; // (by LDS slot, not by position: all 16 NS entries)
             quad_lds_fence();
             for (int k = nObj; k--;)
             {
@@ -606,7 +609,7 @@ namespace lexls
 #pragma unroll
                 for (int s = 0; s < NS; s++)
                 {
-                    const int P = 16 * s + gl;
+                    const int P = 16 * s + gl; // every position once, whatever the layout offset
                     if (P < n)
                     {
                         a.x[(size_t)b * n + B8(o_phys + P)] = D(o_xs + 8 * P); // x = P x: the variable at position P (lexlse.h:1044)
@@ -646,25 +649,25 @@ namespace lexls
             return (8 * ((size_t)quad_image_doubles(n, nObj, md) + 16 * NS + 18) + 64 + 64 + 16 * kQuadMaxObj + 512 + 4 * kQuadMaxObj + 15) & ~(size_t)15;
         }
 
-        template <int NS, int MD, bool WF>
+        template <int NS, int MD, bool WF, int SIG>
         hipError_t launch_quad_t(const LseArgs &a, hipStream_t s)
         {
             const uint32_t img = quad_image_doubles(a.nVar, a.nObj, MD);
             const size_t gbytes = quad_group_bytes<NS>(a.nVar, a.nObj, MD);
             const size_t lds    = 4 * gbytes;
-            if (lds > kMaxLdsBytes || a.nObj > (uint32_t)kQuadMaxObj || a.nVar + 1 > 16u * NS || a.nVar > 63u) return hipErrorInvalidValue;
+            if (lds > kMaxLdsBytes || a.nObj > (uint32_t)kQuadMaxObj || a.nVar + 1 + SIG > 16u * NS || a.nVar > 63u) return hipErrorInvalidValue;
             if (lds > 64 * 1024)
             {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_quad_kernel<NS, MD, WF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_quad_kernel<NS, MD, WF, SIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
             }
             const uint32_t blocks = (a.batch + 3u) / 4u;
-            hipLaunchKernelGGL((lqr_quad_kernel<NS, MD, WF>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes);
+            hipLaunchKernelGGL((lqr_quad_kernel<NS, MD, WF, SIG>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes);
             return hipGetLastError();
         }
     } // namespace
 } // namespace lexls
 
 // One translation unit per instantiation (parallel builds): LEXLS_QUAD_INSTANCE(name, NS, MD, WF)
-#define LEXLS_QUAD_INSTANCE(NAME, NS, MD, WF) \
-    namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_quad_t<NS, MD, WF>(a, s); } }
+#define LEXLS_QUAD_INSTANCE(NAME, NS, MD, WF, SIG) \
+    namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_quad_t<NS, MD, WF, SIG>(a, s); } }

@@ -19,6 +19,7 @@ namespace lexls
 
     hipError_t launch_quad_3x12_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_4x16_x(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_3x12s7_x(const LseArgs &a, hipStream_t s);
     size_t quad_lds_bytes(uint32_t slots, uint32_t md, uint32_t nVar, uint32_t nObj);
 
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed)
@@ -57,6 +58,11 @@ namespace lexls
             size_t lds = (max_level_dim <= 12) ? quad_lds_bytes(3, 12, a.nVar, a.nObj) : 0;
             if (lds && lds <= kMaxLdsBytes)
             {
+                if (a.nVar == 40) // the IK shape: columns right-aligned in the slots (see SIG in lqr_quad_impl.h)
+                {
+                    *variant = "lqr_quad<3,12,shift 7>";
+                    return launch_quad_3x12s7_x(a, s);
+                }
                 *variant = "lqr_quad<3,12>";
                 return launch_quad_3x12_x(a, s);
             }
