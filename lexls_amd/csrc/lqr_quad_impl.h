@@ -212,7 +212,13 @@ namespace lexls
 #pragma unroll
                                 for (int r = 0; r < MD / 2; r++)
                                 {
+#ifdef LEXLS_QUAD_NT_LOADS
+                                    typedef double nt_d2 __attribute__((ext_vector_type(2)));
+                                    const nt_d2 vv    = __builtin_nontemporal_load(reinterpret_cast<const nt_d2 *>(s2 + r));
+                                    const double2 v   = make_double2(vv.x, vv.y);
+#else
                                     const double2 v   = s2[r];
+#endif
                                     blk[s][2 * r]     = v.x;
                                     blk[s][2 * r + 1] = v.y;
                                 }

@@ -32,10 +32,17 @@ lod = P.lse_batch(20260001, 1, n, dims)
 s = lexls_amd.BatchedLexLSE(1, n, dims)
 s.setProblem(lod)
 t = timed(lambda: s.factorize_solve(True), s.synchronize, 5)
+tf = timed(lambda: s.factorize(), s.synchronize, 5)
 flops = P.flop_model(n, dims)["total"]
 tc, _ = oc.lse_time(lod, dims, n, 1, 3)
-out["config1_single_large"] = dict(kernel=s.last_kernel(), ms=1e3 * t, gflops=flops / t / 1e9, cpu_oracle_ms=1e3 * tc / 3, cpu_oracle_gflops=flops / (tc / 3) / 1e9,
-                                   note="multi-launch large path: one launch per pivot stage (serial pivot kernel + tiled apply over the chip), ordered chains as in the oracle")
+s5 = lexls_amd.BatchedLexLSE(1, n, dims)
+s5.set_kernel_policy(5)
+s5.setProblem(lod)
+t5 = timed(lambda: s5.factorize_solve(True), s5.synchronize, 5)
+out["config1_single_large"] = dict(kernel=s.last_kernel(), ms=1e3 * t, factorize_only_ms=1e3 * tf, gflops=flops / t / 1e9, cpu_oracle_ms=1e3 * tc / 3, cpu_oracle_gflops=flops / (tc / 3) / 1e9,
+                                   bit_exact_path=dict(kernel=s5.last_kernel(), ms=1e3 * t5),
+                                   note="step-per-pivot path: one launch per pivot (search + reflector + tile update), tree sums, trailing update on v_mfma_f64_16x16x4; "
+                                        "bit_exact_path = ordered chains, two launches per pivot (policy 5)")
 
 # ---- secondary kernels on the IK batch ---------------------------------------------------------------------------------
 n, dims, batch = 40, [12] * 5, 4096
@@ -49,8 +56,8 @@ import ctypes as C
 from lexls_amd import capi
 L = capi.lib()
 for name, fn in [("residual(get_v)", lambda: L.lexls_lse_residual(s._h)),
-                 ("sensitivity(level 3)", lambda: L.lexls_lse_sensitivity(s._h, None, C.c_int32(3), C.c_double(1e-8), C.c_double(1e-12))),
-                 ("solve(from factor)", lambda: L.lexls_lse_solve(s._h))]:
+                 ("sensitivity(level 3)", lambda: L.lexls_lse_sensitivity(s._h, None, C.c_int32(3), C.c_double(1e-8), C.c_double(1e-12)))]:
+    # (lexls_lse_solve is not in this list: it launches nothing while the solution of the current factor is cached)
     t = timed(fn, s.synchronize, 20)
     out[name] = dict(ms=1e3 * t, factor_read_GBs=fac_bytes / t / 1e9)
 
@@ -63,7 +70,7 @@ t = timed(lambda: L.lexls_lse_solve_least_norm(s2._h), s2.synchronize, 5)
 out["least_norm_givens(1024 x n=40, 5x6)"] = dict(ms=1e3 * t)
 
 # ---- configs[4]: lock-step batched LSI, warm-started ----------------------------------------------------------------------
-n, dims, batch = 40, [12] * 5, int(os.environ.get("LSI_BATCH", "256"))
+n, dims, batch = 40, [12] * 5, int(os.environ.get("LSI_BATCH", "1024"))
 base = lexlsi.pack_batch(n, [P.lsi_problem(20260500 + b, n, dims) for b in range(batch)])  # problem generation and flattening are not timed
 lexlsi.lsi_batch_solve(n, base)  # warm-up: library load, first launches
 t0 = time.perf_counter()
