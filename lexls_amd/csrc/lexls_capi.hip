@@ -742,7 +742,7 @@ extern "C"
         {
             return fail(LEXLS_ERR_INVALID, "ObjIndex >= nObj");
         }
-        HIP_TRY(launch_sensitivity(h->args(), d_obj, obj_index_all, tolW, tolC, h->stream, h->sens_scan));
+        HIP_TRY(launch_sensitivity(h->args(), d_obj, obj_index_all, tolW, tolC, h->stream, h->sens_scan, h->max_level_dim));
         return LEXLS_OK;
     }
 
@@ -757,7 +757,7 @@ extern "C"
     {
         if (int rc = need_factor(h, "lexls_lse_sensitivity_resident")) return rc;
         HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(launch_sensitivity(h->args(), h->d_objidx, 0, tolW, tolC, h->stream, h->sens_scan));
+        HIP_TRY(launch_sensitivity(h->args(), h->d_objidx, 0, tolW, tolC, h->stream, h->sens_scan, h->max_level_dim));
         return LEXLS_OK;
     }
 

@@ -846,9 +846,11 @@ struct lexls_lsi_batch_s
             ctx.create(device, lo[g + 1] - lo[g], nVar, nObj - off, h_dims + off, gather);
             hip_check(lexls_lse_set_deferred_sync(ctx.h, 1)); // every per-round array of BatchCtx is pinned and only touched between stages
             hip_check(lexls_lse_set_sensitivity_scan(ctx.h, 1)); // the removal search of an iteration in ONE sensitivity stage (all its levels)
-            // LEXLS_LSI_SPECULATIVE_SENS=1: the removal search runs speculatively behind every factorization (half the stages).  Measured
-            // on MI355X it loses — 1024 instances cold 0.040 s vs 0.036 s: the search is an ~80 us chain that then lengthens EVERY stage,
-            // also those whose step turns out to be blocked — so it is off by default.
+            // The removal search runs speculatively behind every factorization (a third fewer stages: one synchronisation per active-set
+            // iteration instead of two).  With round 1's 83-us level-by-level search it lost (1024 instances cold 0.040 s vs 0.036 s); since the
+            // search is one 36-us sweep (sensitivity_sweep_kernel) it wins: warm-started ~30 iterations 0.027-0.028 s vs 0.029-0.034 s.
+            // LEXLS_LSI_SPECULATIVE_SENS=0 restores the two-stage form.
+            ctx.spec_sens = true;
             if (const char *e = std::getenv("LEXLS_LSI_SPECULATIVE_SENS")) ctx.spec_sens = std::atoi(e) != 0;
         }
         // the step of an iteration can run on the device when the constraint data is resident

@@ -15,16 +15,16 @@
 // distinct 8-byte bank pairs (ds_read_b64: bank = (addr/4) % 64, stride 2*ldp dwords).
 #include "lexls_kernels.h"
 #include "lexls_launch.h"
+#include "lqr_wave_common.h"
 #include "lexls_regularize.h"
 
 #include <cfloat>
+#include <cstdlib>
 
 namespace lexls
 {
     namespace
     {
-        __device__ __forceinline__ double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-
         /// block-wide "first index of the maximum": every thread passes its best candidate
         template <int NT>
         __device__ __forceinline__ uint32_t block_argmax(double v, uint32_t idx, double *rv, uint32_t *ri, uint32_t tid)
@@ -1293,6 +1293,288 @@ namespace lexls
                 out[idx] = src[rs[r] + (size_t)(j < n ? j : n + ub) * ld];
             }
         }
+
+        // -----------------------------------------------------------------------------------------
+        // The removal search of a LexLSI iteration as ONE downward sweep (lexlsi.h:1115-1139 around lexlse.h:611-762).
+        //
+        // The reference calls ObjectiveSensitivity level by level — objective L costs L + 1 level steps (its own level, then the
+        // Householder sequences and the L^T lambda products of the levels above it), so a search that goes through all nObj
+        // objectives walks nObj (nObj + 1) / 2 level steps, each a chain of dependent Householder applications.  The multipliers
+        // of objective L do not depend on the marks the scan of objective L - 1 left (only findDescentDirection's choice does), so all
+        // objectives are swept TOGETHER: level step k serves every objective L >= k at once — objective L = oi + 4 t + rho lives in
+        // DPP row rho (register t), lane i of the row is row i of the level, the ordered dot products of a reflector run along the
+        // row with v_mov_b64_dpp row_newbcast (no SGPR round trips), the factor is staged in LDS once.  Afterwards the decisions are
+        // taken objective by objective in the reference's order (marks carried along, first objective with a wrong-sign multiplier
+        // wins) on the stored multipliers, sixteen entries at a time.  Every multiplier is the same ordered chain as in
+        // sensitivity_kernel: results are bit-identical (tests/test_gpu_parity.py::test_sensitivity_scan_*).
+        // One wavefront per problem; level dims <= 16, at most 8 objectives in a sweep, nVar <= 64.
+        // -----------------------------------------------------------------------------------------
+        template <int CTRL>
+        __device__ __forceinline__ double dpp_min(double v)
+        {
+            const int lo2 = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+            const int hi2 = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+            const double o = __hiloint2double(hi2, lo2);
+            return o < v ? o : v;
+        }
+        __device__ __forceinline__ double row_minf16(double v)
+        {
+            v = dpp_min<0xB1>(v);
+            v = dpp_min<0x4E>(v);
+            v = dpp_min<0x141>(v);
+            v = dpp_min<0x140>(v);
+            return v;
+        }
+
+        constexpr int SWEEP_MD = 16, SWEEP_T = 2; // rows per level; objective registers per DPP row (4 rows x 2 = 8 objectives)
+
+        __global__ __launch_bounds__(64) void sensitivity_sweep_kernel(LseArgs a, const int32_t *obj_index, int32_t obj_all, double tolW, double tolC, int scan_up)
+        {
+            constexpr int MD = SWEEP_MD, TT = SWEEP_T;
+            extern __shared__ double smem[];
+            const uint32_t b = blockIdx.x, lane = threadIdx.x;
+            const int rho = (int)(lane >> 4), il = (int)(lane & 15u);
+            const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
+            const int32_t oi = obj_index ? obj_index[b] : obj_all;
+            int32_t *sens    = a.sens + (size_t)b * 3;
+            if (oi < 0 || (uint32_t)oi >= nObj)
+            {
+                if (lane == 0)
+                {
+                    sens[0]     = 0;
+                    sens[1]     = -1;
+                    sens[2]     = -2;
+                    a.maxabs[b] = 0.0;
+                }
+                return;
+            }
+            const int last = scan_up ? (int)nObj - 1 : oi; // objectives oi .. last are swept
+            const uint32_t *dims = a.dims + (size_t)b * nObj;
+            const uint32_t *rk = a.rank + (size_t)b * nObj, *fc = a.fcol + (size_t)b * nObj;
+            const uint32_t nf  = a.nfixed ? a.nfixed[b] : 0;
+            const uint32_t ld  = cap | 1u;
+
+            // LDS: staged factor | Householder scalars | multipliers per objective (cap each) | rhs per objective (n each) | fixed-variable
+            //      multipliers per objective (n each) | activation types (cap constraint rows, then nVar fixed variables)
+            double *Wl     = smem;
+            double *hhl    = Wl + (size_t)ld * (n + 1);
+            double *LamAll = hhl + cap;
+            double *RhsAll = LamAll + (size_t)4 * TT * cap;
+            double *FixAll = RhsAll + (size_t)4 * TT * n;
+            uint8_t *types = reinterpret_cast<uint8_t *>(FixAll + (size_t)4 * TT * n);
+            for (uint32_t i = lane; i < cap; i += 64) hhl[i] = a.hh[(size_t)b * cap + i];
+            for (uint32_t i = lane; i < cap; i += 64) types[i] = a.ctr_type[(size_t)b * cap + i];
+            for (uint32_t i = lane; i < n; i += 64) types[cap + i] = a.fixed_type[(size_t)b * n + i];
+            for (uint32_t i = lane; i < 4u * TT * (cap + 2 * n); i += 64) LamAll[i] = 0.0;
+            stage_factor<64>(a.fac + (size_t)b * cap * (n + 1), Wl, cap, n + 1, ld, lane); // ends with a barrier
+
+            // ---- the sweep: level k serves every objective L >= k ----
+            uint32_t Fend = 0;
+            for (int k = 0; k <= last; k++) Fend += dims[k];
+            uint32_t F = Fend;
+            for (int k = last; k >= 0; k--)
+            {
+                const int dim = (int)dims[k], rank = (int)rk[k];
+                const uint32_t Fc = fc[k];
+                F -= (uint32_t)dim;
+                double lam[TT];
+                bool act[TT], own[TT];
+#pragma unroll
+                for (int t = 0; t < TT; t++)
+                {
+                    const int L = oi + 4 * t + rho;
+                    act[t]      = L <= last && L >= k;
+                    own[t]      = L == k;
+                    double v    = 0.0;
+                    if (own[t] && L <= last)
+                        v = (il >= rank && il < dim) ? -Wl[F + il + (size_t)n * ld] : 0.0; // residual part of the objective's own level (lexlse.h:658-664)
+                    else if (act[t])
+                        v = (il < rank) ? RhsAll[(size_t)(L - oi) * n + Fc + il] : 0.0; // lexlse.h:716
+                    lam[t] = v;
+                }
+                // Householder sequence of the level, last reflector first (applyOnTheLeft.m:11-14); all control flow is wave-uniform
+                for_each_index<0, MD>([&](auto jj) __attribute__((always_inline)) {
+                    constexpr int J = MD - 1 - decltype(jj)::value;
+                    if (J < rank)
+                    {
+                        const int rows   = dim - J;
+                        const double tau = hhl[F + J];
+                        if (rows == 1)
+                        {
+#pragma unroll
+                            for (int t = 0; t < TT; t++) lam[t] = sel(il == J, lam[t] * (1.0 - tau), lam[t]);
+                        }
+                        else if (tau != 0.0)
+                        {
+                            const bool tail = il > J && il < dim;
+                            const double e  = tail ? Wl[F + il + (size_t)(Fc + J) * ld] : 0.0;
+                            double tt[TT];
+#pragma unroll
+                            for (int t = 0; t < TT; t++) tt[t] = 0.0;
+                            for_each_index<J + 1, MD>([&](auto ii) __attribute__((always_inline)) {
+                                constexpr int I = decltype(ii)::value;
+                                if (I < dim)
+                                {
+                                    const double ei = gbc<I>(e);
+#pragma unroll
+                                    for (int t = 0; t < TT; t++) tt[t] = dfma(ei, gbc<I>(lam[t]), tt[t]);
+                                }
+                            });
+                            const double ce = -(tau * e);
+#pragma unroll
+                            for (int t = 0; t < TT; t++)
+                            {
+                                const double tsum = tt[t] + gbc<J>(lam[t]);
+                                const double head = dfma(-tau, tsum, lam[t]);
+                                const double body = dfma(ce, tsum, lam[t]);
+                                lam[t]            = sel(il == J, head, sel(tail, body, lam[t]));
+                            }
+                        }
+                    }
+                });
+                // keep the level's multipliers (decisions are taken after the sweep)
+#pragma unroll
+                for (int t = 0; t < TT; t++)
+                {
+                    const int L = oi + 4 * t + rho;
+                    if (act[t] && il < dim) LamAll[(size_t)(L - oi) * cap + F + il] = lam[t];
+                }
+                // rhs.head(Fc) -= L^T lambda (lexlse.h:706-707, :722-728); an objective's own level only if it is not objective 0 (:702)
+                if (Fc > 0)
+                {
+                    double lb[TT][MD];
+                    for_each_index<0, MD>([&](auto ii) __attribute__((always_inline)) {
+                        constexpr int I = decltype(ii)::value;
+#pragma unroll
+                        for (int t = 0; t < TT; t++) lb[t][I] = gbc<I>(lam[t]);
+                    });
+                    for (uint32_t c0 = 0; c0 < Fc; c0 += 16)
+                    {
+                        const uint32_t c  = c0 + (uint32_t)il;
+                        const uint32_t cc = c < Fc ? c : 0;
+                        double sacc[TT];
+#pragma unroll
+                        for (int t = 0; t < TT; t++) sacc[t] = 0.0;
+#pragma unroll
+                        for (int I = 0; I < MD; I++)
+                        {
+                            if (I < dim)
+                            {
+                                const double w = Wl[F + I + (size_t)cc * ld];
+#pragma unroll
+                                for (int t = 0; t < TT; t++) sacc[t] = dfma(w, lb[t][I], sacc[t]);
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < TT; t++)
+                        {
+                            const int L = oi + 4 * t + rho;
+                            if (act[t] && c < Fc && !(own[t] && L == 0)) RhsAll[(size_t)(L - oi) * n + c] -= sacc[t];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+
+            // ---- fixed variables: lambda_fixed = -LOD[0:nLambda, 0:nf]^T lambda (lexlse.h:742-758) ----
+            if (nf > 0)
+            {
+#pragma unroll
+                for (int t = 0; t < TT; t++)
+                {
+                    const int L = oi + 4 * t + rho;
+                    if (L > last) continue;
+                    uint32_t nLam = 0;
+                    for (int k = 0; k <= L; k++) nLam += dims[k];
+                    for (uint32_t c0 = 0; c0 < nf; c0 += 16)
+                    {
+                        const uint32_t c  = c0 + (uint32_t)il;
+                        const uint32_t cc = c < nf ? c : 0;
+                        double sacc       = 0.0;
+                        const double *lv  = LamAll + (size_t)(L - oi) * cap;
+                        for (uint32_t i = 0; i < nLam; i++) sacc = dfma(Wl[i + (size_t)cc * ld], lv[i], sacc);
+                        if (c < nf) FixAll[(size_t)(L - oi) * n + c] = -sacc;
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- decisions, objective by objective (findDescentDirection, lexlse.h:935-987): sequential semantics — the most negative
+            //      sign-adjusted multiplier wins, the first one among equals; marks are in place before the next group is looked at ----
+            double best   = 0.0;
+            uint32_t bctr = 0;
+            int bobj = -2, found = 0, Lout = oi;
+            auto scan_group = [&](uint8_t *ty, const double *lm, uint32_t count, int tag) __attribute__((always_inline)) {
+                for (uint32_t g0 = 0; g0 < count; g0 += 16)
+                {
+                    const uint32_t kx = g0 + (uint32_t)il;
+                    const bool in     = kx < count;
+                    const uint8_t t   = in ? ty[kx] : (uint8_t)CTR_ACTIVE_EQ;
+                    double al         = in ? lm[kx] : 0.0;
+                    if (t == CTR_ACTIVE_LB) al = -al;
+                    const bool look = in && t != CTR_ACTIVE_EQ && t != CORRECT_SIGN_OF_LAMBDA;
+                    if (look && al > tolC && rho == 0) ty[kx] = CORRECT_SIGN_OF_LAMBDA;
+                    const bool cand  = look && !(al > tolC) && al < -tolW;
+                    const double key = cand ? al : 1.0; // candidates are negative
+                    const double m   = row_minf16(key);
+                    const unsigned ik = (cand && key == m) ? (unsigned)il : 0xffu;
+                    const unsigned fi = row_min16(ik);
+                    if (m < 0.0 && m < best) // (wave-uniform: every row holds the same sixteen entries)
+                    {
+                        best  = m;
+                        bctr  = g0 + fi;
+                        bobj  = tag;
+                        found = 1;
+                    }
+                }
+                __syncthreads(); // marks visible to the scans that follow
+            };
+            for (int L = oi; L <= last; L++)
+            {
+                best  = 0.0;
+                bctr  = 0;
+                bobj  = -2;
+                found = 0;
+                Lout  = L;
+                const double *lm = LamAll + (size_t)(L - oi) * cap;
+                uint32_t Fk = 0;
+                for (int k = 0; k <= L; k++) Fk += dims[k];
+                for (int k = L; k >= 0; k--) // own level first, then upwards (lexlse.h:664, :706-730)
+                {
+                    Fk -= dims[k];
+                    scan_group(types + Fk, lm + Fk, dims[k], k);
+                }
+                if (nf > 0) scan_group(types + cap, FixAll + (size_t)(L - oi) * n, nf, -1);
+                if (found) break;
+            }
+
+            // ---- results of the objective the search stopped at (getWorkspace: [lambda_fixed; lambda], lexlse.h:636-639) ----
+            {
+                uint32_t nLam = 0;
+                for (int k = 0; k <= Lout; k++) nLam += dims[k];
+                double *out      = a.lambda + (size_t)b * (n + cap);
+                const double *lm = LamAll + (size_t)(Lout - oi) * cap;
+                const double *fx = FixAll + (size_t)(Lout - oi) * n;
+                for (uint32_t i = lane; i < n + cap; i += 64)
+                {
+                    double val = 0.0;
+                    if (i < nf)
+                        val = fx[i];
+                    else if (i < nf + nLam)
+                        val = lm[i - nf];
+                    out[i] = val;
+                }
+                if (lane == 0)
+                {
+                    sens[0]     = found;
+                    sens[1]     = found ? (int32_t)bctr : -1;
+                    sens[2]     = found ? bobj : -2;
+                    a.maxabs[b] = best;
+                }
+            }
+            for (uint32_t i = lane; i < cap; i += 64) a.ctr_type[(size_t)b * cap + i] = types[i];
+            for (uint32_t i = lane; i < n; i += 64) a.fixed_type[(size_t)b * n + i] = types[cap + i];
+        }
     } // namespace
 
     hipError_t launch_gather_rows(const LseArgs &a, const double *d_cdata, uint64_t per_problem, const uint32_t *d_row_src, const uint32_t *d_row_ld,
@@ -1312,7 +1594,7 @@ namespace lexls
         return hipGetLastError();
     }
 
-    hipError_t launch_sensitivity(const LseArgs &a, const int32_t *d_obj_index, int32_t obj_all, double tolW, double tolC, hipStream_t s, bool scan_up)
+    hipError_t launch_sensitivity(const LseArgs &a, const int32_t *d_obj_index, int32_t obj_all, double tolW, double tolC, hipStream_t s, bool scan_up, uint32_t sweep_level_dim_hint)
     {
         const size_t lds = 8 * (2 * (size_t)a.nVar + a.cap + 2) + sizeof(SensState) + 16;
         if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
@@ -1324,6 +1606,15 @@ namespace lexls
         {
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        }
+        // the single-sweep form (sensitivity_sweep_kernel): level dims <= 16, at most 8 objectives per sweep, one wavefront per problem with
+        // the factor staged in LDS — what a lock-step LSI stage asks for.  max_level_dim comes from the caller (0 = unknown: not taken)
+        const size_t lds_sweep = 8 * ((size_t)(a.cap | 1u) * (a.nVar + 1) + a.cap + 8 * ((size_t)a.cap + 2 * a.nVar)) + (((size_t)a.cap + a.nVar + 15) & ~(size_t)15);
+        if (sweep_level_dim_hint > 0 && sweep_level_dim_hint <= (uint32_t)SWEEP_MD && a.nObj <= 8 && a.nVar <= 64 && lds_sweep <= 64 * 1024 && a.batch <= 4u * (uint32_t)cus &&
+            !std::getenv("LEXLS_SENS_NO_SWEEP"))
+        {
+            hipLaunchKernelGGL(sensitivity_sweep_kernel, dim3(a.batch), dim3(64), lds_sweep, s, a, d_obj_index, obj_all, tolW, tolC, scan_up ? 1 : 0);
+            return hipGetLastError();
         }
         if (lds_staged <= 40 * 1024 && a.batch <= 4u * (uint32_t)cus)
         {

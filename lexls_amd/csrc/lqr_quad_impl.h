@@ -29,64 +29,6 @@ namespace lexls
 {
     namespace
     {
-        extern "C" __device__ double lexls_update_dpp_f64(double, double, int, int, int, bool) __asm("llvm.amdgcn.update.dpp.f64");
-
-        /// value of lane L of this lane's 16-lane row (v_mov_b64_dpp row_newbcast:L)
-        template <int L>
-        __device__ __forceinline__ double gbc(double v)
-        {
-            return lexls_update_dpp_f64(0.0, v, 0x150 + L, 0xf, 0xf, true);
-        }
-        template <int L>
-        __device__ __forceinline__ int gbci(int v)
-        {
-            return __builtin_amdgcn_update_dpp(0, v, 0x150 + L, 0xf, 0xf, true);
-        }
-
-        /// maximum over the 16 lanes of a DPP row, in every lane of the row
-        __device__ __forceinline__ double row_max16(double v)
-        {
-            v = dpp_max<0xB1>(v);  // quad_perm [1,0,3,2]
-            v = dpp_max<0x4E>(v);  // quad_perm [2,3,0,1]
-            v = dpp_max<0x141>(v); // row_half_mirror
-            v = dpp_max<0x140>(v); // row_mirror
-            return v;
-        }
-        template <int CTRL>
-        __device__ __forceinline__ unsigned dpp_minu(unsigned v)
-        {
-            const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); // folds into v_min_u32_dpp
-            return o < v ? o : v;
-        }
-        __device__ __forceinline__ unsigned row_min16(unsigned v)
-        {
-            v = dpp_minu<0xB1>(v);
-            v = dpp_minu<0x4E>(v);
-            v = dpp_minu<0x141>(v);
-            v = dpp_minu<0x140>(v);
-            return v;
-        }
-        /// max / min over the four rows of a value that is uniform inside each row
-        __device__ __forceinline__ int rows_max(int v)
-        {
-            const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-            const int ab = a > b ? a : b, cd = c > d ? c : d;
-            return ab > cd ? ab : cd;
-        }
-        __device__ __forceinline__ int rows_min(int v)
-        {
-            const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-            const int ab = a < b ? a : b, cd = c < d ? c : d;
-            return ab < cd ? ab : cd;
-        }
-
-        /// c ? x : y on VALUES (the built-in operator on two lvalues yields an lvalue: a select of addresses, which keeps arrays in memory)
-        template <class T>
-        __device__ __forceinline__ T sel(bool c, T x, T y)
-        {
-            return c ? x : y;
-        }
-
         __device__ __forceinline__ void quad_lds_fence()
         {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -16,4 +16,4 @@ for rep in range(5):
     s.synchronize(); t0 = time.perf_counter()
     for _ in range(100): s.factorize_solve(keep_factor=False)
     s.synchronize(); best = min(best, (time.perf_counter() - t0) / 100)
-print(f"{s.last_kernel()} {best*1e6:8.1f} us  {batch/best:.3e} fact/s  checksum {float(np.abs(x0).sum()):.12e}")
+print(f"{best*1e6:.1f} us {batch/best:.3e} fact/s kernel {s.last_kernel()} checksum {float(np.abs(x0).sum()):.12e}")

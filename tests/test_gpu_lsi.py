@@ -355,10 +355,11 @@ def test_lock_step_groups_take_turns(hip, oracle, monkeypatch, groups):
 
 
 def test_speculative_removal_search(hip, oracle, monkeypatch):
-    """LEXLS_LSI_SPECULATIVE_SENS=1: every factorization of a lock-step batch is followed by its removal search in the same stage and the
-    result is used when the step turns out not to be blocked — half the stages, the same trajectories."""
+    """default since round 2 (LEXLS_LSI_SPECULATIVE_SENS=0 switches it off): every factorization of a lock-step batch is followed by its removal
+    search in the same stage and the result is used when the step turns out not to be blocked — fewer stages, the same trajectories."""
     n, dims, batch = 16, [5, 4, 6, 5], 12
     problems = [P.lsi_problem(2100 + b, n, dims) for b in range(batch)]
+    monkeypatch.setenv("LEXLS_LSI_SPECULATIVE_SENS", "0")
     plain = lexlsi.lsi_batch_solve(n, problems)
     monkeypatch.setenv("LEXLS_LSI_SPECULATIVE_SENS", "1")
     spec = lexlsi.lsi_batch_solve(n, problems)
