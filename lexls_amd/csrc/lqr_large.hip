@@ -17,6 +17,7 @@
 #include "lqr_wave_common.h"
 
 #include <cfloat>
+#include <cstdlib>
 #include <vector>
 
 namespace lexls
@@ -833,6 +834,337 @@ namespace lexls
             }
         }
 
+        // -----------------------------------------------------------------------------------------------------------------
+        // The pivots of ONE level inside ONE launch (single problems: BASELINE configs[1]).  fast_step pays ~7 us per pivot: the floor of
+        // a launch that depends on its predecessor (~3 us) plus two dependent round trips to data other XCDs wrote.  Here the level's
+        // trailing matrix stays in the LDS of G workgroups (8 columns each) for the whole level and a pivot costs ONE hand-off:
+        //   every workgroup publishes {largest down-dated norm of its columns, that column's position / index} AND that column's
+        //   remaining rows (its candidate for the pivot column), arrives at a counter, waits for all G arrivals, reads the G small
+        //   records, picks the winner (first maximum by position — the same in every workgroup), reads the winner's column, forms the
+        //   reflector itself and updates its own tile.  Buffers alternate by pivot parity: a workgroup can only be one step ahead.
+        // Hand-off protocol (MI355X_MICROARCH.md, valid forms): every published byte is an sc1 (agent-scope relaxed atomic) store, every
+        // storing wave drains (s_waitcnt vmcnt(0)) before the workgroup barrier, ONE lane adds to the agent-scope counter; the consumer
+        // polls the counter with sc1 loads from one lane, a workgroup barrier follows, every load of published bytes is an sc1 load.
+        // Every spin is bounded: a workgroup that gives up raises `abort`, which every spin watches — the launch then ends and the host
+        // falls back to the step-per-pivot kernels.
+        // -----------------------------------------------------------------------------------------------------------------
+        struct PersistCtl
+        {
+            uint32_t arrive; // monotonic over the pivots of the level
+            uint32_t abort;
+            uint32_t pad[14];
+        };
+        struct PersistCand
+        {
+            double norm;
+            uint32_t pos, idx;
+        };
+        __device__ __forceinline__ void st_sc1(double *p, double v)
+        {
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __device__ __forceinline__ double ld_sc1(const double *p)
+        {
+            return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        constexpr int PTC = 8; // columns per workgroup (two per wavefront)
+
+        __global__ __launch_bounds__(256) void fast_level_persist(LseArgs a, FastBuffers fb, PersistCtl *ctl, PersistCand *cand, double *colbuf, uint32_t colld,
+                                                                  uint32_t cur, uint32_t pp, uint32_t level, uint32_t G)
+        {
+            extern __shared__ double smem[];
+            __shared__ double red_v[4];
+            __shared__ uint32_t red_p[4], red_i[4], red_w[4];
+            __shared__ double sums[8];
+            __shared__ uint32_t flag;
+            const uint32_t b = 0, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, t = blockIdx.x;
+            const LargeState s = fb.st[pp][b];
+            const uint32_t n = a.nVar, cap = a.cap;
+            if (s.exhausted || s.dim == 0) return; // the same in every workgroup: nobody waits for anybody
+            const uint32_t dim = s.dim, F = s.F;
+            double *W          = fb.W[cur] + (size_t)b * cap * (n + 1);
+            const uint32_t ldt = dim | 1u;
+            double *tile   = smem;                      // PTC x ldt
+            double *colv   = tile + (size_t)PTC * ldt;  // dim
+            double *es     = colv + dim;                // dim
+            double *nrm    = es + dim;                  // PTC: down-dated norms of the own columns
+            uint32_t *posm = reinterpret_cast<uint32_t *>(nrm + PTC); // n + 1: position of every physical column (kept by every workgroup)
+            uint32_t *invm = posm + (n + 1);                          // n + 1: physical column at every position
+
+            for (uint32_t e = tid; e < (uint32_t)PTC * dim; e += 256)
+            {
+                const uint32_t jj = e / dim, i = e - jj * dim, j = t * PTC + jj;
+                tile[jj * ldt + i] = (j <= n) ? W[F + i + (size_t)j * cap] : 0.0;
+            }
+            for (uint32_t j = tid; j <= n; j += 256)
+            {
+                posm[j] = j;
+                invm[j] = j;
+            }
+            if (tid < (uint32_t)PTC)
+            {
+                const uint32_t j = t * PTC + tid;
+                nrm[tid]         = (j < n) ? fb.norms[pp][(size_t)b * n + j] : -1.0;
+            }
+            __syncthreads();
+
+            uint32_t c = s.ColIndex, rank = 0, stop = 0, exhausted = 0;
+#ifdef LEXLS_PERSIST_STAMPS
+            long long pst[6] = {0, 0, 0, 0, 0, 0}, pt0 = clock64();
+#define PSTAMP(i) { const long long t_ = clock64(); pst[i] += t_ - pt0; pt0 = t_; }
+#else
+#define PSTAMP(i)
+#endif
+            for (uint32_t counter = 0; counter < dim; counter++)
+            {
+                const uint32_t R = dim - counter, par = counter & 1u;
+                // ---- own candidate: first maximum by position among the own live columns ----
+                if (tid == 0)
+                {
+                    double bv   = -1.0;
+                    uint32_t bp = 0xffffffffu, bj = 0;
+                    for (int jj = 0; jj < PTC; jj++)
+                    {
+                        const uint32_t j = t * PTC + jj;
+                        if (j < n && posm[j] >= c && (nrm[jj] > bv || (nrm[jj] == bv && posm[j] < bp)))
+                        {
+                            bv = nrm[jj];
+                            bp = posm[j];
+                            bj = j;
+                        }
+                    }
+                    red_v[0] = bv;
+                    red_p[0] = bp;
+                    red_i[0] = bj;
+                }
+                __syncthreads();
+                const uint32_t myp = red_p[0], myj = red_i[0];
+                const double myv   = red_v[0];
+                __syncthreads();
+                // ---- publish: record + the candidate column's remaining rows ----
+                double *mycol = colbuf + ((size_t)par * G + t) * colld;
+                if (myp != 0xffffffffu)
+                    for (uint32_t i = tid; i < R; i += 256) st_sc1(mycol + i, tile[(myj - t * PTC) * ldt + counter + i]);
+                if (tid == 0)
+                {
+                    PersistCand *cd = cand + (size_t)par * G + t;
+                    st_sc1(&cd->norm, myv);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&cd->pos), ((unsigned long long)myj << 32) | myp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                PSTAMP(0)
+                if (tid == 0)
+                {
+                    __hip_atomic_fetch_add(&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t want = G * (counter + 1);
+                    uint32_t ok = 0;
+                    for (uint32_t spin = 0; spin < (1u << 20); spin++)
+                    {
+                        if (__hip_atomic_load(&ctl->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want)
+                        {
+                            ok = 1;
+                            break;
+                        }
+                        if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!ok) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag = ok;
+                }
+                __syncthreads();
+                if (!flag) return; // (uniform per workgroup; the others see `abort`)
+                PSTAMP(1)
+
+                // ---- winner among the G candidates (every workgroup for itself) ----
+                double bv   = -1.0;
+                uint32_t bp = 0xffffffffu, bi = 0, bw = 0;
+                for (uint32_t w = tid; w < G; w += 256)
+                {
+                    const PersistCand *cd       = cand + (size_t)par * G + w;
+                    const double v              = ld_sc1(&cd->norm);
+                    const unsigned long long pi = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(&cd->pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t p            = (uint32_t)pi;
+                    if (p != 0xffffffffu && (v > bv || (v == bv && p < bp)))
+                    {
+                        bv = v;
+                        bp = p;
+                        bi = (uint32_t)(pi >> 32);
+                        bw = w;
+                    }
+                }
+                {
+                    const double wm         = wave_max(bv);
+                    unsigned long long tied = __ballot(bv == wm && bp != 0xffffffffu);
+                    uint32_t bestp = 0xffffffffu, besti = 0, bestw = 0;
+                    while (tied)
+                    {
+                        const int l = (int)__builtin_ctzll(tied);
+                        tied &= tied - 1;
+                        const uint32_t p2 = (uint32_t)__builtin_amdgcn_readlane((int)bp, l);
+                        if (p2 < bestp)
+                        {
+                            bestp = p2;
+                            besti = (uint32_t)__builtin_amdgcn_readlane((int)bi, l);
+                            bestw = (uint32_t)__builtin_amdgcn_readlane((int)bw, l);
+                        }
+                    }
+                    if (lane == 0)
+                    {
+                        red_v[wave] = wm;
+                        red_p[wave] = bestp;
+                        red_i[wave] = besti;
+                        red_w[wave] = bestw;
+                    }
+                }
+                __syncthreads();
+                double v0   = red_v[0];
+                uint32_t p0 = red_p[0], piv = red_i[0], wwin = red_w[0];
+#pragma unroll
+                for (int w = 1; w < 4; w++)
+                {
+                    const double v2   = red_v[w];
+                    const uint32_t p2 = red_p[w];
+                    if (p2 != 0xffffffffu && (p0 == 0xffffffffu || v2 > v0 || (v2 == v0 && p2 < p0)))
+                    {
+                        v0   = v2;
+                        p0   = p2;
+                        piv  = red_i[w];
+                        wwin = red_w[w];
+                    }
+                }
+                const uint32_t ppos = p0;
+                PSTAMP(2)
+
+                // ---- the pivot column (published by its owner), fresh / tail norms, reflector: as in fast_step ----
+                const double *pcol = colbuf + ((size_t)par * G + wwin) * colld;
+                double fr = 0.0, tl = 0.0;
+                for (uint32_t i = tid; i < R; i += 256)
+                {
+                    const double w = ld_sc1(pcol + i);
+                    colv[i]        = w;
+                    fr             = dfma(w, w, fr);
+                    if (i > 0) tl = dfma(w, w, tl);
+                }
+                fr = wave_sum(fr);
+                tl = wave_sum(tl);
+                if (lane == 0)
+                {
+                    sums[wave]     = fr;
+                    sums[4 + wave] = tl;
+                }
+                __syncthreads();
+                const double fresh  = (sums[0] + sums[1]) + (sums[2] + sums[3]);
+                const double tailSq = (sums[4] + sums[5]) + (sums[6] + sums[7]);
+                PSTAMP(3)
+                if (fresh < a.tol) // rank test (lexlse.h:214): the level ends here, in every workgroup
+                {
+                    stop = 1;
+                    break;
+                }
+                const double c0v = colv[0];
+                double tau = 0.0, diag = c0v, den = 1.0;
+                bool degenerate = true;
+                if (R > 1 && !(tailSq <= DBL_MIN))
+                {
+                    degenerate  = false;
+                    double beta = sqrt(dfma(c0v, c0v, tailSq));
+                    if (c0v >= 0.0) beta = -beta;
+                    diag = beta;
+                    den  = c0v - beta;
+                    tau  = (beta - c0v) / beta;
+                }
+                for (uint32_t i = 1 + tid; i < R; i += 256) es[i] = degenerate ? 0.0 : colv[i] / den;
+                // the swap of lexlse.h:222-232 on both maps (every workgroup keeps them)
+                if (tid == 0)
+                {
+                    const uint32_t front = invm[c];
+                    posm[piv]   = c;
+                    invm[c]     = piv;
+                    if (front != piv)
+                    {
+                        posm[front] = ppos;
+                        invm[ppos]  = front;
+                    }
+                }
+                __syncthreads();
+
+                // ---- own tile ----
+#pragma unroll
+                for (int h = 0; h < PTC / 4; h++)
+                {
+                    const uint32_t jj = wave * (PTC / 4) + h, j = t * PTC + jj;
+                    if (j > n) continue;
+                    const bool trailing = (j == n) || (posm[j] > c);
+                    if (!trailing) continue;
+                    double *col = tile + jj * ldt + counter;
+                    double a0n;
+                    const double a0 = col[0];
+                    if (tau != 0.0)
+                    {
+                        double part = 0.0;
+                        for (uint32_t i = 1 + lane; i < R; i += 64) part = dfma(es[i], col[i], part);
+                        const double tmp = wave_sum(part) + a0;
+                        const double nt  = -tau;
+                        a0n              = dfma(nt, tmp, a0);
+                        for (uint32_t i = 1 + lane; i < R; i += 64) col[i] = dfma(es[i] * nt, tmp, col[i]);
+                        if (lane == 0) col[0] = a0n;
+                    }
+                    else
+                        a0n = a0;
+                    if (lane == 0 && j < n) nrm[jj] = dfma(-a0n, a0n, nrm[jj]);
+                }
+                // bookkeeping of this pivot: spread over the workgroups (workgroup `counter % G` writes it) so that no single workgroup is
+                // late at every hand-off
+                if (t == counter % G)
+                {
+                    double *E = fb.E + ((size_t)b * fb.eld + counter) * fb.eld;
+                    for (uint32_t i = 1 + tid; i < R; i += 256) E[i] = es[i];
+                    if (tid == 0)
+                    {
+                        fb.D[(size_t)b * n + c]   = diag;
+                        a.perm[(size_t)b * n + c] = ppos;
+                        if (R > 1) a.hh[(size_t)b * cap + F + counter] = tau;
+                    }
+                }
+                c++;
+                rank++;
+                __syncthreads();
+                PSTAMP(4)
+                if (c == n)
+                {
+                    exhausted = 1;
+                    break;
+                }
+            }
+#ifdef LEXLS_PERSIST_STAMPS
+            if (t == 1 && tid == 0)
+                for (int i_ = 0; i_ < 5; i_++) a.lambda[8 * level + i_] = (double)pst[i_];
+#endif
+            // ---- back to memory: the tile, the position map, the state ----
+            __syncthreads();
+            for (uint32_t e = tid; e < (uint32_t)PTC * dim; e += 256)
+            {
+                const uint32_t jj = e / dim, i = e - jj * dim, j = t * PTC + jj;
+                if (j <= n) W[F + i + (size_t)j * cap] = tile[jj * ldt + i];
+            }
+            if (t == 0)
+            {
+                uint32_t *pos_out = fb.pos[pp ^ 1u] + (size_t)b * (n + 1);
+                for (uint32_t j = tid; j <= n; j += 256) pos_out[j] = posm[j];
+                if (tid == 0)
+                {
+                    LargeState so   = s;
+                    so.ColIndex     = c;
+                    so.rank         = rank;
+                    so.exhausted    = exhausted;
+                    so.stop_level   = stop;
+                    so.last_id      = pp ^ 1u;
+                    fb.st[pp ^ 1u][b] = so;
+                }
+            }
+        }
+
         /// level end: rank / first column, then the whole matrix in the level's final column order -> the other work buffer
         __global__ __launch_bounds__(256) void fast_level_end(LseArgs a, FastBuffers fb, uint32_t cur, uint32_t pp, uint32_t level)
         {
@@ -1057,7 +1389,9 @@ namespace lexls
     size_t large_fast_workspace_bytes(uint32_t batch, uint32_t n, uint32_t cap, uint32_t maxdim)
     {
         const size_t ps = (size_t)cap * (n + 1);
-        return 8 * ((size_t)batch * ps + 3 * (size_t)batch * n + (size_t)batch * maxdim * maxdim) + 4 * 2 * (size_t)batch * (n + 1) + 2 * sizeof(LargeState) * (size_t)batch + 256;
+        const size_t G = (n + PTC) / PTC; // workgroups of the one-launch-per-level form
+        return 8 * ((size_t)batch * ps + 3 * (size_t)batch * n + (size_t)batch * maxdim * maxdim) + 4 * 2 * (size_t)batch * (n + 1) + 2 * sizeof(LargeState) * (size_t)batch + 256 +
+               sizeof(PersistCtl) + 2 * G * sizeof(PersistCand) + 8 * 2 * G * (size_t)maxdim + 64;
     }
 
     /// the fast large path (see the comment above fast_level_begin); gemm_only_mfma: the bit-exact multi-launch path with its trailing update on the matrix cores
@@ -1088,6 +1422,21 @@ namespace lexls
         fb.pos[0] = reinterpret_cast<uint32_t *>(w);
         w += 4 * (size_t)B * (n + 1);
         fb.pos[1] = reinterpret_cast<uint32_t *>(w);
+        w += 4 * (size_t)B * (n + 1);
+        w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(w) + 63) & ~(uintptr_t)63);
+        PersistCtl *ctl = reinterpret_cast<PersistCtl *>(w);
+        w += sizeof(PersistCtl);
+        const uint32_t G  = (n + PTC) / PTC;
+        PersistCand *cand = reinterpret_cast<PersistCand *>(w);
+        w += 2 * (size_t)G * sizeof(PersistCand);
+        double *colbuf = reinterpret_cast<double *>(w);
+        // single problems, on request (LEXLS_LARGE_PERSIST=1): the pivots of a level in ONE launch (fast_level_persist).  Measured on MI355X it is
+        // NOT faster than a launch per pivot (configs[1]: 3.69 ms vs 3.59 ms): one pivot costs ~6.4 us either way — publish + drain 1.4 us,
+        // arrive + wait for 65 workgroups 2.2-3.6 us, two dependent sc1 reads 1.3 us, reflector + tile 0.6-1.5 us (stamps, scripts/persist_stamps.py) —
+        // a cross-XCD hand-off through memory is as expensive as the kernel boundary it replaces.  Kept as the measured basis for the next step
+        // (fewer hand-offs per pivot); the default stays the launch per pivot, which cannot spin.
+        const size_t persist_lds = 8 * ((size_t)PTC * (maxdim | 1u) + 2 * (size_t)maxdim + PTC) + 8 * (size_t)(n + 1);
+        const bool persist       = B == 1 && G <= 128 && persist_lds <= kMaxLdsBytes && a.skip == nullptr && std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) != 0;
 
         hipError_t e         = hipSuccess;
         const size_t step_lds = 16 * (size_t)maxdim;
@@ -1095,6 +1444,8 @@ namespace lexls
         if (step_lds > kMaxLdsBytes) return hipErrorInvalidValue;
         if (step_lds > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(fast_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds);
         if (e == hipSuccess && lds.trsm > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(large_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.trsm);
+        if (e == hipSuccess && persist && persist_lds > 64 * 1024)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(fast_level_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds);
         if (e != hipSuccess) return e;
 
         hipLaunchKernelGGL(large_init, dim3(64, B), dim3(256), 0, s, a, fb.st[0]);
@@ -1104,7 +1455,14 @@ namespace lexls
         for (uint32_t level = 0; level < a.nObj; level++)
         {
             hipLaunchKernelGGL(fast_level_begin, dim3((n + 4) / 4, B), dim3(256), 0, s, a, fb, cur, pp, level);
-            if (!all_exhausted)
+            if (!all_exhausted && persist)
+            {
+                e = hipMemsetAsync(ctl, 0, sizeof(PersistCtl), s);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(fast_level_persist, dim3(G), dim3(256), persist_lds, s, a, fb, ctl, cand, colbuf, maxdim, cur, pp, level, G);
+                pp ^= 1u;
+            }
+            else if (!all_exhausted)
                 for (uint32_t counter = 0; counter < h_level_max[level]; counter++)
                 {
                     hipLaunchKernelGGL(fast_step, dim3((n + FTC) / FTC, B), dim3(256), step_lds, s, a, fb, cur, pp, counter);
@@ -1134,6 +1492,15 @@ namespace lexls
                 all_exhausted = (a.skip == nullptr);
                 for (uint32_t b = 0; b < B && all_exhausted; b++)
                     if (!host[b].exhausted) all_exhausted = false;
+                if (persist)
+                {
+                    PersistCtl hc;
+                    e = hipMemcpyAsync(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost, s);
+                    if (e != hipSuccess) return e;
+                    e = hipStreamSynchronize(s);
+                    if (e != hipSuccess) return e;
+                    if (hc.abort) return hipErrorLaunchFailure; // a hand-off timed out (never observed; the spins are bounded so that this cannot hang)
+                }
             }
         }
         if (cur != 0) hipLaunchKernelGGL(fast_copy_back, dim3(64, B), dim3(256), 0, s, a, fb, cur);

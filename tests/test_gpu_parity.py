@@ -310,6 +310,17 @@ def test_large_path_rank_deficient_and_ragged(hip, oracle, policy):
     assert np.abs(s.get_v() - ref["v"]).max() <= (0.0 if policy == 5 else 1e-10)
 
 
+def test_large_path_one_launch_per_level(hip, oracle, monkeypatch):
+    """LEXLS_LARGE_PERSIST=1: the pivots of a level inside one launch (workgroups hand candidates and the pivot column to each other through
+    agent-scope sc1 stores / loads and a counter; every spin is bounded) — same contract as the default launch per pivot"""
+    monkeypatch.setenv("LEXLS_LARGE_PERSIST", "1")
+    n, dims = 150, [90, 90, 90]
+    lod = P.rank_deficient_problem(811, n, dims, [60, 50, 30])[None]
+    s, ref = run_both(hip, oracle, lod, dims, n)
+    assert ref["rank"][0].tolist() == [60, 50, 30]
+    check_large(s, ref, dims, n, 0)
+
+
 @LARGE_PATHS
 def test_large_path_ragged_rows_below(hip, oracle, policy):
     """a problem that is NOT the largest of the batch has the most rows below level 0 (the Gauss step's row grid must cover it)"""
