@@ -1,0 +1,2 @@
+#include "lqr_quad_impl.h"
+LEXLS_QUAD_INSTANCE(launch_quad_3x12_f, 3, 12, true, 0)

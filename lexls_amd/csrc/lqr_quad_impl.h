@@ -44,7 +44,6 @@ namespace lexls
         __global__ __launch_bounds__(64) void lqr_quad_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes)
         {
             static_assert(NS >= 1 && NS <= 4 && MD <= 16 && (MD % 2) == 0, "shape limits of the row layout");
-            static_assert(!WF, "factor output: see lqr_quad_wf (not in this instantiation)");
             extern __shared__ double smem[];
             char *const L  = reinterpret_cast<char *>(smem);
             const int lane = threadIdx.x & 63;
@@ -59,6 +58,13 @@ namespace lexls
             const size_t pstride = (size_t)cap * (n + 1);
             const double *in     = a.in + bb * pstride;
             const uint32_t *dims = a.dims + (size_t)bb * nObj;
+            double *out          = a.fac + bb * pstride; // (WF) get_lexqr layout: column = final position
+            if constexpr (WF)
+            {
+                if (live)
+                    for (int i = gl; i < cap; i += 16) a.hh[(size_t)b * cap + i] = 0.0; // initialize(), lexlse.h:1683
+            }
+            int parked_levels = 0; // (WF) bit k: the free columns of level k were written by physical column and are put in place at the end
 
             // ---- LDS carve-up of this row's slice (byte offsets; launch_quad_t computes group_bytes) ----
             const int o_img  = g * (int)group_bytes;
@@ -121,7 +127,9 @@ namespace lexls
             for (int k = 0; k < nObj; k++)
             {
                 const int dim   = (int)U32(o_dims + 4 * k);
-                const bool work = dim > 0 && !exh; // x only: once the columns are exhausted nothing below matters
+                const bool exh0 = exh;                      // columns exhausted before this level: no Householder loop
+                const bool work = dim > 0 && (WF || !exh); // x only: once the columns are exhausted nothing below matters; the factor
+                                                           // keeps the multipliers and the eliminated right-hand side of those rows too
                 const int Fc    = ColIndex;
                 int rank        = 0;
 
@@ -187,6 +195,7 @@ namespace lexls
                     // =====================================================================================
                     // Gauss elimination of these rows by every finished pivot c' (lexlse.h:431-471, left-looking)
                     // =====================================================================================
+                    const bool wf_aligned = __ballot(work && !(dim == MD && ((F | cap) & 1) == 0)) == 0ull; // (WF) 16-byte stores of a multiplier column
                     const int Fcmax = rows_max(work ? Fc : 0);
                     // Rows that take part all have Fc == Fcmax in a batch of equally shaped, full-rank problems: the pivots then run without
                     // any per-row predicate (a row that does not work in this level may compute garbage, nothing of it is kept).  A divergent
@@ -226,11 +235,17 @@ namespace lexls
                                         constexpr int r = decltype(rr)::value;
                                         lr[r]           = -gbc<lc>(blk[sc][r] * idgreg[sc]);
                                     });
+                                    // (WF) the pivot's own column must survive until the multipliers are written (after the loop): columns at or
+                                    // before pivot C absorb -l * 0 — their value is kept (an exact zero may change its sign, nothing else)
+                                    double uc[NS];
+#pragma unroll
+                                    for (int s = sc; s < NS; s++) uc[s] = ucur[s];
+                                    if constexpr (WF) uc[sc] = sel(gl > lc, ucur[sc], 0.0);
 #pragma unroll
                                     for (int s = sc; s < NS; s++)
                                     {
 #pragma unroll
-                                        for (int r = 0; r < MD; r++) blk[s][r] = dfma(lr[r], ucur[s], blk[s][r]);
+                                        for (int r = 0; r < MD; r++) blk[s][r] = dfma(lr[r], uc[s], blk[s][r]);
                                     }
                                 };
                                 if constexpr (MASKED)
@@ -248,6 +263,31 @@ namespace lexls
                         eliminate(std::false_type{});
                     else
                         eliminate(std::true_type{});
+                    if constexpr (WF)
+                    {
+                        // the multipliers L = A R^-1 of these rows (lexlse.h:441-446): column c' of the factor, final.  A pivot position's lane
+                        // still holds the value its column had when it was pivot c' of the loop above; the product with 1 / R_c'c' is the same one
+#pragma unroll
+                        for (int s = 0; s < NS; s++)
+                        {
+                            const int P0 = 16 * s + gl - SIG;
+                            if (work && P0 >= 0 && P0 < Fc)
+                            {
+                                double *dst = out + F + (size_t)P0 * cap;
+                                if (wf_aligned)
+                                {
+#pragma unroll
+                                    for (int r = 0; r < MD; r += 2) *reinterpret_cast<double2 *>(dst + r) = make_double2(blk[s][r] * idgreg[s], blk[s][r + 1] * idgreg[s]);
+                                }
+                                else
+                                {
+#pragma unroll
+                                    for (int r = 0; r < MD; r++)
+                                        if (r < dim) dst[r] = blk[s][r] * idgreg[s];
+                                }
+                            }
+                        }
+                    }
 
                     STAMP(7)
                     // =====================================================================================
@@ -265,7 +305,7 @@ namespace lexls
 #pragma unroll
                             for (int r = 0; r < MD; r++) nrm[s] = dfma(blk[s][r], blk[s][r], nrm[s]);
                         }
-                        bool go = work;
+                        bool go = work && !exh0;
                         for_each_index<0, MD>([&](auto cnt) __attribute__((always_inline)) {
                             constexpr int counter = decltype(cnt)::value;
                             const bool act        = go && counter < dim;
@@ -398,7 +438,8 @@ namespace lexls
                                     e[r]            = gbc<r>(qe);
                                     ett[r]          = gbc<r>(et);
                                 });
-                                if (__ballot(cont && tau == 0.0) == 0ull)
+                                // (WF: a row of the wavefront that has stopped must keep its block — dependent rows are part of the factor)
+                                if (__ballot(cont && tau == 0.0) == 0ull && (!WF || __ballot(!cont) == 0ull))
                                 {
 #pragma unroll
                                     for (int s = S0; s < NS; s++)
@@ -414,7 +455,7 @@ namespace lexls
                                 }
                                 else // some row has H = I (lexlse.h:239): there the block must come through bit for bit
                                 {
-                                    const bool app = tau != 0.0;
+                                    const bool app = tau != 0.0 && (!WF || cont);
 #pragma unroll
                                     for (int s = S0; s < NS; s++)
                                     {
@@ -428,7 +469,13 @@ namespace lexls
                                     }
                                 }
 #pragma unroll
-                                for (int s = S0; s < NS; s++) blk[s][counter] = sel(isp[s], diag, blk[s][counter]);
+                                for (int s = S0; s < NS; s++) blk[s][counter] = sel(isp[s] && (!WF || cont), diag, blk[s][counter]);
+                                if constexpr (WF)
+                                {
+                                    // essential part and tau leave at once (lane r holds the entry of row r); the column's rows above stay intact
+                                    if (cont && gl > counter && gl < dim) out[F + gl + (size_t)ColIndex * cap] = qe;
+                                    if (cont && gl == 0) a.hh[(size_t)b * cap + F + counter] = tau;
+                                }
                             }
                             else
                             {
@@ -478,6 +525,25 @@ namespace lexls
                             for (int p = 0; p < MD; p++) D(sel(p < rank, base + 8 * p * wk, dump)) = blk[s][p];
                             B8(o_emap + 8 * pc[s] + k) = (uint8_t)e;
                             if (P0 < n) B8(o_phys + pos[s]) = (uint8_t)pc[s];
+                        }
+                        if constexpr (WF)
+                        {
+                            // factor rows of this level (get_lexqr: column = final position).  Pivot columns of the level: the rows down to
+                            // their diagonal are intact and final (essential parts left at pivot time); the right-hand side: position n;
+                            // columns still free: rows below the rank (a rank-deficient level only) wait at their CURRENT position — free
+                            // positions hold nothing else — and move to the final one at the end (rows above: from the image)
+                            const bool parked = work && !exh0 && rank != dim && ColIndex < n;
+                            if (parked) parked_levels |= 1 << k;
+                            if (work && P0 >= 0 && P0 <= n && (P0 == n || (!exh0 && P0 >= Fc)))
+                            {
+                                const int pe = pos[s];
+                                double *dst  = out + F + (size_t)pe * cap;
+                                const int j  = pe - Fc;
+                                const bool rhs = P0 == n, pivc = !rhs && j < rank, fr = !rhs && !pivc && parked;
+#pragma unroll
+                                for (int p = 0; p < MD; p++)
+                                    if (p < dim && (rhs || (pivc && p <= j) || (fr && p >= rank))) dst[p] = blk[s][p];
+                            }
                         }
                         // pivot position P0 of this level: its image row and the selector of this level's index byte
                         const bool piv = work && P0 >= Fc && P0 < Fc + rank;
@@ -550,6 +616,56 @@ namespace lexls
                 quad_lds_fence();
             }
 
+            if constexpr (WF)
+            {
+                // ---- the factor's free columns: T entries from the images, parked rows to their final positions ----
+                __builtin_amdgcn_s_waitcnt(0); // every factor store of this wavefront has been issued before the parked rows are read back
+                int Fk = 0;
+                for (int k = 0; k < nObj; k++)
+                {
+                    const int dimk = (int)U32(o_dims + 4 * k);
+                    const int Fck = (int)U32(o_meta + 16 * k), rkk = (int)U32(o_meta + 16 * k + 4), okk = (int)U32(o_meta + 16 * k + 8), wkk = (int)U32(o_meta + 16 * k + 12);
+                    const bool hhran = live && dimk > 0 && Fck < n;
+                    if (__ballot(hhran) != 0ull)
+                    {
+                        const bool parked = (parked_levels >> k) & 1;
+                        double keep[NS][MD];
+                        int src[NS];
+                        bool mine[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; s++)
+                        {
+                            const int P = 16 * s + gl;
+                            mine[s]     = hhran && P < n && P >= Fck + rkk; // free when level k ended
+                            const int e = mine[s] ? (int)B8(o_emap + 8 * (int)B8(o_phys + P) + k) : 0;
+                            src[s]      = Fck + e; // its position when level k ended
+#pragma unroll
+                            for (int p = 0; p < MD; p++)
+                            {
+                                double v = 0.0;
+                                if (mine[s] && p < rkk)
+                                    v = D(o_img + 8 * (okk + p * wkk + e));
+                                else if (mine[s] && parked && p < dimk)
+                                    v = out[Fk + p + (size_t)src[s] * cap];
+                                keep[s][p] = v;
+                            }
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // all parked rows are in registers before any of them is overwritten
+#pragma unroll
+                        for (int s = 0; s < NS; s++)
+                        {
+                            const int P = 16 * s + gl;
+                            if (mine[s])
+                            {
+#pragma unroll
+                                for (int p = 0; p < MD; p++)
+                                    if (p < rkk || (parked && p < dimk)) out[Fk + p + (size_t)P * cap] = keep[s][p];
+                            }
+                        }
+                    }
+                    Fk += dimk;
+                }
+            }
             STAMP(9)
             // ---- results ----
             if (live)

@@ -20,6 +20,8 @@ namespace lexls
     hipError_t launch_quad_3x12_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_4x16_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12s7_x(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_3x12_f(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_3x12s7_f(const LseArgs &a, hipStream_t s);
     size_t quad_lds_bytes(uint32_t slots, uint32_t md, uint32_t nVar, uint32_t nObj);
 
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed)
@@ -52,7 +54,7 @@ namespace lexls
         const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
         // four problems per wavefront (lqr_quad_impl.h): x-only, no fixed variables; one wave per SIMD serves 4 x 4 x CUs problems per round.
         // left_looking == 2 forces it (parity tests), automatic dispatch takes it wherever the left-looking kernel would have been taken
-        const bool quad_ok = !write_factor && !has_fixed;
+        const bool quad_ok = !has_fixed;
         if (quad_ok && (left_looking == 2 || (left_looking == 0 && lwave_pays)))
         {
             size_t lds = (max_level_dim <= 12) ? quad_lds_bytes(3, 12, a.nVar, a.nObj) : 0;
@@ -60,13 +62,13 @@ namespace lexls
             {
                 if (a.nVar == 40) // the IK shape: columns right-aligned in the slots (see SIG in lqr_quad_impl.h)
                 {
-                    *variant = "lqr_quad<3,12,shift 7>";
-                    return launch_quad_3x12s7_x(a, s);
+                    *variant = write_factor ? "lqr_quad<3,12,shift 7,factor>" : "lqr_quad<3,12,shift 7>";
+                    return write_factor ? launch_quad_3x12s7_f(a, s) : launch_quad_3x12s7_x(a, s);
                 }
-                *variant = "lqr_quad<3,12>";
-                return launch_quad_3x12_x(a, s);
+                *variant = write_factor ? "lqr_quad<3,12,factor>" : "lqr_quad<3,12>";
+                return write_factor ? launch_quad_3x12_f(a, s) : launch_quad_3x12_x(a, s);
             }
-            lds = (max_level_dim <= 16) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0; // n + 1 <= 64, level dims <= 16
+            lds = (max_level_dim <= 16 && !write_factor) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0; // n + 1 <= 64, level dims <= 16 (x-only)
             if (lds && lds <= kMaxLdsBytes)
             {
                 *variant = "lqr_quad<4,16>";

@@ -84,7 +84,7 @@ def test_ik_batch_bit_exact(hip, oracle, force_generic):
     assert (ref["rank"] == [12, 12, 12, 4, 0]).all()
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
-    assert s.last_kernel() == {0: "lqr_wave<41,12,exact>", 1: "lqr_generic<64,lds>", 2: "lqr_wave<41,12,exact>", 3: "lqr_lwave<41,12,exact>", 4: "lqr_lwave<41,12,exact>"}[force_generic]  # 4 with the factor kept: the quad kernel is x-only, the left-looking one serves it
+    assert s.last_kernel() == {0: "lqr_wave<41,12,exact>", 1: "lqr_generic<64,lds>", 2: "lqr_wave<41,12,exact>", 3: "lqr_lwave<41,12,exact>", 4: "lqr_quad<3,12,shift 7,factor>"}[force_generic]
 
 
 @BOTH_PATHS
@@ -175,6 +175,38 @@ def test_quad_kernel_shapes(hip, oracle, n, dims, batch):
 def test_quad_kernel_wide_shapes(hip, oracle, n, dims):
     """the <4 slots, 16 rows> instantiation: n + 1 <= 64, level dims <= 16 (the IK families beyond 47 variables / 12 rows per level)"""
     _quad_x_only(hip, oracle, P.lse_batch(3000 + n, 7, n, dims), dims, n, kernel="lqr_quad<4,16>")
+
+
+@pytest.mark.parametrize("n,dims", [(47, [12, 12, 12, 12]), (30, [9, 12, 5]), (40, [6] * 5), (5, [12, 12]), (40, [12, 0, 12, 12, 12]), (12, [1] * 8), (33, [11, 7, 12, 3]),
+                                    (40, [12] * 5)])
+def test_quad_kernel_factor_output(hip, oracle, n, dims):
+    """the factor-keeping instantiation: get_lexqr layout (multipliers, R / T blocks, essential parts, eliminated rows of the levels after the
+    columns ran out), Householder scalars, pivots and x bit for bit"""
+    s, ref = run_both(hip, oracle, P.lse_batch(4000 + n, 11, n, dims), dims, n, keep_factor=True, force_generic=4)
+    assert s.last_kernel() == ("lqr_quad<3,12,shift 7,factor>" if n == 40 else "lqr_quad<3,12,factor>")
+    assert_factor_equal(s, ref, dims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    np.testing.assert_array_equal(s.get_v(), ref["v"])  # the residual kernel reads the stored factor
+
+
+def test_quad_kernel_factor_output_rank_deficient_and_ragged(hip, oracle):
+    """dependent rows of a rank-deficient level wait at their current position and move with later swaps; wavefronts whose rows stop at
+    different pivots keep the stopped rows' blocks"""
+    n, dims = 15, [5, 5, 5, 5]
+    lod = np.stack([P.rank_deficient_problem(500 + b, n, dims, [3, 3, 3, 3] if b % 2 else [5, 2, 4, 1]) for b in range(14)])
+    s, ref = run_both(hip, oracle, lod, dims, n, keep_factor=True, force_generic=4)
+    assert s.last_kernel() == "lqr_quad<3,12,factor>"
+    assert_factor_equal(s, ref, dims, n)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    n3, cap3 = 20, [8, 8, 8]
+    rd = np.array([[8, 8, 8], [3, 0, 5], [1, 8, 2], [0, 0, 4], [8, 1, 0], [5, 5, 5], [2, 2, 2], [7, 3, 8]], np.uint32)
+    full = np.zeros((8, n3 + 1, 24))
+    for b in range(8):
+        m = int(rd[b].sum())
+        full[b, :, :m] = P.lse_problem(900 + b, n3, rd[b])
+    s, ref = run_both(hip, oracle, full, rd, n3, maxdim=np.array(cap3, np.uint32), keep_factor=True, force_generic=4)
+    assert_factor_equal(s, ref, rd, n3)
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
 def test_quad_kernel_rank_deficient_and_ragged(hip, oracle):
