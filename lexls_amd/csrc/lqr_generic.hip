@@ -513,15 +513,26 @@ namespace lexls
                     for (uint32_t j = 0; j < acc; j++) s = dfma(-W[F + i + (c0 + j) * ld], xs[c0 + j], s);
                     xs[Fc + i] = s;
                 }
+                // the diagonal of R_k once into LDS; the column of the NEXT step is requested before the current step's division, so that a
+                // step costs one division + one barrier instead of two dependent trips to the stored factor (same operations, same order)
+                double *dgl = xs + n;
+                for (uint32_t i = tid; i < rank; i += NT) dgl[i] = W[F + i + (Fc + i) * ld];
+                double wcur = (rank >= 2 && tid + 1 < rank) ? W[F + tid + (Fc + rank - 1) * ld] : 0.0; // my row's entry of column rank-1
                 __syncthreads();
+                double xprev = 0.0;
                 for (uint32_t j = rank; j--;)
                 {
-                    if (tid == 0) xs[Fc + j] = xs[Fc + j] / W[F + j + (Fc + j) * ld];
+                    const double wnext = (j >= 1 && tid + 1 < j) ? W[F + tid + (Fc + j - 1) * ld] : 0.0;
+                    if (j + 1 < rank && tid == 0) xs[Fc + j + 1] = xprev; // (nobody reads that entry any more in this loop)
+                    const double xj = xs[Fc + j] / dgl[j];                 // every thread for itself: no hand-off
+                    if (tid < j) xs[Fc + tid] = dfma(-wcur, xj, xs[Fc + tid]);
+                    for (uint32_t i = tid + NT; i < j; i += NT) xs[Fc + i] = dfma(-W[F + i + (Fc + j) * ld], xj, xs[Fc + i]);
                     __syncthreads();
-                    const double xj = xs[Fc + j];
-                    for (uint32_t i = tid; i < j; i += NT) xs[Fc + i] = dfma(-W[F + i + (Fc + j) * ld], xj, xs[Fc + i]);
-                    __syncthreads();
+                    wcur  = wnext;
+                    xprev = xj;
                 }
+                if (tid == 0) xs[Fc] = xprev;
+                __syncthreads();
                 acc += rank;
             }
             if (tid == 0)
@@ -1254,7 +1265,7 @@ namespace lexls
 
     hipError_t launch_solve_generic(const LseArgs &a, hipStream_t s)
     {
-        const size_t lds = 8 * (size_t)a.nVar + 16;
+        const size_t lds = 16 * (size_t)a.nVar + 16; // x by position + the diagonal of the level being solved
         if (a.nVar + 1 <= 64)
         {
             hipError_t e = set_lds(solve_generic_kernel<64>, lds);

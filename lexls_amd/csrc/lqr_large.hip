@@ -543,7 +543,15 @@ namespace lexls
             return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
         }
 
-        constexpr int FTC = 8;         // columns per workgroup of the step kernel (two per wavefront)
+#ifndef LEXLS_FAST_NW
+#define LEXLS_FAST_NW 4
+#endif
+#ifndef LEXLS_FAST_CPW
+#define LEXLS_FAST_CPW 1
+#endif
+        constexpr int FNW = LEXLS_FAST_NW, FNT = 64 * FNW; // wavefronts / threads per workgroup of the step kernel
+        constexpr int FCPW = LEXLS_FAST_CPW;                // columns per wavefront
+        constexpr int FTC  = FNW * FCPW;                    // columns per workgroup
         constexpr int FRC = 4;         // rows a lane keeps in registers between the dot product and the update (R <= 64 * FRC)
 
         struct FastBuffers
@@ -598,12 +606,12 @@ namespace lexls
         }
 
         /// one pivot of the level: search, reflector, application to this workgroup's tile, norm down-date
-        __global__ __launch_bounds__(256) void fast_step(LseArgs a, FastBuffers fb, uint32_t cur, uint32_t pin, uint32_t counter)
+        __global__ __launch_bounds__(FNT) void fast_step(LseArgs a, FastBuffers fb, uint32_t cur, uint32_t pin, uint32_t counter)
         {
             extern __shared__ double smem[];
-            __shared__ double red_v[4];
-            __shared__ uint32_t red_p[4], red_i[4];
-            __shared__ double sums[8];
+            __shared__ double red_v[FNW];
+            __shared__ uint32_t red_p[FNW], red_i[FNW];
+            __shared__ double sums[2 * FNW];
             const uint32_t b = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
             if (skipped(a, b)) return;
             const uint32_t pout = pin ^ 1u;
@@ -614,13 +622,13 @@ namespace lexls
             uint32_t *pos_out      = fb.pos[pout] + (size_t)b * (n + 1);
             // Everything whose ADDRESS does not depend on the pivot is requested up front, so that a step is two dependent round trips to
             // L2 / memory (state + norms + positions + own tile, then the pivot column) instead of four: the search candidates of this thread
-            constexpr int NCAND = 4; // candidates per thread in registers (n <= 1024); beyond that the loop below reads again
+            constexpr int NCAND = 1024 / FNT; // candidates per thread in registers (n <= 1024); beyond that the loop below reads again
             double cv[NCAND];
             uint32_t cp[NCAND];
 #pragma unroll
             for (int u = 0; u < NCAND; u++)
             {
-                const uint32_t k = tid + 256u * u;
+                const uint32_t k = tid + (uint32_t)FNT * u;
                 cv[u]            = (k < n) ? norms_in[k] : -1.0;
                 cp[u]            = (k < n) ? pos_in[k] : 0u;
             }
@@ -638,11 +646,11 @@ namespace lexls
             double *es   = smem + R; // R: essential part (es[i], i >= 1)
 
             // ... and this wavefront's two columns of the tile (rows across the lanes)
-            double keep[FTC / 4][FRC];
+            double keep[FCPW][FRC];
 #pragma unroll
-            for (int h = 0; h < FTC / 4; h++)
+            for (int h = 0; h < FCPW; h++)
             {
-                const uint32_t j = blockIdx.x * FTC + wave * (FTC / 4) + h;
+                const uint32_t j = blockIdx.x * FTC + wave * FCPW + h;
 #pragma unroll
                 for (int u = 0; u < FRC; u++)
                 {
@@ -657,7 +665,7 @@ namespace lexls
 #pragma unroll
             for (int u = 0; u < NCAND; u++)
             {
-                const uint32_t k = tid + 256u * u;
+                const uint32_t k = tid + (uint32_t)FNT * u;
                 if (k < n && cp[u] >= c && (cv[u] > bv || (cv[u] == bv && cp[u] < bp)))
                 {
                     bv = cv[u];
@@ -665,7 +673,7 @@ namespace lexls
                     bi = k;
                 }
             }
-            for (uint32_t k = tid + 256u * NCAND; k < n; k += 256)
+            for (uint32_t k = tid + (uint32_t)FNT * NCAND; k < n; k += FNT)
             {
                 const uint32_t p = pos_in[k];
                 if (p >= c)
@@ -706,7 +714,7 @@ namespace lexls
             double v0   = red_v[0];
             uint32_t p0 = red_p[0], piv = red_i[0];
 #pragma unroll
-            for (int w = 1; w < 4; w++)
+            for (int w = 1; w < FNW; w++)
             {
                 const double v2   = red_v[w];
                 const uint32_t p2 = red_p[w];
@@ -721,7 +729,7 @@ namespace lexls
 
             // ---- the pivot column, its fresh norm and tail norm (lexlse.h:210-211, :241) ----
             double fr = 0.0, tl = 0.0;
-            for (uint32_t i = tid; i < R; i += 256)
+            for (uint32_t i = tid; i < R; i += FNT)
             {
                 const double w = W[row + i + (size_t)piv * cap];
                 colv[i]        = w;
@@ -733,11 +741,16 @@ namespace lexls
             if (lane == 0)
             {
                 sums[wave]     = fr;
-                sums[4 + wave] = tl;
+                sums[FNW + wave] = tl;
             }
             __syncthreads();
-            const double fresh  = (sums[0] + sums[1]) + (sums[2] + sums[3]);
-            const double tailSq = (sums[4] + sums[5]) + (sums[6] + sums[7]);
+            double fresh = sums[0], tailSq = sums[FNW]; // fixed order: the same in every workgroup
+#pragma unroll
+            for (int w = 1; w < FNW; w++)
+            {
+                fresh += sums[w];
+                tailSq += sums[FNW + w];
+            }
             if (fresh < a.tol) // rank test on the squared norm (lexlse.h:214): the level ends here
             {
                 if (owner && tid == 0)
@@ -759,15 +772,15 @@ namespace lexls
                 den  = c0v - beta;
                 tau  = (beta - c0v) / beta;
             }
-            for (uint32_t i = 1 + tid; i < R; i += 256) es[i] = degenerate ? 0.0 : colv[i] / den;
+            for (uint32_t i = 1 + tid; i < R; i += FNT) es[i] = degenerate ? 0.0 : colv[i] / den;
             __syncthreads();
 
             // ---- this workgroup's tile: two columns per wavefront, rows across the lanes ----
             const uint32_t posf = ppos;
 #pragma unroll
-            for (int h = 0; h < FTC / 4; h++)
+            for (int h = 0; h < FCPW; h++)
             {
-                const uint32_t j = blockIdx.x * FTC + wave * (FTC / 4) + h;
+                const uint32_t j = blockIdx.x * FTC + wave * FCPW + h;
                 if (j > n) continue; // wave-uniform
                 uint32_t pj = (j == n) ? n : pos_in[j];
                 // the swap of lexlse.h:222-232 on the position map
@@ -819,7 +832,7 @@ namespace lexls
             if (owner)
             {
                 double *E = fb.E + ((size_t)b * fb.eld + counter) * fb.eld; // row `counter` of this level's essential parts
-                for (uint32_t i = 1 + tid; i < R; i += 256) E[i] = es[i];
+                for (uint32_t i = 1 + tid; i < R; i += FNT) E[i] = es[i];
                 if (tid == 0)
                 {
                     fb.D[(size_t)b * n + c]     = diag;
@@ -1465,7 +1478,7 @@ namespace lexls
             else if (!all_exhausted)
                 for (uint32_t counter = 0; counter < h_level_max[level]; counter++)
                 {
-                    hipLaunchKernelGGL(fast_step, dim3((n + FTC) / FTC, B), dim3(256), step_lds, s, a, fb, cur, pp, counter);
+                    hipLaunchKernelGGL(fast_step, dim3((n + FTC) / FTC, B), dim3(FNT), step_lds, s, a, fb, cur, pp, counter);
                     pp ^= 1u;
                 }
             hipLaunchKernelGGL(fast_level_end, dim3((h_rows_max + 1023) / 1024, n + 1, B), dim3(256), 0, s, a, fb, cur, pp, level);
