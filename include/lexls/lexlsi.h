@@ -434,6 +434,11 @@ namespace LexLS
 
             /// what the next advance() will ask the equality solver for (and, for sensitivity, at which LexLSE level)
             DeviceNeed need() const { return pending; }
+            /// the equality problem of a regular iteration (not phase 1) is formed and waits for its solve: from here on an iteration is
+            /// "solve, step, one working-set change, form the next problem" — the point where a backend that keeps x, v, A*x AND the
+            /// working sets resident can run whole iterations by itself (lock-step device batches)
+            bool atIterationSolve() const { return pc == PC_IT_SOLVED && pending == NEED_FACTORIZE_SOLVE; }
+            const std::vector<Objective> &getObjectives() const { return objectives; }
             Index needLevel() const { return sens_level; }
             bool finished() const { return pc == PC_DONE; }
 

@@ -520,6 +520,30 @@ extern "C"
     /* internal: the resident constraint data (lexls_lse_set_constraint_data), read by the lock-step driver's step kernel */
     const double *lexls_internal_cdata(lexls_lse_t h) { return h ? h->d_cdata : nullptr; }
 
+    /* internal: the device copy of the in slab (lexls_lse_round_layout) — the lock-step driver's resident iterations write the next
+     * equality problem's dimensions, fixed variables, types and row references there themselves */
+    char *lexls_internal_round_in(lexls_lse_t h) { return h ? h->d_round_in : nullptr; }
+    /* internal: the in slab was written ON THE DEVICE (same stream): gather the rows it names.  The host does not know this round's
+     * dimensions, so kernel choice and LDS budgets follow the capacities given at creation (every kernel takes smaller problems). */
+    int lexls_internal_round_resident(lexls_lse_t h, int has_fixed)
+    {
+        CHECK_HANDLE(h);
+        if (!h->d_cdata || !h->d_in_owned) return fail(LEXLS_ERR_INVALID, "round_resident: needs resident constraint data and one uploaded round");
+        HIP_TRY(hipSetDevice(h->device));
+        uint32_t max_level = 0;
+        h->level_max.assign(h->maxdim.begin(), h->maxdim.end());
+        for (uint32_t v : h->maxdim) max_level = v > max_level ? v : max_level;
+        h->max_rows      = h->cap ? h->cap : 1;
+        h->max_level_dim = max_level;
+        h->dims_set      = true;
+        h->has_fixed     = has_fixed != 0;
+        h->has_skip      = true;
+        h->factor_valid  = false;
+        HIP_TRY(launch_gather_rows(h->args(), h->d_cdata, h->cdata_per_problem, h->d_row_src, h->d_row_ld, h->d_in_owned, h->stream));
+        h->d_in = h->d_in_owned;
+        return LEXLS_OK;
+    }
+
     static int upload_round(lexls_lse_t h, const void *h_in, int gather, bool trusted);
     int lexls_lse_upload_round(lexls_lse_t h, const void *h_in, int gather) { return upload_round(h, h_in, gather, false); }
     /* internal (not in include/lexls_hip.h): the lock-step LexLSI driver of this library fills the block itself — variable indices and

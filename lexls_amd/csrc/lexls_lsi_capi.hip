@@ -20,6 +20,8 @@ using namespace LexLS;
 
 extern "C" int lexls_internal_upload_round_trusted(lexls_lse_t h, const void *h_in, int gather); // lexls_capi.hip
 extern "C" const double *lexls_internal_cdata(lexls_lse_t h);                                        // lexls_capi.hip
+extern "C" char *lexls_internal_round_in(lexls_lse_t h);                                             // lexls_capi.hip
+extern "C" int lexls_internal_round_resident(lexls_lse_t h, int has_fixed);                          // lexls_capi.hip
 #include "lqr_wave_common.h" // wave_max
 
 namespace
@@ -94,25 +96,16 @@ namespace
         double *res;              // B x 4: alpha, blocking objective (-1: none), constraint, type
     };
 
-    __global__ __launch_bounds__(256) void lsi_step_kernel(StepArgs a)
+    /// One wavefront, one instance: dx = x_lse - x, A*dx, dv, the ratio test over the inactive constraints (first minimum in working-set
+    /// scan order) and the update of x / v / A*x in `st` (read from `src`).  Every lane returns the verdict.
+    __device__ __forceinline__ void lsi_step_wave(const StepShape &sh, const double *data, const uint32_t *var_b, const double *x_lse_b, const double *src, double *st,
+                                                  const uint8_t *ctr_state_b, const uint16_t *inact_pos_b, double *dx_s, double *adx_s, double *dv_s, double &alpha,
+                                                  int &blk_obj, uint32_t &blk_ctr, uint32_t &blk_type)
     {
-        extern __shared__ double smem[];
-        const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
-        const uint32_t b = blockIdx.x * 4 + wib;
-        if (b >= a.B) return;
-        const uint32_t md = a.mode[b];
-        if (md == 0) return;
-        const StepShape &sh = a.sh;
+        const uint32_t lane = threadIdx.x & 63u;
         const uint32_t n = sh.n, total = sh.total;
-        double *dx_s  = smem + (size_t)wib * sh.SD; // n
-        double *adx_s = dx_s + n;                   // total
-        double *dv_s  = adx_s + total;              // total
-        double *st         = a.state + (size_t)b * sh.SD;
-        const double *src  = (md == 2 ? a.state_in : a.state) + (size_t)b * sh.SD;
-        const double *data = a.cdata + (size_t)b * sh.per_data;
-
         // dx = x_lse - x (lexlsi.h:990-991)
-        for (uint32_t j = lane; j < n; j += 64) dx_s[j] = a.x_lse[(size_t)b * n + j] - src[j];
+        for (uint32_t j = lane; j < n; j += 64) dx_s[j] = x_lse_b[j] - src[j];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         asm volatile("" ::: "memory");
 
@@ -127,7 +120,7 @@ namespace
             double adx, lb, ub;
             if (sh.simple[k])
             {
-                adx = dx_s[a.var[(size_t)b * sh.dim0 + c]]; // objective.h:266-270
+                adx = dx_s[var_b[c]]; // objective.h:266-270
                 lb  = blk[c];
                 ub  = blk[c + dim];
             }
@@ -148,7 +141,7 @@ namespace
                 ub = blk[c + (size_t)(n + 1) * dim];
             }
             const double v = src[n + g], ax = src[n + total + g];
-            const uint32_t act = a.ctr_state[(size_t)b * total + g];
+            const uint32_t act = ctr_state_b[g];
             double dv = -v; // objective.h:292
             if (act)
             {
@@ -175,7 +168,7 @@ namespace
                     const double num = (rhs - ax) + v;
                     double ratio     = num / den;
                     if (ratio < 0.0) ratio = 0.0;
-                    const uint32_t key = (k << 16) | a.inact_pos[(size_t)b * total + g];
+                    const uint32_t key = (k << 16) | inact_pos_b[g];
                     if (ratio < 1.0 && (ratio < best || (ratio == best && key < best_key)))
                     {
                         best      = ratio;
@@ -189,10 +182,10 @@ namespace
             dv_s[g]  = dv;
         }
         // first minimum in scan order over the wave (strict '<' of the sequential scan, lexlsi.h:1011-1019)
-        const double wmin        = -lexls::wave_max(-best);
-        double alpha             = 1.0;
-        int blk_obj              = -1;
-        uint32_t blk_ctr = 0, blk_type = 0;
+        const double wmin = -lexls::wave_max(-best);
+        alpha             = 1.0;
+        blk_obj           = -1;
+        blk_ctr = 0, blk_type = 0;
         if (wmin < 1.0)
         {
             unsigned long long tied = __ballot(best == wmin);
@@ -214,14 +207,6 @@ namespace
             blk_ctr  = (uint32_t)__builtin_amdgcn_readlane((int)best_ctr, win);
             blk_type = (uint32_t)__builtin_amdgcn_readlane((int)best_type, win);
         }
-        if (lane == 0)
-        {
-            double *r = a.res + (size_t)b * 4;
-            r[0]      = alpha;
-            r[1]      = (double)blk_obj;
-            r[2]      = (double)blk_ctr;
-            r[3]      = (double)blk_type;
-        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         asm volatile("" ::: "memory");
         // the step itself (lexlsi.h:1236-1240, objective.h:585-589); with alpha == 0 the state only moves to its home
@@ -237,6 +222,193 @@ namespace
             st[n + g]         = move ? v + alpha * dv_s[g] : v;
             st[n + total + g] = move ? ax + alpha * adx_s[g] : ax;
         }
+    }
+
+    __global__ __launch_bounds__(256) void lsi_step_kernel(StepArgs a)
+    {
+        extern __shared__ double smem[];
+        const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+        const uint32_t b = blockIdx.x * 4 + wib;
+        if (b >= a.B) return;
+        const uint32_t md = a.mode[b];
+        if (md == 0) return;
+        const StepShape &sh = a.sh;
+        double *dx_s  = smem + (size_t)wib * sh.SD; // n
+        double *adx_s = dx_s + sh.n;                // total
+        double *dv_s  = adx_s + sh.total;           // total
+        double *st         = a.state + (size_t)b * sh.SD;
+        const double *src  = (md == 2 ? a.state_in : a.state) + (size_t)b * sh.SD;
+        double alpha;
+        int blk_obj;
+        uint32_t blk_ctr, blk_type;
+        lsi_step_wave(sh, a.cdata + (size_t)b * sh.per_data, a.var + (size_t)b * sh.dim0, a.x_lse + (size_t)b * sh.n, src, st, a.ctr_state + (size_t)b * sh.total,
+                      a.inact_pos + (size_t)b * sh.total, dx_s, adx_s, dv_s, alpha, blk_obj, blk_ctr, blk_type);
+        if (lane == 0)
+        {
+            double *r = a.res + (size_t)b * 4;
+            r[0]      = alpha;
+            r[1]      = (double)blk_obj;
+            r[2]      = (double)blk_ctr;
+            r[3]      = (double)blk_type;
+        }
+    }
+
+    // =============================================================================================
+    // Resident iterations: a whole active-set iteration without the host.  Once an instance has left phase 1 an iteration is
+    //   solve the equality problem -> step + ratio test -> ONE working-set change (add the blocking constraint, or remove the one the
+    //   removal search names, or stop) -> form the next equality problem
+    // (verifyWorkingSet, lexlsi.h:1144-1265).  The first and the last part are this kernel: behind the l-QR kernel and the speculative
+    // removal sweep of the stage it runs the step (lsi_step_wave), applies the working-set rules of workingset.h:79-118 (swap-with-last
+    // in the inactive list, ordered erase in the active list: they decide ties of later ratio tests and the row order of later
+    // equality problems, i.e. index parity), keeps the counters of lexlsi.h:1250-1264 and writes the next problem's dimensions, fixed
+    // variables, constraint types and row references (Objective::formLexLSE, objective.h:434-494) straight into the equality solver's
+    // in slab, where the next stage's row gather finds them.  The host only enqueues stages and polls the count of finished instances.
+    // One wavefront per instance.
+    // =============================================================================================
+    struct ResidentArgs
+    {
+        StepShape sh;
+        uint32_t B, cap, nObjL, off; // off = 1: objective 0 is the simple-bounds objective (its active bounds are the fixed variables)
+        int32_t max_factorizations;
+        const double *cdata;
+        const uint32_t *var;
+        const double *x_lse;       // B x n
+        const uint32_t *totalrank; // B
+        const int32_t *sens;       // B x 3: found, index in the active list, LexLSE level (-1: a fixed variable)
+        double *state;             // B x SD
+        uint8_t *ctr_state;        // B x total: activation type per constraint (0 = inactive)
+        uint16_t *act, *inact, *inact_pos; // B x total each, objective k in [first[k], first[k] + dim[k])
+        uint16_t *na;              // B x STEP_MAX_OBJ: active constraints per objective
+        int32_t *info;             // B x 8: status, iterations, activations, deactivations, factorizations, total rank, -, -
+        uint8_t *alive;            // B
+        uint32_t *finished;        // one counter for the group
+        // the equality solver's in slab (lexls_lse_round_layout)
+        uint32_t *dims, *nfixed, *fixed_idx;
+        double *fixed_val;
+        uint8_t *skip;
+        int32_t *objidx;
+        uint32_t *row_src, *row_ld;
+        uint8_t *fixed_type, *ctr_type;
+    };
+
+    __global__ __launch_bounds__(256) void lsi_iterate_kernel(ResidentArgs a)
+    {
+        extern __shared__ double smem[];
+        const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+        const uint32_t b = blockIdx.x * 4 + wib;
+        if (b >= a.B) return;
+        if (!a.alive[b]) return;
+        const StepShape &sh = a.sh;
+        const uint32_t n = sh.n, total = sh.total;
+        double *dx_s  = smem + (size_t)wib * sh.SD;
+        double *adx_s = dx_s + n;
+        double *dv_s  = adx_s + total;
+        double *st         = a.state + (size_t)b * sh.SD;
+        const double *data = a.cdata + (size_t)b * sh.per_data;
+        const uint32_t *var = a.var + (size_t)b * sh.dim0;
+        uint8_t *cs    = a.ctr_state + (size_t)b * total;
+        uint16_t *act  = a.act + (size_t)b * total;
+        uint16_t *ina  = a.inact + (size_t)b * total;
+        uint16_t *ipos = a.inact_pos + (size_t)b * total;
+        uint16_t *na   = a.na + (size_t)b * STEP_MAX_OBJ;
+        int32_t *info  = a.info + (size_t)b * 8;
+
+        double alpha;
+        int blk_obj;
+        uint32_t blk_ctr, blk_type;
+        lsi_step_wave(sh, data, var, a.x_lse + (size_t)b * n, st, st, cs, ipos, dx_s, adx_s, dv_s, alpha, blk_obj, blk_ctr, blk_type);
+
+        // ---- one working-set change (lexlsi.h:1181-1232) and the counters; lane 0, the lists are short ----
+        int status       = info[0];
+        const int nfact  = info[4] + 1; // lexlsi.h:1172
+        if (lane == 0)
+        {
+            if (blk_obj >= 0) // OPERATION_ADD: workingset.h:79-92
+            {
+                const uint32_t f = sh.first[blk_obj], nak = na[blk_obj], nik = sh.dim[blk_obj] - nak;
+                const uint32_t pos = ipos[f + blk_ctr], last = ina[f + nik - 1];
+                ina[f + pos]       = (uint16_t)last;
+                ipos[f + last]     = (uint16_t)pos;
+                cs[f + blk_ctr]    = (uint8_t)blk_type;
+                act[f + nak]       = (uint16_t)blk_ctr;
+                na[blk_obj]        = (uint16_t)(nak + 1);
+                info[2]++;
+            }
+            else if (a.sens[(size_t)b * 3]) // OPERATION_REMOVE: workingset.h:99-108
+            {
+                const uint32_t k = (uint32_t)(a.sens[(size_t)b * 3 + 2] + (int32_t)a.off), p = (uint32_t)a.sens[(size_t)b * 3 + 1];
+                const uint32_t f = sh.first[k], nak = na[k], nik = sh.dim[k] - nak;
+                const uint32_t c = act[f + p];
+                for (uint32_t i = p; i + 1 < nak; i++) act[f + i] = act[f + i + 1];
+                cs[f + c]     = (uint8_t)CTR_INACTIVE;
+                ina[f + nik]  = (uint16_t)c;
+                ipos[f + c]   = (uint16_t)nik;
+                na[k]         = (uint16_t)(nak - 1);
+                info[3]++;
+            }
+            else
+                status = (int)PROBLEM_SOLVED;
+            bool done = status == (int)PROBLEM_SOLVED;
+            if (!done && nfact >= a.max_factorizations) // lexlsi.h:236-240
+            {
+                status = (int)MAX_NUMBER_OF_FACTORIZATIONS_EXCEEDED;
+                done   = true;
+            }
+            info[0] = status;
+            info[1] = info[1] + 1;
+            info[4] = nfact;
+            info[5] = (int32_t)a.totalrank[b];
+            if (done)
+            {
+                a.alive[b]  = 0;
+                a.skip[b]   = 1;
+                a.objidx[b] = -1;
+                atomicAdd(a.finished, 1u);
+            }
+        }
+        __threadfence(); // lane 0's list updates are read by the whole wave below
+        status = __builtin_amdgcn_readfirstlane(status);
+        const bool blocked = blk_obj >= 0, found = !blocked && a.sens[(size_t)b * 3] != 0;
+        if (!blocked && !found) return;                      // solved
+        if (nfact >= a.max_factorizations) return;            // gave up
+        (void)status;
+
+        // ---- the next equality problem (lexlsi.h:968-982, objective.h:434-494), lane = active constraint ----
+        uint32_t counter = 0;
+        for (uint32_t k = 0; k < sh.nObj; k++)
+        {
+            const uint32_t f = sh.first[k], dim = sh.dim[k];
+            const uint32_t nak = __builtin_amdgcn_readfirstlane((uint32_t) * (volatile uint16_t *)(na + k));
+            const double *blk  = data + sh.off[k];
+            if (sh.simple[k])
+            {
+                if (lane == 0) a.nfixed[b] = nak;
+                for (uint32_t i = lane; i < nak; i += 64)
+                {
+                    const uint32_t c = *(volatile uint16_t *)(act + f + i);
+                    const uint32_t t = *(volatile uint8_t *)(cs + f + c);
+                    const size_t o   = (size_t)b * n + i;
+                    a.fixed_idx[o]   = var[c];
+                    a.fixed_val[o]   = (t == CTR_ACTIVE_LB) ? blk[c] : blk[c + dim];
+                    a.fixed_type[o]  = (uint8_t)t;
+                }
+            }
+            else
+            {
+                if (lane == 0) a.dims[(size_t)b * a.nObjL + k - a.off] = nak;
+                for (uint32_t i = lane; i < nak; i += 64)
+                {
+                    const uint32_t c = *(volatile uint16_t *)(act + f + i);
+                    const uint32_t t = *(volatile uint8_t *)(cs + f + c);
+                    const size_t o   = (size_t)b * a.cap + counter + i;
+                    a.row_src[o]     = (uint32_t)(sh.off[k] + c);
+                    a.row_ld[o]      = dim | (t == CTR_ACTIVE_LB ? 0u : 0x80000000u);
+                    a.ctr_type[o]    = (uint8_t)t;
+                }
+                counter += nak;
+            }
+        }
+        for (uint32_t r = counter + lane; r < a.cap; r += 64) a.row_ld[(size_t)b * a.cap + r] = 0u;
     }
 
     /// host array in pinned memory (hipHostMalloc): the per-round copies of a lock-step batch are enqueued, not waited for
@@ -322,6 +494,20 @@ namespace
         std::atomic<bool> handover{false};         // some instance put its state into state_host for the next stage
         bool stage_step = false;
         bool spec_sens  = false; // every factorization is followed by its removal search in the same stage (results used if the step is not blocked)
+        // ---- resident iterations (lsi_iterate_kernel): x / v / A x, the working sets and the counters of an instance live on the device ----
+        bool resident = false; // buffers exist (the structure allows it)
+        StepShape rshape;
+        uint32_t r_off = 0;
+        double *d_rstate = NULL;
+        uint32_t *d_rvar = NULL;
+        char *d_rws      = NULL; // one slab: ctr_state | alive | act | inact | inact_pos | na | info | finished
+        size_t rws_bytes = 0, r_alive = 0, r_act = 0, r_inact = 0, r_ipos = 0, r_na = 0, r_info = 0, r_fin = 0;
+        Pinned<char> rws_host;
+        Pinned<double> rstate_host;
+        Pinned<uint32_t> fin_host;
+        std::vector<uint8_t> is_resident; // per instance: handed over to the device
+        uint32_t n_resident  = 0;
+        int rounds_resident  = 0;
         int rounds_fs = 0, rounds_sens = 0, rounds_step = 0;
         double t_enqueue = 0, t_wait = 0; // seconds, reported when LEXLS_LSI_TIMING is set
         static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -374,6 +560,168 @@ namespace
             on_device.assign(B, 0);
             device_step = true;
         }
+        /// buffers of the resident iterations for a batch of this structure (once per batch object)
+        void create_resident(const StepShape &sh, uint32_t off)
+        {
+            rshape = sh;
+            r_off  = off;
+            auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+            const size_t total = sh.total;
+            size_t o = 0;
+            o        = up(o + (size_t)B * total); // ctr_state at 0
+            r_alive = o, o = up(o + B);
+            r_act = o, o = up(o + 2 * (size_t)B * total);
+            r_inact = o, o = up(o + 2 * (size_t)B * total);
+            r_ipos = o, o = up(o + 2 * (size_t)B * total);
+            r_na = o, o = up(o + 2 * (size_t)B * STEP_MAX_OBJ);
+            r_info = o, o = up(o + 4 * (size_t)B * 8);
+            r_fin = o, o = up(o + 16);
+            rws_bytes = o;
+            if (hipMalloc((void **)&d_rstate, 8 * (size_t)B * sh.SD) != hipSuccess || hipMalloc((void **)&d_rws, rws_bytes) != hipSuccess ||
+                hipMalloc((void **)&d_rvar, 4 * (size_t)B * (sh.dim0 ? sh.dim0 : 1)) != hipSuccess)
+                throw Exception("hipMalloc failed (resident LSI iterations)");
+            rws_host.assign(rws_bytes, 0);
+            rstate_host.assign((size_t)B * sh.SD, 0.0);
+            fin_host.assign(4, 0u);
+            is_resident.assign(B, 0);
+            resident = true;
+        }
+        uint8_t *r_ctr_state(uint32_t b) { return reinterpret_cast<uint8_t *>(rws_host.data()) + (size_t)b * rshape.total; }
+        int32_t *r_info_of(uint32_t b) { return reinterpret_cast<int32_t *>(rws_host.data() + r_info) + (size_t)b * 8; }
+
+        /// instance b (its equality problem of a regular iteration is formed and staged in the in block) leaves the host: state, working
+        /// sets in list order (workingset.h) and counters go into the hand-over slabs
+        template <class LSI>
+        void hand_over(uint32_t b, const LSI &inst)
+        {
+            const StepShape &sh = rshape;
+            double *st          = rstate_host.data() + (size_t)b * sh.SD;
+            const dVectorType &x = inst.get_x();
+            for (uint32_t j = 0; j < sh.n; j++) st[j] = x(j);
+            char *base    = rws_host.data();
+            uint8_t *cs   = reinterpret_cast<uint8_t *>(base) + (size_t)b * sh.total;
+            uint16_t *act = reinterpret_cast<uint16_t *>(base + r_act) + (size_t)b * sh.total;
+            uint16_t *ina = reinterpret_cast<uint16_t *>(base + r_inact) + (size_t)b * sh.total;
+            uint16_t *ip  = reinterpret_cast<uint16_t *>(base + r_ipos) + (size_t)b * sh.total;
+            uint16_t *na  = reinterpret_cast<uint16_t *>(base + r_na) + (size_t)b * STEP_MAX_OBJ;
+            std::memset(cs, 0, sh.total);
+            const std::vector<internal::Objective> &obj = inst.getObjectives();
+            for (uint32_t k = 0; k < sh.nObj; k++)
+            {
+                const uint32_t first = sh.first[k];
+                const dVectorType &v = obj[k].get_v(), &ax = obj[k].get_Ax();
+                for (uint32_t i = 0; i < sh.dim[k]; i++)
+                {
+                    st[sh.n + first + i]            = v(i);
+                    st[sh.n + sh.total + first + i] = ax(i);
+                }
+                na[k] = static_cast<uint16_t>(obj[k].getActiveCtrCount());
+                for (Index a = 0; a < obj[k].getActiveCtrCount(); a++)
+                {
+                    act[first + a]                          = static_cast<uint16_t>(obj[k].getActiveCtrIndex(a));
+                    cs[first + obj[k].getActiveCtrIndex(a)] = static_cast<uint8_t>(obj[k].getActiveCtrType(a));
+                }
+                for (Index i = 0; i < obj[k].getInactiveCtrCount(); i++)
+                {
+                    ina[first + i]                            = static_cast<uint16_t>(obj[k].getInactiveCtrIndex(i));
+                    ip[first + obj[k].getInactiveCtrIndex(i)] = static_cast<uint16_t>(i);
+                }
+            }
+            int32_t *info = r_info_of(b);
+            info[0]       = static_cast<int32_t>(inst.getStatus());
+            info[1]       = static_cast<int32_t>(inst.getIterationsCount());
+            info[2]       = static_cast<int32_t>(inst.getActivationsCount());
+            info[3]       = static_cast<int32_t>(inst.getDeactivationsCount());
+            info[4]       = static_cast<int32_t>(inst.getFactorizationsCount());
+            info[5]       = static_cast<int32_t>(totalrank[b]);
+            reinterpret_cast<uint8_t *>(base + r_alive)[b] = 1;
+            is_resident[b] = 1;
+            skip[b]        = 0; // its staged equality problem is served by the first resident stage, followed by its removal sweep
+            objidx[b]      = 0;
+        }
+
+        ResidentArgs resident_args(int32_t max_factorizations)
+        {
+            ResidentArgs ra;
+            std::memset(&ra, 0, sizeof(ra));
+            void *d_out = NULL;
+            hip_check(lexls_lse_device_ptr(h, LEXLS_ARRAY_X, &d_out)); // x is the head of the out slab (lexls_lse_round_layout)
+            char *out = static_cast<char *>(d_out), *in = lexls_internal_round_in(h);
+            ra.sh     = rshape;
+            ra.B = B, ra.cap = cap, ra.nObjL = nObjL, ra.off = r_off;
+            ra.max_factorizations = max_factorizations;
+            ra.cdata     = lexls_internal_cdata(h);
+            ra.var       = d_rvar;
+            ra.x_lse     = reinterpret_cast<const double *>(out + lay.x);
+            ra.totalrank = reinterpret_cast<const uint32_t *>(out + lay.total_rank);
+            ra.sens      = reinterpret_cast<const int32_t *>(out + lay.found);
+            ra.state     = d_rstate;
+            ra.ctr_state = reinterpret_cast<uint8_t *>(d_rws);
+            ra.alive     = reinterpret_cast<uint8_t *>(d_rws + r_alive);
+            ra.act       = reinterpret_cast<uint16_t *>(d_rws + r_act);
+            ra.inact     = reinterpret_cast<uint16_t *>(d_rws + r_inact);
+            ra.inact_pos = reinterpret_cast<uint16_t *>(d_rws + r_ipos);
+            ra.na        = reinterpret_cast<uint16_t *>(d_rws + r_na);
+            ra.info      = reinterpret_cast<int32_t *>(d_rws + r_info);
+            ra.finished  = reinterpret_cast<uint32_t *>(d_rws + r_fin);
+            ra.dims      = reinterpret_cast<uint32_t *>(in + lay.dims);
+            ra.nfixed    = reinterpret_cast<uint32_t *>(in + lay.nfixed);
+            ra.fixed_idx = reinterpret_cast<uint32_t *>(in + lay.fixed_idx);
+            ra.fixed_val = reinterpret_cast<double *>(in + lay.fixed_val);
+            ra.skip      = reinterpret_cast<uint8_t *>(in + lay.skip);
+            ra.objidx    = reinterpret_cast<int32_t *>(in + lay.obj_index);
+            ra.row_src   = reinterpret_cast<uint32_t *>(in + lay.row_src);
+            ra.row_ld    = reinterpret_cast<uint32_t *>(in + lay.row_ld);
+            ra.fixed_type = reinterpret_cast<uint8_t *>(in + lay.fixed_type);
+            ra.ctr_type   = reinterpret_cast<uint8_t *>(in + lay.ctr_type);
+            return ra;
+        }
+
+        /// the handed-over instances start: slabs up, then `count` whole iterations are enqueued (nothing is waited for)
+        void begin_resident()
+        {
+            *reinterpret_cast<uint32_t *>(rws_host.data() + r_fin) = 0u;
+            if (hipMemcpyAsync(d_rws, rws_host.data(), rws_bytes, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                hipMemcpyAsync(d_rstate, rstate_host.data(), 8 * (size_t)B * rshape.SD, hipMemcpyHostToDevice, stream) != hipSuccess)
+                throw Exception("hipMemcpyAsync failed (resident hand-over)");
+            rounds_resident = 0;
+        }
+        void enqueue_resident(int count, double tolW, double tolC, int32_t max_factorizations)
+        {
+            const double t0        = now();
+            const ResidentArgs ra  = resident_args(max_factorizations);
+            for (int i = 0; i < count; i++)
+            {
+                if (rounds_resident == 0)
+                    hip_check(lexls_internal_upload_round_trusted(h, in_block.data(), 1)); // the problems the host formed last
+                else
+                    hip_check(lexls_internal_round_resident(h, rshape.dim0 ? 1 : 0)); // the problems lsi_iterate_kernel formed
+                hip_check(lexls_lse_factorize_solve(h, 1));
+                hip_check(lexls_lse_sensitivity_resident(h, tolW, tolC)); // speculative: used when the step is not blocked
+                hipLaunchKernelGGL(lsi_iterate_kernel, dim3((B + 3) / 4), dim3(256), 8 * (size_t)rshape.SD * 4, stream, ra);
+                if (hipGetLastError() != hipSuccess) throw Exception("lsi_iterate_kernel launch failed");
+                rounds_resident++;
+                rounds_fs++;
+                rounds_sens++;
+            }
+            if (hipMemcpyAsync(fin_host.data(), d_rws + r_fin, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) throw Exception("hipMemcpyAsync failed (finished count)");
+            t_enqueue += now() - t0;
+        }
+        /// waits for what is enqueued; true when every handed-over instance has stopped
+        bool resident_done()
+        {
+            const double t0 = now();
+            hip_check(lexls_lse_synchronize(h));
+            t_wait += now() - t0;
+            return fin_host[0] >= n_resident;
+        }
+        void download_resident()
+        {
+            if (hipMemcpyAsync(rws_host.data(), d_rws, rws_bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipMemcpyAsync(rstate_host.data(), d_rstate, 8 * (size_t)B * rshape.SD, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess)
+                throw Exception("download of the resident state failed");
+        }
         uint8_t *mode() { return wset_host.data(); }
         uint8_t *ctr_state(uint32_t b) { return wset_host.data() + wset_state + (size_t)b * shape.total; }
         uint16_t *inact_pos(uint32_t b) { return reinterpret_cast<uint16_t *>(wset_host.data() + wset_pos) + (size_t)b * shape.total; }
@@ -410,11 +758,18 @@ namespace
                 stage_step = false;
             }
             stage_fs = stage_sens = false;
+            if (resident)
+            {
+                std::fill(rws_host.begin(), rws_host.end(), 0);
+                std::fill(is_resident.begin(), is_resident.end(), 0);
+                n_resident      = 0;
+                rounds_resident = 0;
+            }
         }
         ~BatchCtx()
         {
             if (h) lexls_lse_destroy(h);
-            void *dev[] = {d_state, d_state_in, d_res, d_var, d_wset};
+            void *dev[] = {d_state, d_state_in, d_res, d_var, d_wset, d_rstate, d_rvar, d_rws};
             for (void *q : dev)
                 if (q) (void)hipFree(q);
             if (stream) (void)hipStreamDestroy(stream);
@@ -810,6 +1165,7 @@ struct lexls_lsi_batch_s
     std::vector<std::unique_ptr<BatchCtx>> grp;
     std::vector<uint32_t> lo, group_of;
     std::unique_ptr<WorkerPool> pool;
+    bool resident_ok = false;
     double t_create = 0.0;
     int32_t last_stats[4] = {0, 0, 0, 0}; // of the last run: factorize+solve stages, sensitivity stages, stages with the step on the device, groups
 
@@ -832,7 +1188,12 @@ struct lexls_lsi_batch_s
         // synchronisation) that a split multiplies, so it pays for large batches only.  Measured on MI355X, cold
         // solve of n = 40, 5 x 12, seconds with 1 / 2 / 3 groups: 512 instances 0.034 / 0.030 / 0.040; 1024: 0.039 / 0.034 / 0.045
         // (256 instances, an earlier state of the driver: 0.044 / 0.047).  LEXLS_LSI_GROUPS overrides the number.
-        nGroups = batch >= 512 ? 2u : 1u;
+        // (With resident iterations — the default, see below — there is no host work per stage left to overlap: one group.)
+        {
+            const char *want_res = std::getenv("LEXLS_LSI_RESIDENT"), *want_step = std::getenv("LEXLS_LSI_DEVICE_STEP");
+            const bool host_logic = (want_res && std::atoi(want_res) == 0) || (want_step && std::atoi(want_step) != 0);
+            nGroups               = (host_logic && batch >= 512) ? 2u : 1u;
+        }
         if (const char *e = std::getenv("LEXLS_LSI_GROUPS")) nGroups = std::max(1, std::atoi(e));
         nGroups = std::min(nGroups, batch);
         gather = per_data < 0x7fffffffull && !std::getenv("LEXLS_LSI_HOST_STAGING"); // (diagnostic switch: assemble on the host, stage over PCIe)
@@ -876,6 +1237,26 @@ struct lexls_lsi_batch_s
         }
         if (step_ok)
             for (uint32_t g = 0; g < nGroups; g++) grp[g]->create_step(sh);
+        // Resident iterations (lsi_iterate_kernel), the default where the structure allows it: after phase 1 the instances leave the host —
+        // a stage is row gather + l-QR + removal sweep + step / working-set change / next problem, all enqueued, and the host only polls
+        // how many instances have stopped.  LEXLS_LSI_RESIDENT=0 keeps the active-set logic on the host (one synchronisation per stage).
+        const char *want_res = std::getenv("LEXLS_LSI_RESIDENT");
+        resident_ok = !(want_res && std::atoi(want_res) == 0) && !step_ok && gather && nObj <= STEP_MAX_OBJ && 8 * (size_t)sh.SD * 4 <= 48 * 1024 && total <= 65535;
+        if (resident_ok)
+        {
+            uint64_t o = 0;
+            uint32_t f = 0;
+            for (uint32_t k = 0; k < nObj; k++)
+            {
+                sh.dim[k] = h_dims[k], sh.simple[k] = h_types[k] == 1, sh.first[k] = f, sh.off[k] = o;
+                if (h_types[k] == 1 && k != 0) resident_ok = false; // (the driver itself only takes a simple-bounds objective first, lexlsi.h:402-405)
+                o += (uint64_t)h_dims[k] * (h_types[k] == 1 ? 2 : nVar + 2);
+                f += h_dims[k];
+            }
+            if (o > 0xffffffffull) resident_ok = false;
+        }
+        if (resident_ok)
+            for (uint32_t g = 0; g < nGroups; g++) grp[g]->create_resident(sh, off);
         group_of.resize(batch);
         for (uint32_t g = 0; g < nGroups; g++)
             for (uint32_t b = lo[g]; b < lo[g + 1]; b++) group_of[b] = g;
@@ -920,6 +1301,23 @@ struct lexls_lsi_batch_s
                 }
             }
         }
+        // whole iterations on the device: plain runs only (cycling handling edits the host's bounds; a regularized equality problem has
+        // per-run factors the host posts)
+        const bool run_resident = run_gather && resident_ok && grp[0]->resident && par.regularization_type == REGULARIZATION_NONE &&
+                                  par.max_number_of_factorizations < 0x7fffffff;
+        if (run_resident)
+            for (uint32_t g = 0; g < nGroups; g++)
+            {
+                BatchCtx &ctx               = *grp[g];
+                ctx.rshape.tol_feasibility = par.tol_feasibility;
+                if (ctx.rshape.dim0)
+                {
+                    if (!h_var_index) throw Exception("lexls_lsi_batch_run: a simple-bounds objective needs variable indices");
+                    if (hipMemcpyAsync(ctx.d_rvar, h_var_index + (size_t)lo[g] * ctx.rshape.dim0, 4 * (size_t)ctx.B * ctx.rshape.dim0, hipMemcpyHostToDevice, ctx.stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx.stream) != hipSuccess)
+                        throw Exception("upload of the variable indices failed");
+                }
+            }
         const bool run_step = run_gather && grp[0]->device_step;
         std::vector<SlotStep> hooks(run_step ? batch : 0);
         const double t_ctx = BatchCtx::now() - t_begin;
@@ -963,6 +1361,7 @@ struct lexls_lsi_batch_s
             const double t0 = BatchCtx::now();
             pool.run(lo[g + 1] - lo[g], [&](uint32_t k) {
                 SlotLSI &inst        = *lsi[lo[g] + k];
+                if (run_resident && ctx.is_resident[k]) return; // waits for the others to leave phase 1
                 const bool served_fs = ctx.stage_fs && !ctx.skip[k], served_sens = ctx.stage_sens && ctx.skip[k] && ctx.objidx[k] >= 0;
                 const bool has_spec  = served_fs && ctx.stage_sens && ctx.objidx[k] == 0; // its removal search ran right behind its l-QR
                 if (run_step) ctx.mode()[k] = 0; // (the hook raises it again when the instance posts an iteration's equality problem)
@@ -970,6 +1369,15 @@ struct lexls_lsi_batch_s
                 if (served_fs || served_sens) inst.advance();
                 if (has_spec && !inst.finished() && inst.need() == SlotLSI::NEED_SENSITIVITY && inst.needLevel() == 0) inst.advance(); // step not blocked: use it
                 const bool alive = !inst.finished();
+                if (run_resident && alive && inst.atIterationSolve())
+                {
+                    // phase 1 is over and the equality problem of a regular iteration is staged: from here on the instance iterates on the
+                    // device (its staged problem is served by the first resident stage)
+                    ctx.hand_over(k, inst);
+                    ctx.skip[k]   = 1;
+                    ctx.objidx[k] = -1;
+                    return;
+                }
                 const bool fs    = alive && inst.need() == SlotLSI::NEED_FACTORIZE_SOLVE;
                 const bool se    = alive && inst.need() == SlotLSI::NEED_SENSITIVITY;
                 const bool spec  = fs && ctx.spec_sens;
@@ -1014,6 +1422,46 @@ struct lexls_lsi_batch_s
                 }
         }
 
+        if (run_resident)
+        {
+            std::vector<char> going(nGroups, 0);
+            bool more = false;
+            for (uint32_t g = 0; g < nGroups; g++)
+            {
+                BatchCtx &ctx  = *grp[g];
+                ctx.n_resident = 0;
+                for (uint32_t k = 0; k < ctx.B; k++)
+                {
+                    const bool r  = ctx.is_resident[k] != 0;
+                    ctx.skip[k]   = r ? 0 : 1;
+                    ctx.objidx[k] = r ? 0 : -1;
+                    ctx.n_resident += r ? 1u : 0u;
+                }
+                if (ctx.n_resident)
+                {
+                    ctx.begin_resident();
+                    going[g] = 1;
+                    more     = true;
+                }
+            }
+            // stages are enqueued in chunks; after each chunk ONE word comes back (instances that have stopped).  Stages past an
+            // instance's end skip it in every kernel; a chunk that turns out not to be needed costs a few launches of early-exit kernels
+            const int chunk = 8;
+            while (more)
+            {
+                more = false;
+                for (uint32_t g = 0; g < nGroups; g++)
+                    if (going[g]) grp[g]->enqueue_resident(chunk, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda, static_cast<int32_t>(par.max_number_of_factorizations));
+                for (uint32_t g = 0; g < nGroups; g++)
+                    if (going[g])
+                    {
+                        if (grp[g]->resident_done()) going[g] = 0;
+                        more = more || going[g];
+                    }
+            }
+            for (uint32_t g = 0; g < nGroups; g++)
+                if (grp[g]->n_resident) grp[g]->download_resident();
+        }
         if (run_step) // x and v of the instances whose state lives on the device
             for (uint32_t g = 0; g < nGroups; g++)
             {
@@ -1027,6 +1475,19 @@ struct lexls_lsi_batch_s
             runner::collect(*lsi[b], prob[b], h_x + (size_t)b * nVar, &info, h_active ? h_active + (size_t)b * total : NULL,
                             h_v ? h_v + (size_t)b * total : NULL);
             if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
+            if (run_resident)
+            {
+                BatchCtx &ctx    = *grp[group_of[b]];
+                const uint32_t k = b - lo[group_of[b]];
+                if (ctx.is_resident[k]) // x, v, working set and counters as the device left them
+                {
+                    const double *st = ctx.rstate_host.data() + (size_t)k * ctx.rshape.SD;
+                    std::copy(st, st + nVar, h_x + (size_t)b * nVar);
+                    if (h_v) std::copy(st + nVar, st + nVar + total, h_v + (size_t)b * total);
+                    if (h_active) std::copy(ctx.r_ctr_state(k), ctx.r_ctr_state(k) + total, h_active + (size_t)b * total);
+                    if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, ctx.r_info_of(k), 6 * sizeof(int32_t));
+                }
+            }
             if (run_step)
             {
                 BatchCtx &ctx    = *grp[group_of[b]];
@@ -1045,7 +1506,7 @@ struct lexls_lsi_batch_s
         {
             rounds_fs += grp[g]->rounds_fs;
             rounds_sens += grp[g]->rounds_sens;
-            rounds_step += grp[g]->rounds_step;
+            rounds_step += grp[g]->rounds_step + grp[g]->rounds_resident;
             t_enq += grp[g]->t_enqueue;
             t_wait += grp[g]->t_wait;
         }

@@ -107,6 +107,7 @@ def test_lock_step_device_gather_equals_host_staging(hip, oracle, monkeypatch):
     trajectories and bit-identical results."""
     n, dims, batch = 40, [12] * 5, 16
     pk = lexlsi.pack_batch(n, [P.lsi_problem(1300 + b, n, dims) for b in range(batch)])
+    monkeypatch.setenv("LEXLS_LSI_RESIDENT", "0")  # (stage counts are compared: both runs with the host-side active-set logic)
     dev = lexlsi.lsi_batch_solve(n, pk)
     monkeypatch.setenv("LEXLS_LSI_HOST_STAGING", "1")
     host = lexlsi.lsi_batch_solve(n, pk)
@@ -335,6 +336,42 @@ def test_device_side_step_matches_host_step(hip, oracle, monkeypatch, simple_bou
         np.testing.assert_array_equal(dev["v"][b], np.concatenate(o["v"]))
 
 
+@pytest.mark.parametrize("simple_bounds", [True, False])
+def test_resident_iterations_match_host_driver(hip, oracle, monkeypatch, simple_bounds):
+    """Default since round 2 (LEXLS_LSI_RESIDENT=0 switches it off): after phase 1 the instances iterate on the device — step, ratio test,
+    ONE working-set change by the rules of workingset.h (swap-with-last / ordered erase), counters and the next equality problem in
+    lsi_iterate_kernel — and the host only polls.  Same trajectories (info: status, iterations, activations, deactivations,
+    factorizations, total rank), same x / v / working sets bit for bit as the host-side driver and the oracle-backed one, cold and
+    warm-started; a factorization limit stops the instances at the same iteration."""
+    n, dims, batch = 18, [6, 5, 7, 4], 14
+    problems = [P.lsi_problem(1500 + b, n, dims, simple_bounds=simple_bounds) for b in range(batch)]
+    pk = lexlsi.pack_batch(n, problems)
+    srv = lexlsi.LsiBatch(n, pk.dims, pk.types, batch)
+    res = srv.run(pk)
+    assert srv.stats()["device_step"] > 0  # stages whose step ran on the device
+    guess = np.where(res["active"] == 3, 0, res["active"]).astype(np.uint8)
+    pert = lexlsi.pack_batch(n, [P.lsi_problem(1500 + b, n, dims, simple_bounds=simple_bounds, perturb=0.4) for b in range(batch)])
+    res_w = srv.run(pert, active_guess=guess, x0=res["x"])
+    res_lim = srv.run(pk, max_number_of_factorizations=4)
+    srv.close()
+    monkeypatch.setenv("LEXLS_LSI_RESIDENT", "0")
+    host = lexlsi.lsi_batch_solve(n, pk)
+    host_w = lexlsi.lsi_batch_solve(n, pert, active_guess=guess, x0=res["x"])
+    host_lim = lexlsi.lsi_batch_solve(n, pk, max_number_of_factorizations=4)
+    assert any(i["status"] == 2 for i in host_lim["info"]) and any(i["deactivations"] > 0 for i in host["info"])
+    for d, h in ((res, host), (res_w, host_w), (res_lim, host_lim)):
+        assert d["info"] == h["info"]
+        np.testing.assert_array_equal(d["x"], h["x"])
+        np.testing.assert_array_equal(d["v"], h["v"])
+        np.testing.assert_array_equal(d["active"], h["active"])
+    for b in range(batch):
+        o = oracle.lsi_run(n, problems[b])
+        assert res["info"][b] == o["info"]
+        np.testing.assert_array_equal(res["x"][b], o["x"])
+        np.testing.assert_array_equal(res["v"][b], np.concatenate(o["v"]))
+        np.testing.assert_array_equal(res["active"][b], np.concatenate(o["active"]))
+
+
 @pytest.mark.parametrize("groups", [2, 3])
 def test_lock_step_groups_take_turns(hip, oracle, monkeypatch, groups):
     """large batches are split into groups that take turns on their own streams (default from 512 instances on); forced here on a small
@@ -418,10 +455,14 @@ def test_removal_path_closed_form_on_the_device(hip, oracle):
     np.testing.assert_allclose(np.abs(s.getWorkspace()[0, :4]), np.abs(lam), atol=1e-13)
 
 
-def test_config5_full_size_lock_step_batch(hip, oracle):
-    """BASELINE.json configs[4] at full size: 1024 instances (n = 40, 5 x 12, level 0 simple bounds) in ONE lock-step batch object with the
-    automatic group split, warm-started from the unperturbed neighbour with right-hand sides perturbed by 0.9 N(0,1) (~30 factorizations
-    per instance).  Every instance solved; 64 sampled instances equal the oracle-backed driver bit for bit (x, v, working set, counters)."""
+@pytest.mark.parametrize("resident", [True, False])
+def test_config5_full_size_lock_step_batch(hip, oracle, monkeypatch, resident):
+    """BASELINE.json configs[4] at full size: 1024 instances (n = 40, 5 x 12, level 0 simple bounds) in ONE lock-step batch object,
+    warm-started from the unperturbed neighbour with right-hand sides perturbed by 0.9 N(0,1) (~30 factorizations per instance) — with the
+    iterations resident on the device (default) and with the active-set logic on the host (LEXLS_LSI_RESIDENT=0: automatic group split).
+    Every instance solved; 64 sampled instances equal the oracle-backed driver bit for bit (x, v, working set, counters)."""
+    if not resident:
+        monkeypatch.setenv("LEXLS_LSI_RESIDENT", "0")
     n, dims, batch = 40, [12] * 5, 1024
     base = lexlsi.pack_batch(n, [P.lsi_problem(20260500 + b, n, dims) for b in range(batch)])
     pert = lexlsi.pack_batch(n, [P.lsi_problem(20260500 + b, n, dims, perturb=0.9) for b in range(batch)])
@@ -435,7 +476,10 @@ def test_config5_full_size_lock_step_batch(hip, oracle):
     finally:
         srv.close()
     assert all(i["status"] == 0 for i in warm["info"])
-    assert stats["groups"] >= 2  # batches from 512 instances on take turns in groups
+    if resident:
+        assert stats["device_step"] >= max(i["factorizations"] for i in warm["info"]) - 1  # all but the phase-1 stage ran without the host
+    else:
+        assert stats["groups"] >= 2  # host logic: batches from 512 instances on take turns in groups
     f = np.array([i["factorizations"] for i in warm["info"]])
     assert 20.0 <= f.mean() <= 40.0, f.mean()  # the workload BASELINE.md C5 describes: ~30 factorizations per instance
     assert sum(i["deactivations"] for i in warm["info"]) > batch  # the removal path is exercised throughout
