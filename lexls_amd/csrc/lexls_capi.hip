@@ -65,6 +65,7 @@ struct lexls_lse_s
     uint32_t *d_perm, *d_rank, *d_fcol, *d_totalrank, *d_dims, *d_nfixed, *d_fixed_idx;
     uint8_t *d_fixed_type, *d_ctr_type, *d_skip;
     bool has_skip;
+    bool fused_gather = false; // this round's rows are read by reference inside lqr_wave_kernel (lexls_internal_round_resident)
     int32_t *d_sens, *d_objidx;
     uint32_t reg_type;    // LexLS::RegularizationType, 0 = none
     uint32_t reg_cg_iters;
@@ -108,6 +109,10 @@ struct lexls_lse_s
         a.reg_variable = reg_variable;
         a.reg_factor   = d_reg_factor;
         a.reg_scratch  = d_reg_scratch;
+        a.g_cdata      = fused_gather ? d_cdata : nullptr;
+        a.g_per        = cdata_per_problem;
+        a.g_row_src    = d_row_src;
+        a.g_row_ld     = d_row_ld;
         return a;
     }
     size_t problem_elems() const { return (size_t)cap * (nVar + 1); }
@@ -459,6 +464,7 @@ extern "C"
         HIP_TRY(hipMemcpyAsync(h->d_in_owned, h_lod, bytes, hipMemcpyHostToDevice, h->stream));
         if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
         h->d_in         = h->d_in_owned;
+        h->fused_gather = false;
         h->factor_valid = false;
         return LEXLS_OK;
     }
@@ -505,6 +511,7 @@ extern "C"
         HIP_TRY(launch_gather_rows(h->args(), h->d_cdata, h->cdata_per_problem, h->d_row_src, h->d_row_ld, h->d_in_owned, h->stream));
         if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream)); // the host arrays may be reused by the caller
         h->d_in         = h->d_in_owned;
+        h->fused_gather = false;
         h->factor_valid = false;
         return LEXLS_OK;
     }
@@ -539,8 +546,15 @@ extern "C"
         h->has_fixed     = has_fixed != 0;
         h->has_skip      = true;
         h->factor_valid  = false;
-        HIP_TRY(launch_gather_rows(h->args(), h->d_cdata, h->cdata_per_problem, h->d_row_src, h->d_row_ld, h->d_in_owned, h->stream));
-        h->d_in = h->d_in_owned;
+        h->fused_gather  = false;
+        h->d_in          = h->d_in_owned;
+        // the register-resident wave kernel reads the rows by reference itself (one launch and one pass over the problems less)
+        const int ll = h->force_generic == 2 ? -1 : (h->force_generic == 3 ? 1 : (h->force_generic == 4 ? 2 : 0));
+        if (h->force_generic != 1 && h->reg_type == 0 && wave_kernel_supports(h->args(), h->max_rows, h->max_level_dim, h->has_fixed) &&
+            wave_dispatch_is_register_resident(h->args(), h->max_level_dim, h->has_fixed, ll))
+            h->fused_gather = true;
+        else
+            HIP_TRY(launch_gather_rows(h->args(), h->d_cdata, h->cdata_per_problem, h->d_row_src, h->d_row_ld, h->d_in_owned, h->stream));
         return LEXLS_OK;
     }
 
@@ -595,6 +609,7 @@ extern "C"
         }
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipMemcpyAsync(h->d_round_in, h_in, L.in_bytes, hipMemcpyHostToDevice, h->stream));
+        h->fused_gather  = false;
         h->max_rows      = max_rows ? max_rows : 1;
         h->max_level_dim = max_level;
         h->dims_set      = true;
@@ -631,6 +646,7 @@ extern "C"
         CHECK_HANDLE(h);
         if (!d_lod) return fail(LEXLS_ERR_INVALID, "set_problem_device: null");
         h->d_in         = d_lod;
+        h->fused_gather = false;
         h->factor_valid = false;
         return LEXLS_OK;
     }
@@ -854,6 +870,7 @@ extern "C"
             }
             *d_ptr  = h->d_in_owned;
             h->d_in = h->d_in_owned;
+            h->fused_gather = false;
             break;
         default: return fail(LEXLS_ERR_INVALID, "unknown array id");
         }

@@ -46,5 +46,11 @@ namespace lexls
         const double *reg_factor;        // batch x nObj regularization factors (lexlse.h:1477)
         double *reg_scratch;             // batch x reg_scratch_doubles(nVar): null-space basis + work matrices (lexls_regularize.h)
         const uint8_t *skip;             // batch flags: non-zero = leave this problem untouched (NULL: none); lock-step LSI batches
+        // Row gather fused into the load of lqr_wave_kernel (NULL: `in` holds the assembled problems).  Row r of problem b is row
+        // row_src[b*cap+r] of the resident constraint data: element j at g_cdata[b*g_per + row_src + j*ld], right-hand side at column
+        // nVar (+1 when the top bit of row_ld is set): the layout lexls_lse_gather_problem documents (include/lexls_hip.h)
+        const double *g_cdata;
+        uint64_t g_per;
+        const uint32_t *g_row_src, *g_row_ld;
     };
 } // namespace lexls

@@ -126,15 +126,23 @@ namespace
             }
             else
             {
-                adx = 0.0; // one ordered chain per row, as the host's apply_A; eight loads in flight
+                adx = 0.0; // one ordered chain per row, as the host's apply_A; twenty loads in flight (the chain is short, the loads are not)
                 uint32_t j = 0;
-                for (; j + 8 <= n; j += 8)
+                for (; j + 20 <= n; j += 20)
                 {
-                    double av[8];
+                    double av[20];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) av[u] = blk[c + (size_t)(j + u) * dim];
+                    for (int u = 0; u < 20; u++) av[u] = blk[c + (size_t)(j + u) * dim];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) adx = lexls::dfma(av[u], dx_s[j + u], adx);
+                    for (int u = 0; u < 20; u++) adx = lexls::dfma(av[u], dx_s[j + u], adx);
+                }
+                for (; j + 4 <= n; j += 4)
+                {
+                    double av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) av[u] = blk[c + (size_t)(j + u) * dim];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) adx = lexls::dfma(av[u], dx_s[j + u], adx);
                 }
                 for (; j < n; j++) adx = lexls::dfma(blk[c + (size_t)j * dim], dx_s[j], adx);
                 lb = blk[c + (size_t)n * dim];
@@ -291,6 +299,10 @@ namespace
         uint8_t *fixed_type, *ctr_type;
     };
 
+    /// LDS of one instance's wavefront: [dx n | A dx total | dv total] doubles, u16 na[STEP_MAX_OBJ], then the working-set lists
+    /// u16 [act | inact | inact_pos] and u8 [ctr_state]
+    __host__ __device__ inline size_t resident_lds_per_wave(uint32_t SD, uint32_t total) { return (8 * (size_t)SD + 7 * (size_t)total + 2 * STEP_MAX_OBJ + 15) & ~size_t(15); }
+
     __global__ __launch_bounds__(256) void lsi_iterate_kernel(ResidentArgs a)
     {
         extern __shared__ double smem[];
@@ -300,30 +312,50 @@ namespace
         if (!a.alive[b]) return;
         const StepShape &sh = a.sh;
         const uint32_t n = sh.n, total = sh.total;
-        double *dx_s  = smem + (size_t)wib * sh.SD;
+        char *wl      = reinterpret_cast<char *>(smem) + (size_t)wib * resident_lds_per_wave(sh.SD, total);
+        double *dx_s  = reinterpret_cast<double *>(wl);
         double *adx_s = dx_s + n;
         double *dv_s  = adx_s + total;
+        uint16_t *na   = reinterpret_cast<uint16_t *>(dv_s + total); // the working sets are edited in LDS and written back
+        uint16_t *act  = na + STEP_MAX_OBJ;
+        uint16_t *ina  = act + total;
+        uint16_t *ipos = ina + total;
+        uint8_t *cs    = reinterpret_cast<uint8_t *>(ipos + total);
         double *st         = a.state + (size_t)b * sh.SD;
         const double *data = a.cdata + (size_t)b * sh.per_data;
         const uint32_t *var = a.var + (size_t)b * sh.dim0;
-        uint8_t *cs    = a.ctr_state + (size_t)b * total;
-        uint16_t *act  = a.act + (size_t)b * total;
-        uint16_t *ina  = a.inact + (size_t)b * total;
-        uint16_t *ipos = a.inact_pos + (size_t)b * total;
-        uint16_t *na   = a.na + (size_t)b * STEP_MAX_OBJ;
-        int32_t *info  = a.info + (size_t)b * 8;
+        uint8_t *g_cs    = a.ctr_state + (size_t)b * total;
+        uint16_t *g_act  = a.act + (size_t)b * total;
+        uint16_t *g_ina  = a.inact + (size_t)b * total;
+        uint16_t *g_ipos = a.inact_pos + (size_t)b * total;
+        uint16_t *g_na   = a.na + (size_t)b * STEP_MAX_OBJ;
+        int32_t *info    = a.info + (size_t)b * 8;
+        for (uint32_t g = lane; g < total; g += 64)
+        {
+            act[g]  = g_act[g];
+            ina[g]  = g_ina[g];
+            ipos[g] = g_ipos[g];
+            cs[g]   = g_cs[g];
+        }
+        if (lane < STEP_MAX_OBJ) na[lane] = g_na[lane];
+        const int32_t found_i = a.sens[(size_t)b * 3], rm_pos = a.sens[(size_t)b * 3 + 1], rm_lvl = a.sens[(size_t)b * 3 + 2];
+        const int32_t nfact   = info[4] + 1; // lexlsi.h:1172
+        const int32_t niter = info[1], nact = info[2], ndeact = info[3];
+        const uint32_t trank = a.totalrank[b];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        asm volatile("" ::: "memory");
 
         double alpha;
         int blk_obj;
         uint32_t blk_ctr, blk_type;
         lsi_step_wave(sh, data, var, a.x_lse + (size_t)b * n, st, st, cs, ipos, dx_s, adx_s, dv_s, alpha, blk_obj, blk_ctr, blk_type);
 
-        // ---- one working-set change (lexlsi.h:1181-1232) and the counters; lane 0, the lists are short ----
-        int status       = info[0];
-        const int nfact  = info[4] + 1; // lexlsi.h:1172
+        // ---- one working-set change (lexlsi.h:1181-1232) and the counters; lane 0 on the LDS copy ----
+        const bool blocked = blk_obj >= 0, removed = !blocked && found_i != 0;
+        const bool done    = (!blocked && !removed) || nfact >= a.max_factorizations; // lexlsi.h:236-240
         if (lane == 0)
         {
-            if (blk_obj >= 0) // OPERATION_ADD: workingset.h:79-92
+            if (blocked) // OPERATION_ADD: workingset.h:79-92
             {
                 const uint32_t f = sh.first[blk_obj], nak = na[blk_obj], nik = sh.dim[blk_obj] - nak;
                 const uint32_t pos = ipos[f + blk_ctr], last = ina[f + nik - 1];
@@ -332,32 +364,24 @@ namespace
                 cs[f + blk_ctr]    = (uint8_t)blk_type;
                 act[f + nak]       = (uint16_t)blk_ctr;
                 na[blk_obj]        = (uint16_t)(nak + 1);
-                info[2]++;
             }
-            else if (a.sens[(size_t)b * 3]) // OPERATION_REMOVE: workingset.h:99-108
+            else if (removed) // OPERATION_REMOVE: workingset.h:99-108
             {
-                const uint32_t k = (uint32_t)(a.sens[(size_t)b * 3 + 2] + (int32_t)a.off), p = (uint32_t)a.sens[(size_t)b * 3 + 1];
+                const uint32_t k = (uint32_t)(rm_lvl + (int32_t)a.off), p = (uint32_t)rm_pos;
                 const uint32_t f = sh.first[k], nak = na[k], nik = sh.dim[k] - nak;
                 const uint32_t c = act[f + p];
                 for (uint32_t i = p; i + 1 < nak; i++) act[f + i] = act[f + i + 1];
-                cs[f + c]     = (uint8_t)CTR_INACTIVE;
-                ina[f + nik]  = (uint16_t)c;
-                ipos[f + c]   = (uint16_t)nik;
-                na[k]         = (uint16_t)(nak - 1);
-                info[3]++;
+                cs[f + c]    = (uint8_t)CTR_INACTIVE;
+                ina[f + nik] = (uint16_t)c;
+                ipos[f + c]  = (uint16_t)nik;
+                na[k]        = (uint16_t)(nak - 1);
             }
-            else
-                status = (int)PROBLEM_SOLVED;
-            bool done = status == (int)PROBLEM_SOLVED;
-            if (!done && nfact >= a.max_factorizations) // lexlsi.h:236-240
-            {
-                status = (int)MAX_NUMBER_OF_FACTORIZATIONS_EXCEEDED;
-                done   = true;
-            }
-            info[0] = status;
-            info[1] = info[1] + 1;
+            info[0] = (!blocked && !removed) ? (int32_t)PROBLEM_SOLVED : (done ? (int32_t)MAX_NUMBER_OF_FACTORIZATIONS_EXCEEDED : info[0]);
+            info[1] = niter + 1;
+            info[2] = nact + (blocked ? 1 : 0);
+            info[3] = ndeact + (removed ? 1 : 0);
             info[4] = nfact;
-            info[5] = (int32_t)a.totalrank[b];
+            info[5] = (int32_t)trank;
             if (done)
             {
                 a.alive[b]  = 0;
@@ -366,27 +390,30 @@ namespace
                 atomicAdd(a.finished, 1u);
             }
         }
-        __threadfence(); // lane 0's list updates are read by the whole wave below
-        status = __builtin_amdgcn_readfirstlane(status);
-        const bool blocked = blk_obj >= 0, found = !blocked && a.sens[(size_t)b * 3] != 0;
-        if (!blocked && !found) return;                      // solved
-        if (nfact >= a.max_factorizations) return;            // gave up
-        (void)status;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        asm volatile("" ::: "memory");
+        for (uint32_t g = lane; g < total; g += 64) // (a change touches a handful of entries; the lists are short: all of them go back)
+        {
+            g_act[g]  = act[g];
+            g_ina[g]  = ina[g];
+            g_ipos[g] = ipos[g];
+            g_cs[g]   = cs[g];
+        }
+        if (lane < STEP_MAX_OBJ) g_na[lane] = na[lane];
+        if (done) return;
 
         // ---- the next equality problem (lexlsi.h:968-982, objective.h:434-494), lane = active constraint ----
         uint32_t counter = 0;
         for (uint32_t k = 0; k < sh.nObj; k++)
         {
-            const uint32_t f = sh.first[k], dim = sh.dim[k];
-            const uint32_t nak = __builtin_amdgcn_readfirstlane((uint32_t) * (volatile uint16_t *)(na + k));
-            const double *blk  = data + sh.off[k];
+            const uint32_t f = sh.first[k], dim = sh.dim[k], nak = na[k];
+            const double *blk = data + sh.off[k];
             if (sh.simple[k])
             {
                 if (lane == 0) a.nfixed[b] = nak;
                 for (uint32_t i = lane; i < nak; i += 64)
                 {
-                    const uint32_t c = *(volatile uint16_t *)(act + f + i);
-                    const uint32_t t = *(volatile uint8_t *)(cs + f + c);
+                    const uint32_t c = act[f + i], t = cs[f + c];
                     const size_t o   = (size_t)b * n + i;
                     a.fixed_idx[o]   = var[c];
                     a.fixed_val[o]   = (t == CTR_ACTIVE_LB) ? blk[c] : blk[c + dim];
@@ -398,8 +425,7 @@ namespace
                 if (lane == 0) a.dims[(size_t)b * a.nObjL + k - a.off] = nak;
                 for (uint32_t i = lane; i < nak; i += 64)
                 {
-                    const uint32_t c = *(volatile uint16_t *)(act + f + i);
-                    const uint32_t t = *(volatile uint8_t *)(cs + f + c);
+                    const uint32_t c = act[f + i], t = cs[f + c];
                     const size_t o   = (size_t)b * a.cap + counter + i;
                     a.row_src[o]     = (uint32_t)(sh.off[k] + c);
                     a.row_ld[o]      = dim | (t == CTR_ACTIVE_LB ? 0u : 0x80000000u);
@@ -698,7 +724,7 @@ namespace
                     hip_check(lexls_internal_round_resident(h, rshape.dim0 ? 1 : 0)); // the problems lsi_iterate_kernel formed
                 hip_check(lexls_lse_factorize_solve(h, 1));
                 hip_check(lexls_lse_sensitivity_resident(h, tolW, tolC)); // speculative: used when the step is not blocked
-                hipLaunchKernelGGL(lsi_iterate_kernel, dim3((B + 3) / 4), dim3(256), 8 * (size_t)rshape.SD * 4, stream, ra);
+                hipLaunchKernelGGL(lsi_iterate_kernel, dim3((B + 3) / 4), dim3(256), 4 * resident_lds_per_wave(rshape.SD, rshape.total), stream, ra);
                 if (hipGetLastError() != hipSuccess) throw Exception("lsi_iterate_kernel launch failed");
                 rounds_resident++;
                 rounds_fs++;
@@ -1241,7 +1267,7 @@ struct lexls_lsi_batch_s
         // a stage is row gather + l-QR + removal sweep + step / working-set change / next problem, all enqueued, and the host only polls
         // how many instances have stopped.  LEXLS_LSI_RESIDENT=0 keeps the active-set logic on the host (one synchronisation per stage).
         const char *want_res = std::getenv("LEXLS_LSI_RESIDENT");
-        resident_ok = !(want_res && std::atoi(want_res) == 0) && !step_ok && gather && nObj <= STEP_MAX_OBJ && 8 * (size_t)sh.SD * 4 <= 48 * 1024 && total <= 65535;
+        resident_ok = !(want_res && std::atoi(want_res) == 0) && !step_ok && gather && nObj <= STEP_MAX_OBJ && 4 * resident_lds_per_wave(sh.SD, (uint32_t)total) <= 48 * 1024 && total <= 65535;
         if (resident_ok)
         {
             uint64_t o = 0;

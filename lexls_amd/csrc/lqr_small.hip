@@ -43,6 +43,16 @@ namespace lexls
         return cap;
     }
 
+    /// true when launch_lqr_wave (same arguments) takes the register-resident lqr_wave_kernel — the one whose load can gather the rows by
+    /// reference (LseArgs::g_cdata); the left-looking and four-per-wave kernels read an assembled problem
+    bool wave_dispatch_is_register_resident(const LseArgs &a, uint32_t max_level_dim, bool has_fixed, int left_looking)
+    {
+        (void)max_level_dim;
+        if (left_looking > 0) return false;
+        const bool lwave_pays = left_looking == 0 && a.batch > resident_wave_capacity();
+        return has_fixed || !lwave_pays;
+    }
+
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
                                const char **variant)
     {

@@ -72,8 +72,20 @@ namespace lexls
             // ---- load: row-per-lane, coalesced down each column ----
             const double *in = a.in + b * pstride;
             double T[NC];
+            if (a.g_cdata) // rows named by reference (a lock-step LSI stage whose problem was formed on the device): no assembled copy
+            {
+                const uint32_t rl  = a.g_row_ld[(size_t)b * cap + (lane < cap ? lane : 0)];
+                const size_t ld    = rl & 0x7fffffffu;
+                const double *src  = a.g_cdata + (size_t)b * a.g_per + a.g_row_src[(size_t)b * cap + (lane < cap ? lane : 0)];
+                const bool on      = lane < M && ld != 0;
 #pragma unroll
-            for (int j = 0; j < NC; j++) T[j] = (j <= n && lane < M) ? in[lane + (size_t)j * cap] : 0.0;
+                for (int j = 0; j < NC; j++) T[j] = (j <= n && on) ? src[(size_t)(j < n ? j : n + (int)(rl >> 31)) * ld] : 0.0;
+            }
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < NC; j++) T[j] = (j <= n && lane < M) ? in[lane + (size_t)j * cap] : 0.0;
+            }
 
             double *hhs = a.hh + (size_t)b * cap;
             for (int i = lane; i < cap; i += 64) hhs[i] = 0.0; // initialize(), lexlse.h:1683
