@@ -91,6 +91,7 @@ namespace lexls
             for (int i = lane; i < cap; i += 64) hhs[i] = 0.0; // initialize(), lexlse.h:1683
             perm_s[lane] = lane;
             if (lane < 16) ZB[lane] = 0.0;
+            for (uint32_t i = lane; i < img_doubles; i += 64) IMG[i] = 0.0; // (the trailing update of a ragged level reads past a column's rank)
 
             int pos        = (lane < n) ? lane : (lane == n ? n : 0x3fffffff);
             int rowlim     = 64; // factor output: rows of this lane's physical column that the row-per-lane image T still owns (all, until it is pivoted)
@@ -446,26 +447,30 @@ namespace lexls
 #define LEXLS_GEMM_CH 1
 #endif
                     constexpr int CH               = LEXLS_GEMM_CH;
+                    // A ragged level (rank < MD) runs the same straight-line stream over HP <= MD / 2 pivot pairs: pairs past the rank read
+                    // whatever follows the column in the image (the next column, or the zero-initialised slack behind the last one: finite)
+                    // and multiply it by the zero multipliers Lv[q >= rank] — an exact no-op, like the rows that are not below — instead of
+                    // a branch per pair, which would put every broadcast read on the critical path.
+                    auto trailing = [&](auto hp_c) __attribute__((always_inline)) {
+                        constexpr int HP = decltype(hp_c)::value;
 #pragma unroll
-                    for (int j0 = 0; j0 < NC; j0 += CH)
-                    {
-                        if (((tmask >> j0) & ((1ull << CH) - 1ull)) == 0ull) continue; // no trailing column in this chunk
-                        const double2 *u[CH];
-#pragma unroll
-                        for (int c = 0; c < CH; c++)
+                        for (int j0 = 0; j0 < NC; j0 += CH)
                         {
-                            const int j = j0 + c;
-                            u[c]        = reinterpret_cast<const double2 *>(ZB);
-                            if (j < NC && j <= n)
+                            if (((tmask >> j0) & ((1ull << CH) - 1ull)) == 0ull) continue; // no trailing column in this chunk
+                            const double2 *u[CH];
+#pragma unroll
+                            for (int c = 0; c < CH; c++)
                             {
-                                const int slot = (j < n) ? __builtin_amdgcn_readlane(pos, j < 64 ? j : 0) : n;
-                                if ((tmask >> j) & 1ull) u[c] = reinterpret_cast<const double2 *>(img + (slot - Fc) * stride);
+                                const int j = j0 + c;
+                                u[c]        = reinterpret_cast<const double2 *>(ZB);
+                                if (j < NC && j <= n)
+                                {
+                                    const int slot = (j < n) ? __builtin_amdgcn_readlane(pos, j < 64 ? j : 0) : n;
+                                    if ((tmask >> j) & 1ull) u[c] = reinterpret_cast<const double2 *>(img + (slot - Fc) * stride);
+                                }
                             }
-                        }
 #pragma unroll
-                        for (int pp = 0; pp < MD / 2; pp++)
-                        {
-                            if (FULL || 2 * pp < stride)
+                            for (int pp = 0; pp < HP; pp++)
                             {
                                 double2 uv[CH];
 #pragma unroll
@@ -479,7 +484,11 @@ namespace lexls
                                     }
                             }
                         }
-                    }
+                    };
+                    if (FULL || stride > MD / 2 + (MD / 2) % 2)
+                        trailing(std::integral_constant<int, MD / 2>{});
+                    else
+                        trailing(std::integral_constant<int, (MD / 2 + 1) / 2>{}); // rank <= MD / 2 (rounded up to a pair): half the stream
                     STAMP(8)
                 };
                 if (k + 1 < nObj && rank > 0)

@@ -184,7 +184,7 @@ class LsiBatch:
             self._h, _p(pk.data, C.c_double), _p(pk.var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(v0a, C.c_double), _p(rfa, C.c_double),
             _p(par, C.c_double), C.c_uint32(len(par)), _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8), _p(v, C.c_double),
             _p(rounds, C.c_int32)))
-        return dict(x=x, info=[dict(zip(INFO_KEYS, row.tolist())) for row in info], active=active, v=v,
+        return dict(x=x, info=[dict(zip(INFO_KEYS, row)) for row in info.tolist()], active=active, v=v,
                     rounds=dict(factorize_solve=int(rounds[0]), sensitivity=int(rounds[1])), dims=self.dims)
 
 
