@@ -24,11 +24,14 @@ for _ in range(4):  # warm-up: library load, first launches, GPU clocks; the las
 guess = np.where(cold["active"] == 3, 0, cold["active"]).astype(np.uint8)
 out = dict(batch=batch)
 for name, pk, kw in (("cold", base, {}), ("warm", pert, dict(active_guess=guess, x0=cold["x"])), ("warm_30", pert30, dict(active_guess=guess, x0=cold["x"]))):
-    t0 = time.perf_counter()
-    r = srv.run(pk, **kw)
-    dt = time.perf_counter() - t0
+    reps = []
+    for _ in range(3):  # the host is shared: the fastest of three repetitions, all of them listed
+        t0 = time.perf_counter()
+        r = srv.run(pk, **kw)
+        reps.append(time.perf_counter() - t0)
+    dt = min(reps)
     f = np.array([i["factorizations"] for i in r["info"]])
-    out[name] = dict(seconds=dt, mean_factorizations=float(f.mean()), max=int(f.max()), factorizations_per_s=float(f.sum() / dt),
+    out[name] = dict(seconds=dt, repetitions=reps, mean_factorizations=float(f.mean()), max=int(f.max()), factorizations_per_s=float(f.sum() / dt),
                      solved=int(sum(i["status"] == 0 for i in r["info"])), stages=srv.stats())
 srv.close()
 print(json.dumps(out))
