@@ -372,6 +372,23 @@ def test_resident_iterations_match_host_driver(hip, oracle, monkeypatch, simple_
         np.testing.assert_array_equal(res["active"][b], np.concatenate(o["active"]))
 
 
+def test_resident_iterations_beyond_the_wave_kernel_shapes(hip, oracle):
+    """resident iterations with equality problems the register-resident wave kernel does not take (nVar + 1 > 64: the generic kernel, which
+    reads the assembled problem — the row gather is then its own launch again) and with more than 64 constraints per instance."""
+    n, dims, batch = 70, [9, 30, 28, 12], 6
+    problems = [P.lsi_problem(3100 + b, n, dims) for b in range(batch)]
+    srv = lexlsi.LsiBatch(n, *[getattr(lexlsi.pack_batch(n, problems[:1]), k) for k in ("dims", "types")], batch)
+    r = srv.run(problems)
+    assert srv.stats()["device_step"] > 0
+    srv.close()
+    for b in range(batch):
+        o = oracle.lsi_run(n, problems[b])
+        assert r["info"][b] == o["info"], b
+        np.testing.assert_array_equal(r["x"][b], o["x"])
+        np.testing.assert_array_equal(r["v"][b], np.concatenate(o["v"]))
+        np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
+
+
 @pytest.mark.parametrize("groups", [2, 3])
 def test_lock_step_groups_take_turns(hip, oracle, monkeypatch, groups):
     """large batches are split into groups that take turns on their own streams (default from 512 instances on); forced here on a small
