@@ -850,16 +850,21 @@ namespace lexls
         // -----------------------------------------------------------------------------------------------------------------
         // The pivots of ONE level inside ONE launch (single problems: BASELINE configs[1]).  fast_step pays ~7 us per pivot: the floor of
         // a launch that depends on its predecessor (~3 us) plus two dependent round trips to data other XCDs wrote.  Here the level's
-        // trailing matrix stays in the LDS of G workgroups (8 columns each) for the whole level and a pivot costs ONE hand-off:
-        //   every workgroup publishes {largest down-dated norm of its columns, that column's position / index} AND that column's
-        //   remaining rows (its candidate for the pivot column), arrives at a counter, waits for all G arrivals, reads the G small
-        //   records, picks the winner (first maximum by position — the same in every workgroup), reads the winner's column, forms the
-        //   reflector itself and updates its own tile.  Buffers alternate by pivot parity: a workgroup can only be one step ahead.
-        // Hand-off protocol (MI355X_MICROARCH.md, valid forms): every published byte is an sc1 (agent-scope relaxed atomic) store, every
-        // storing wave drains (s_waitcnt vmcnt(0)) before the workgroup barrier, ONE lane adds to the agent-scope counter; the consumer
-        // polls the counter with sc1 loads from one lane, a workgroup barrier follows, every load of published bytes is an sc1 load.
-        // Every spin is bounded: a workgroup that gives up raises `abort`, which every spin watches — the launch then ends and the host
-        // falls back to the step-per-pivot kernels.
+        // trailing matrix stays in the LDS of G workgroups (4 columns each: one per wavefront) for the whole level and a pivot costs ONE hand-off:
+        //   every workgroup publishes a 16-byte record {largest down-dated norm of its columns, that column's position, tag | index} AND that
+        //   column's remaining rows (its candidate for the pivot column), polls the G records of the pivot, picks the winner (first maximum
+        //   by position — the same in every workgroup), reads the winner's column, forms the reflector itself and updates its own tile.
+        //   Buffers alternate by pivot parity: a workgroup can only be one step ahead.
+        // Hand-off protocol (MI355X_MICROARCH.md: data-tagged granules, the cheapest hand-off of its price list): every published 16 bytes —
+        // a record, or one column entry {value, tag} — are ONE sc0 sc1 store carrying the pivot's tag and are read by ONE sc0 sc1 load that is
+        // taken when the tag matches; nothing is drained, ordered or counted (the first version of this kernel drained the column stores,
+        // added to an agent-scope counter and polled it: 6.4 us per pivot, no faster than a launch per pivot).  What made the difference,
+        // measured with the stamps below: (1) no counter — 129 atomic adds to one address serialise; (2) records 256 bytes apart — 129
+        // workgroups polling 129 records that share sixteen lines made one memory channel the bottleneck (2.80 -> 2.49 ms); (3) four polls per
+        // lane in flight; (4) 4 columns per workgroup instead of 8 (the tile update is on the critical path).  Now 4.1 us per pivot:
+        // publish 0.7, record latency 1.8, winner's column 0.6, reflector + tile 1.1.  The tags restart with every level, so the records and
+        // the column granules are cleared in front of every launch.  Every spin is bounded: a workgroup that gives up raises `abort`, which
+        // every spin watches — the launch then ends WITHOUT committing anything and the host redoes the level with a launch per pivot.
         // -----------------------------------------------------------------------------------------------------------------
         struct PersistCtl
         {
@@ -880,27 +885,47 @@ namespace lexls
         {
             return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
-        constexpr int PTC = 8; // columns per workgroup (two per wavefront)
+#ifndef LEXLS_PERSIST_PTC
+#define LEXLS_PERSIST_PTC 4
+#endif
+        constexpr int PTC = LEXLS_PERSIST_PTC; // columns per workgroup (a multiple of 4: whole columns per wavefront)
+#ifndef LEXLS_PERSIST_RSTRIDE
+#define LEXLS_PERSIST_RSTRIDE 16
+#endif
+        constexpr size_t PRS = LEXLS_PERSIST_RSTRIDE; // a workgroup's record sits PRS x 16 bytes from its neighbour's: G workgroups poll all G records
+                                                      // at once, and records in one line would make that line's memory channel the bottleneck
+        /// 16-byte accesses with agent scope (sc0 sc1): a record {norm, pos, tag | column} travels as ONE store and is read as ONE load
+        /// (observed untorn on gfx950, MI355X_MICROARCH.md "R2's granule"); payload columns go two doubles per lane
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __device__ __forceinline__ void st16_sc1(void *p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+        __device__ __forceinline__ u32x4 ld16_sc1(const void *p)
+        {
+            u32x4 v;
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+            return v;
+        }
 
         __global__ __launch_bounds__(256) void fast_level_persist(LseArgs a, FastBuffers fb, PersistCtl *ctl, PersistCand *cand, double *colbuf, uint32_t colld,
                                                                   uint32_t cur, uint32_t pp, uint32_t level, uint32_t G)
         {
             extern __shared__ double smem[];
             __shared__ double red_v[4];
-            __shared__ uint32_t red_p[4], red_i[4], red_w[4];
+            __shared__ uint32_t red_p[4], red_i[4];
             __shared__ double sums[8];
             __shared__ uint32_t flag;
+            __shared__ uint32_t win_p, win_i, win_w, colbad;
             const uint32_t b = 0, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, t = blockIdx.x;
             const LargeState s = fb.st[pp][b];
             const uint32_t n = a.nVar, cap = a.cap;
             if (s.exhausted || s.dim == 0) return; // the same in every workgroup: nobody waits for anybody
+            if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (raised before the launch: the tests' way into the fallback)
             const uint32_t dim = s.dim, F = s.F;
             double *W          = fb.W[cur] + (size_t)b * cap * (n + 1);
             const uint32_t ldt = dim | 1u;
             double *tile   = smem;                      // PTC x ldt
             double *colv   = tile + (size_t)PTC * ldt;  // dim
-            double *es     = colv + dim;                // dim
-            double *nrm    = es + dim;                  // PTC: down-dated norms of the own columns
+            double *es0    = colv + dim;                // 2 x dim: essential parts, by pivot parity (the previous pivot's leave for memory one step late)
+            double *nrm    = es0 + 2 * dim;             // PTC: down-dated norms of the own columns
             uint32_t *posm = reinterpret_cast<uint32_t *>(nrm + PTC); // n + 1: position of every physical column (kept by every workgroup)
             uint32_t *invm = posm + (n + 1);                          // n + 1: physical column at every position
 
@@ -914,6 +939,7 @@ namespace lexls
                 posm[j] = j;
                 invm[j] = j;
             }
+            if (tid == 0) colbad = 0u;
             if (tid < (uint32_t)PTC)
             {
                 const uint32_t j = t * PTC + tid;
@@ -928,9 +954,29 @@ namespace lexls
 #else
 #define PSTAMP(i)
 #endif
+            // bookkeeping of a pivot (its essential part, R_cc, permutation entry, tau) is written by ONE workgroup, a different one every
+            // pivot, and ONE STEP LATE: behind that workgroup's next publication instead of in front of it, where the drain of those
+            // stores would make it the last to publish — and everybody waits for the last
+            bool pend = false;
+            uint32_t pend_counter = 0, pend_c = 0, pend_ppos = 0, pend_R = 0;
+            double pend_diag = 0.0, pend_tau = 0.0;
+            auto flush_pending = [&]() {
+                if (!pend) return;
+                const double *esp = es0 + (size_t)(pend_counter & 1u) * dim;
+                double *E         = fb.E + ((size_t)b * fb.eld + pend_counter) * fb.eld;
+                for (uint32_t i = 1 + tid; i < pend_R; i += 256) E[i] = esp[i];
+                if (tid == 0)
+                {
+                    fb.D[(size_t)b * n + pend_c]   = pend_diag;
+                    a.perm[(size_t)b * n + pend_c] = pend_ppos;
+                    if (pend_R > 1) a.hh[(size_t)b * cap + F + pend_counter] = pend_tau;
+                }
+                pend = false;
+            };
             for (uint32_t counter = 0; counter < dim; counter++)
             {
                 const uint32_t R = dim - counter, par = counter & 1u;
+                double *es       = es0 + (size_t)par * dim;
                 // ---- own candidate: first maximum by position among the own live columns ----
                 if (tid == 0)
                 {
@@ -954,59 +1000,75 @@ namespace lexls
                 const uint32_t myp = red_p[0], myj = red_i[0];
                 const double myv   = red_v[0];
                 __syncthreads();
-                // ---- publish: record + the candidate column's remaining rows ----
-                double *mycol = colbuf + ((size_t)par * G + t) * colld;
-                if (myp != 0xffffffffu)
-                    for (uint32_t i = tid; i < R; i += 256) st_sc1(mycol + i, tile[(myj - t * PTC) * ldt + counter + i]);
-                if (tid == 0)
+                // ---- publish: the record and the candidate column's remaining rows, every 16-byte store carrying this pivot's tag: nothing is
+                //      drained and nothing is ordered — a reader takes a granule when its tag matches (waves 1-3 store the column, wave 0 the
+                //      record, so that wave 0's polls do not queue behind the column stores) ----
+                const uint32_t tag = counter + 1u;
+                u32x4 *mycol       = reinterpret_cast<u32x4 *>(colbuf) + ((size_t)par * G + t) * colld;
+                if (myp != 0xffffffffu && tid >= 64)
                 {
-                    PersistCand *cd = cand + (size_t)par * G + t;
-                    st_sc1(&cd->norm, myv);
-                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&cd->pos), ((unsigned long long)myj << 32) | myp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                PSTAMP(0)
-                if (tid == 0)
-                {
-                    __hip_atomic_fetch_add(&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t want = G * (counter + 1);
-                    uint32_t ok = 0;
-                    for (uint32_t spin = 0; spin < (1u << 20); spin++)
+                    const double *srcc = tile + (myj - t * PTC) * ldt + counter;
+                    for (uint32_t i = tid - 64; i < R; i += 192)
                     {
-                        if (__hip_atomic_load(&ctl->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want)
+                        const double v0 = srcc[i];
+                        u32x4 q;
+                        q.x = (unsigned)__double2loint(v0), q.y = (unsigned)__double2hiint(v0), q.z = tag, q.w = 0u;
+                        st16_sc1(mycol + i, q);
+                    }
+                }
+                if (tid == 0)
+                {
+                    u32x4 q;
+                    q.x = (unsigned)__double2loint(myv), q.y = (unsigned)__double2hiint(myv), q.z = myp, q.w = (tag << 8) | ((myj - t * PTC) & 255u); // (no candidate: pos says so, the index is not looked at)
+                    st16_sc1(cand + ((size_t)par * G + t) * PRS, q);
+                }
+                flush_pending(); // (the previous pivot's bookkeeping, if it was this workgroup's turn: nobody waits for these stores)
+                PSTAMP(0)
+                // ---- wait for the G records of this pivot and pick the winner: wave 0, lane = workgroup (no counter: a record IS its flag) ----
+                if (wave == 0)
+                {
+                    // every lane keeps up to four records (G <= 256) in flight per poll: ONE round trip per poll, not one per record
+                    const PersistCand *base = cand + (size_t)par * G * PRS;
+                    u32x4 q[4];
+                    uint32_t ok = 0;
+                    for (uint32_t spin = 0; spin < (1u << 18); spin++)
+                    {
+#pragma unroll
+                        for (int kq = 0; kq < 4; kq++)
+                        {
+                            const uint32_t w = lane + 64u * kq;
+                            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(q[kq]) : "v"(base + (size_t)(w < G ? w : 0) * PRS) : "memory");
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3])::"memory");
+                        bool mine = true;
+#pragma unroll
+                        for (int kq = 0; kq < 4; kq++) mine = mine && (lane + 64u * kq >= G || (q[kq].w >> 8) == tag);
+                        if (__ballot(!mine) == 0ull)
                         {
                             ok = 1;
                             break;
                         }
-                        if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        if ((spin & 255u) == 255u && __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    if (!ok) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flag = ok;
-                }
-                __syncthreads();
-                if (!flag) return; // (uniform per workgroup; the others see `abort`)
-                PSTAMP(1)
-
-                // ---- winner among the G candidates (every workgroup for itself) ----
-                double bv   = -1.0;
-                uint32_t bp = 0xffffffffu, bi = 0, bw = 0;
-                for (uint32_t w = tid; w < G; w += 256)
-                {
-                    const PersistCand *cd       = cand + (size_t)par * G + w;
-                    const double v              = ld_sc1(&cd->norm);
-                    const unsigned long long pi = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(&cd->pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t p            = (uint32_t)pi;
-                    if (p != 0xffffffffu && (v > bv || (v == bv && p < bp)))
+                    double bv   = -1.0;
+                    uint32_t bp = 0xffffffffu, bi = 0, bw = 0;
+#pragma unroll
+                    for (int kq = 0; kq < 4; kq++)
                     {
-                        bv = v;
-                        bp = p;
-                        bi = (uint32_t)(pi >> 32);
-                        bw = w;
+                        const uint32_t w = lane + 64u * kq;
+                        const double v   = __hiloint2double((int)q[kq].y, (int)q[kq].x);
+                        const uint32_t p = q[kq].z;
+                        if (ok && w < G && p != 0xffffffffu && (v > bv || (v == bv && p < bp)))
+                        {
+                            bv = v;
+                            bp = p;
+                            bi = w * PTC + (q[kq].w & 255u);
+                            bw = w;
+                        }
                     }
-                }
-                {
+                    const bool all_ok = ok != 0;
+                    if (!all_ok && lane == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const double wm         = wave_max(bv);
                     unsigned long long tied = __ballot(bv == wm && bp != 0xffffffffu);
                     uint32_t bestp = 0xffffffffu, besti = 0, bestw = 0;
@@ -1024,40 +1086,44 @@ namespace lexls
                     }
                     if (lane == 0)
                     {
-                        red_v[wave] = wm;
-                        red_p[wave] = bestp;
-                        red_i[wave] = besti;
-                        red_w[wave] = bestw;
+                        flag  = all_ok ? 1u : 0u;
+                        win_p = bestp;
+                        win_i = besti;
+                        win_w = bestw;
                     }
                 }
                 __syncthreads();
-                double v0   = red_v[0];
-                uint32_t p0 = red_p[0], piv = red_i[0], wwin = red_w[0];
-#pragma unroll
-                for (int w = 1; w < 4; w++)
-                {
-                    const double v2   = red_v[w];
-                    const uint32_t p2 = red_p[w];
-                    if (p2 != 0xffffffffu && (p0 == 0xffffffffu || v2 > v0 || (v2 == v0 && p2 < p0)))
-                    {
-                        v0   = v2;
-                        p0   = p2;
-                        piv  = red_i[w];
-                        wwin = red_w[w];
-                    }
-                }
-                const uint32_t ppos = p0;
+                if (!flag) return; // (uniform per workgroup; the others see `abort`)
+                const uint32_t ppos = win_p, piv = win_i, wwin = win_w;
+                PSTAMP(1)
                 PSTAMP(2)
 
                 // ---- the pivot column (published by its owner), fresh / tail norms, reflector: as in fast_step ----
-                const double *pcol = colbuf + ((size_t)par * G + wwin) * colld;
+                const u32x4 *pcol = reinterpret_cast<const u32x4 *>(colbuf) + ((size_t)par * G + wwin) * colld;
                 double fr = 0.0, tl = 0.0;
                 for (uint32_t i = tid; i < R; i += 256)
                 {
-                    const double w = ld_sc1(pcol + i);
-                    colv[i]        = w;
-                    fr             = dfma(w, w, fr);
-                    if (i > 0) tl = dfma(w, w, tl);
+                    u32x4 q;
+                    uint32_t good = 0;
+                    for (uint32_t spin = 0; spin < (1u << 18); spin++) // (the record may overtake its column: a granule is taken when its tag matches)
+                    {
+                        q = ld16_sc1(pcol + i);
+                        if (q.z == tag)
+                        {
+                            good = 1;
+                            break;
+                        }
+                        if ((spin & 255u) == 255u && __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    }
+                    if (!good)
+                    {
+                        __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        colbad = 1u;
+                    }
+                    const double w0 = __hiloint2double((int)q.y, (int)q.x);
+                    colv[i]         = w0;
+                    fr              = dfma(w0, w0, fr);
+                    if (i > 0) tl = dfma(w0, w0, tl);
                 }
                 fr = wave_sum(fr);
                 tl = wave_sum(tl);
@@ -1070,6 +1136,7 @@ namespace lexls
                 const double fresh  = (sums[0] + sums[1]) + (sums[2] + sums[3]);
                 const double tailSq = (sums[4] + sums[5]) + (sums[6] + sums[7]);
                 PSTAMP(3)
+                if (colbad) return; // (a column granule timed out in this workgroup; `abort` is raised, the others see it in their spins)
                 if (fresh < a.tol) // rank test (lexlse.h:214): the level ends here, in every workgroup
                 {
                     stop = 1;
@@ -1131,14 +1198,9 @@ namespace lexls
                 // late at every hand-off
                 if (t == counter % G)
                 {
-                    double *E = fb.E + ((size_t)b * fb.eld + counter) * fb.eld;
-                    for (uint32_t i = 1 + tid; i < R; i += 256) E[i] = es[i];
-                    if (tid == 0)
-                    {
-                        fb.D[(size_t)b * n + c]   = diag;
-                        a.perm[(size_t)b * n + c] = ppos;
-                        if (R > 1) a.hh[(size_t)b * cap + F + counter] = tau;
-                    }
+                    pend         = true;
+                    pend_counter = counter, pend_c = c, pend_ppos = ppos, pend_R = R;
+                    pend_diag = diag, pend_tau = tau;
                 }
                 c++;
                 rank++;
@@ -1154,8 +1216,13 @@ namespace lexls
             if (t == 1 && tid == 0)
                 for (int i_ = 0; i_ < 5; i_++) a.lambda[8 * level + i_] = (double)pst[i_];
 #endif
-            // ---- back to memory: the tile, the position map, the state ----
+            // ---- back to memory: the tile, the position map, the state — unless some workgroup gave up (then nobody commits: a workgroup that
+            //      timed out did so long before any other could finish the level, every later hand-off needs its record) ----
             __syncthreads();
+            if (tid == 0) flag = __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0u : 1u;
+            __syncthreads();
+            if (!flag) return;
+            flush_pending();
             for (uint32_t e = tid; e < (uint32_t)PTC * dim; e += 256)
             {
                 const uint32_t jj = e / dim, i = e - jj * dim, j = t * PTC + jj;
@@ -1404,7 +1471,7 @@ namespace lexls
         const size_t ps = (size_t)cap * (n + 1);
         const size_t G = (n + PTC) / PTC; // workgroups of the one-launch-per-level form
         return 8 * ((size_t)batch * ps + 3 * (size_t)batch * n + (size_t)batch * maxdim * maxdim) + 4 * 2 * (size_t)batch * (n + 1) + 2 * sizeof(LargeState) * (size_t)batch + 256 +
-               sizeof(PersistCtl) + 2 * G * sizeof(PersistCand) + 8 * 2 * G * (size_t)maxdim + 64;
+               sizeof(PersistCtl) + 2 * G * PRS * sizeof(PersistCand) + 16 * 2 * G * (size_t)((maxdim + 1u) & ~1u) + 64;
     }
 
     /// the fast large path (see the comment above fast_level_begin); gemm_only_mfma: the bit-exact multi-launch path with its trailing update on the matrix cores
@@ -1441,15 +1508,14 @@ namespace lexls
         w += sizeof(PersistCtl);
         const uint32_t G  = (n + PTC) / PTC;
         PersistCand *cand = reinterpret_cast<PersistCand *>(w);
-        w += 2 * (size_t)G * sizeof(PersistCand);
+        w += 2 * (size_t)G * PRS * sizeof(PersistCand);
         double *colbuf = reinterpret_cast<double *>(w);
-        // single problems, on request (LEXLS_LARGE_PERSIST=1): the pivots of a level in ONE launch (fast_level_persist).  Measured on MI355X it is
-        // NOT faster than a launch per pivot (configs[1]: 3.69 ms vs 3.59 ms): one pivot costs ~6.4 us either way — publish + drain 1.4 us,
-        // arrive + wait for 65 workgroups 2.2-3.6 us, two dependent sc1 reads 1.3 us, reflector + tile 0.6-1.5 us (stamps, scripts/persist_stamps.py) —
-        // a cross-XCD hand-off through memory is as expensive as the kernel boundary it replaces.  Kept as the measured basis for the next step
-        // (fewer hand-offs per pivot); the default stays the launch per pivot, which cannot spin.
-        const size_t persist_lds = 8 * ((size_t)PTC * (maxdim | 1u) + 2 * (size_t)maxdim + PTC) + 8 * (size_t)(n + 1);
-        const bool persist       = B == 1 && G <= 128 && persist_lds <= kMaxLdsBytes && a.skip == nullptr && std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) != 0;
+        // single problems: the pivots of a level in ONE launch (fast_level_persist) — 4.1 us per pivot against 6.2 us for a launch per pivot
+        // (configs[1]: 2.74 ms vs 3.45 ms).  Its hand-offs spin (bounded); a launch whose spins ran out raises `abort`, ends, and the level
+        // is redone with a launch per pivot (LEXLS_LARGE_PERSIST=0: always a launch per pivot; =2: raise `abort` at once, for the tests)
+        const size_t persist_lds = 8 * ((size_t)PTC * (maxdim | 1u) + 3 * (size_t)maxdim + PTC) + 8 * (size_t)(n + 1);
+        const bool persist       = B == 1 && G <= 256 && persist_lds <= kMaxLdsBytes && a.skip == nullptr && !(std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) == 0);
+        const bool persist_test_abort = persist && std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) == 2;
 
         hipError_t e         = hipSuccess;
         const size_t step_lds = 16 * (size_t)maxdim;
@@ -1468,14 +1534,32 @@ namespace lexls
         for (uint32_t level = 0; level < a.nObj; level++)
         {
             hipLaunchKernelGGL(fast_level_begin, dim3((n + 4) / 4, B), dim3(256), 0, s, a, fb, cur, pp, level);
+            bool run_steps = false;
             if (!all_exhausted && persist)
             {
-                e = hipMemsetAsync(ctl, 0, sizeof(PersistCtl), s);
+                // the tags restart with every level (and every call): records and column granules of earlier pivots must not match them
+                e = hipMemsetAsync(ctl, 0, sizeof(PersistCtl) + 2 * (size_t)G * PRS * sizeof(PersistCand) + 16 * 2 * (size_t)G * ((maxdim + 1u) & ~1u), s);
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(fast_level_persist, dim3(G), dim3(256), persist_lds, s, a, fb, ctl, cand, colbuf, maxdim, cur, pp, level, G);
-                pp ^= 1u;
+                if (persist_test_abort)
+                {
+                    const uint32_t one = 1u;
+                    e = hipMemcpyAsync(&ctl->abort, &one, 4, hipMemcpyHostToDevice, s);
+                    if (e != hipSuccess) return e;
+                }
+                hipLaunchKernelGGL(fast_level_persist, dim3(G), dim3(256), persist_lds, s, a, fb, ctl, cand, colbuf, (maxdim + 1u) & ~1u, cur, pp, level, G);
+                PersistCtl hc;
+                e = hipMemcpyAsync(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost, s);
+                if (e != hipSuccess) return e;
+                e = hipStreamSynchronize(s);
+                if (e != hipSuccess) return e;
+                if (hc.abort) // a hand-off ran out of spins (workgroups not co-resident?): nothing of the level was committed — a launch per pivot instead
+                    run_steps = true;
+                else
+                    pp ^= 1u;
             }
             else if (!all_exhausted)
+                run_steps = true;
+            if (run_steps)
                 for (uint32_t counter = 0; counter < h_level_max[level]; counter++)
                 {
                     hipLaunchKernelGGL(fast_step, dim3((n + FTC) / FTC, B), dim3(FNT), step_lds, s, a, fb, cur, pp, counter);
@@ -1505,15 +1589,6 @@ namespace lexls
                 all_exhausted = (a.skip == nullptr);
                 for (uint32_t b = 0; b < B && all_exhausted; b++)
                     if (!host[b].exhausted) all_exhausted = false;
-                if (persist)
-                {
-                    PersistCtl hc;
-                    e = hipMemcpyAsync(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost, s);
-                    if (e != hipSuccess) return e;
-                    e = hipStreamSynchronize(s);
-                    if (e != hipSuccess) return e;
-                    if (hc.abort) return hipErrorLaunchFailure; // a hand-off timed out (never observed; the spins are bounded so that this cannot hang)
-                }
             }
         }
         if (cur != 0) hipLaunchKernelGGL(fast_copy_back, dim3(64, B), dim3(256), 0, s, a, fb, cur);

@@ -41,7 +41,7 @@ s5.setProblem(lod)
 t5 = timed(lambda: s5.factorize_solve(True), s5.synchronize, 5)
 out["config1_single_large"] = dict(kernel=s.last_kernel(), ms=1e3 * t, factorize_only_ms=1e3 * tf, gflops=flops / t / 1e9, cpu_oracle_ms=1e3 * tc / 3, cpu_oracle_gflops=flops / (tc / 3) / 1e9,
                                    bit_exact_path=dict(kernel=s5.last_kernel(), ms=1e3 * t5),
-                                   note="step-per-pivot path: one launch per pivot (search + reflector + tile update), tree sums, trailing update on v_mfma_f64_16x16x4; "
+                                   note="fast path: the pivots of a level in one launch (tagged-granule hand-offs between 129 workgroups), tree sums, trailing update on v_mfma_f64_16x16x4; "
                                         "bit_exact_path = ordered chains, two launches per pivot (policy 5)")
 
 # ---- secondary kernels on the IK batch ---------------------------------------------------------------------------------

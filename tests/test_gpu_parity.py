@@ -342,14 +342,20 @@ def test_large_path_rank_deficient_and_ragged(hip, oracle, policy):
     assert np.abs(s.get_v() - ref["v"]).max() <= (0.0 if policy == 5 else 1e-10)
 
 
-def test_large_path_one_launch_per_level(hip, oracle, monkeypatch):
-    """LEXLS_LARGE_PERSIST=1: the pivots of a level inside one launch (workgroups hand candidates and the pivot column to each other through
-    agent-scope sc1 stores / loads and a counter; every spin is bounded) — same contract as the default launch per pivot"""
-    monkeypatch.setenv("LEXLS_LARGE_PERSIST", "1")
+@pytest.mark.parametrize("mode", ["1", "0", "2"])
+def test_large_path_one_launch_per_level(hip, oracle, monkeypatch, mode):
+    """single large problems run the pivots of a level inside ONE launch (default; LEXLS_LARGE_PERSIST=1): workgroups hand their candidate
+    records and the pivot column to each other as tagged 16-byte granules (agent-scope sc1 stores / loads, every spin bounded).  Same
+    contract as the launch per pivot (LEXLS_LARGE_PERSIST=0), also when the launch gives up and the level is redone pivot by pivot
+    (LEXLS_LARGE_PERSIST=2 raises the abort flag before the launch), and on a rank-deficient problem whose levels stop early"""
+    monkeypatch.setenv("LEXLS_LARGE_PERSIST", mode)
     n, dims = 150, [90, 90, 90]
     lod = P.rank_deficient_problem(811, n, dims, [60, 50, 30])[None]
     s, ref = run_both(hip, oracle, lod, dims, n)
     assert ref["rank"][0].tolist() == [60, 50, 30]
+    check_large(s, ref, dims, n, 0)
+    lod = P.lse_batch(5, 1, n, dims)  # full rank: the columns run out inside level 1
+    s, ref = run_both(hip, oracle, lod, dims, n)
     check_large(s, ref, dims, n, 0)
 
 
