@@ -888,7 +888,8 @@ namespace lexls
 #ifndef LEXLS_PERSIST_PTC
 #define LEXLS_PERSIST_PTC 4
 #endif
-        constexpr int PTC = LEXLS_PERSIST_PTC; // columns per workgroup (a multiple of 4: whole columns per wavefront)
+        constexpr int PTC = LEXLS_PERSIST_PTC; // columns per workgroup: one per wavefront
+        static_assert(PTC == 4, "fast_level_persist: one column per wavefront");
 #ifndef LEXLS_PERSIST_RSTRIDE
 #define LEXLS_PERSIST_RSTRIDE 16
 #endif
@@ -909,8 +910,6 @@ namespace lexls
                                                                   uint32_t cur, uint32_t pp, uint32_t level, uint32_t G)
         {
             extern __shared__ double smem[];
-            __shared__ double red_v[4];
-            __shared__ uint32_t red_p[4], red_i[4];
             __shared__ double sums[8];
             __shared__ uint32_t flag;
             __shared__ uint32_t win_p, win_i, win_w, colbad;
@@ -923,9 +922,8 @@ namespace lexls
             double *W          = fb.W[cur] + (size_t)b * cap * (n + 1);
             const uint32_t ldt = dim | 1u;
             double *tile   = smem;                      // PTC x ldt
-            double *colv   = tile + (size_t)PTC * ldt;  // dim
-            double *es0    = colv + dim;                // 2 x dim: essential parts, by pivot parity (the previous pivot's leave for memory one step late)
-            double *nrm    = es0 + 2 * dim;             // PTC: down-dated norms of the own columns
+            double *cv0    = tile + (size_t)PTC * ldt;  // 2 x dim: the pivot column, by pivot parity (the previous pivot's essential part leaves one step late)
+            double *nrm    = cv0 + 2 * dim;             // PTC: down-dated norms of the own columns
             uint32_t *posm = reinterpret_cast<uint32_t *>(nrm + PTC); // n + 1: position of every physical column (kept by every workgroup)
             uint32_t *invm = posm + (n + 1);                          // n + 1: physical column at every position
 
@@ -955,16 +953,16 @@ namespace lexls
 #define PSTAMP(i)
 #endif
             // bookkeeping of a pivot (its essential part, R_cc, permutation entry, tau) is written by ONE workgroup, a different one every
-            // pivot, and ONE STEP LATE: behind that workgroup's next publication instead of in front of it, where the drain of those
-            // stores would make it the last to publish — and everybody waits for the last
-            bool pend = false;
+            // pivot, and ONE STEP LATE: behind that workgroup's next publication instead of in front of it, where its stores would make it
+            // the last to publish — and everybody waits for the last.  The essential part is formed then, from the kept pivot column.
+            bool pend = false, pend_degenerate = false;
             uint32_t pend_counter = 0, pend_c = 0, pend_ppos = 0, pend_R = 0;
-            double pend_diag = 0.0, pend_tau = 0.0;
+            double pend_diag = 0.0, pend_tau = 0.0, pend_den = 1.0;
             auto flush_pending = [&]() {
                 if (!pend) return;
-                const double *esp = es0 + (size_t)(pend_counter & 1u) * dim;
+                const double *cvp = cv0 + (size_t)(pend_counter & 1u) * dim;
                 double *E         = fb.E + ((size_t)b * fb.eld + pend_counter) * fb.eld;
-                for (uint32_t i = 1 + tid; i < pend_R; i += 256) E[i] = esp[i];
+                for (uint32_t i = 1 + tid; i < pend_R; i += 256) E[i] = pend_degenerate ? 0.0 : cvp[i] / pend_den;
                 if (tid == 0)
                 {
                     fb.D[(size_t)b * n + pend_c]   = pend_diag;
@@ -973,55 +971,60 @@ namespace lexls
                 }
                 pend = false;
             };
-            for (uint32_t counter = 0; counter < dim; counter++)
-            {
-                const uint32_t R = dim - counter, par = counter & 1u;
-                double *es       = es0 + (size_t)par * dim;
-                // ---- own candidate: first maximum by position among the own live columns ----
-                if (tid == 0)
+            // Own candidate of pivot `cnt` (first maximum by position among the own live columns; every thread for itself: norms and positions
+            // are behind a barrier) and its RECORD — published as early as the norms allow, before the tile update of the previous pivot has
+            // finished: the others wait for records, the candidate's column follows (publish_column) and is only read by those who need it.
+            // Every 16-byte store carries the pivot's tag: nothing is drained and nothing is ordered — a reader takes a granule when its tag
+            // matches.
+            uint32_t cand_p = 0xffffffffu, cand_j = 0;
+            auto publish_record = [&](uint32_t cnt, uint32_t cfirst) {
+                double myv   = -1.0;
+                uint32_t myp = 0xffffffffu, myj = 0;
+#pragma unroll
+                for (int jj = 0; jj < PTC; jj++)
                 {
-                    double bv   = -1.0;
-                    uint32_t bp = 0xffffffffu, bj = 0;
-                    for (int jj = 0; jj < PTC; jj++)
+                    const uint32_t j = t * PTC + jj;
+                    if (j < n)
                     {
-                        const uint32_t j = t * PTC + jj;
-                        if (j < n && posm[j] >= c && (nrm[jj] > bv || (nrm[jj] == bv && posm[j] < bp)))
+                        const uint32_t pj = posm[j];
+                        const double vj   = nrm[jj];
+                        if (pj >= cfirst && (vj > myv || (vj == myv && pj < myp)))
                         {
-                            bv = nrm[jj];
-                            bp = posm[j];
-                            bj = j;
+                            myv = vj;
+                            myp = pj;
+                            myj = j;
                         }
                     }
-                    red_v[0] = bv;
-                    red_p[0] = bp;
-                    red_i[0] = bj;
                 }
-                __syncthreads();
-                const uint32_t myp = red_p[0], myj = red_i[0];
-                const double myv   = red_v[0];
-                __syncthreads();
-                // ---- publish: the record and the candidate column's remaining rows, every 16-byte store carrying this pivot's tag: nothing is
-                //      drained and nothing is ordered — a reader takes a granule when its tag matches (waves 1-3 store the column, wave 0 the
-                //      record, so that wave 0's polls do not queue behind the column stores) ----
-                const uint32_t tag = counter + 1u;
-                u32x4 *mycol       = reinterpret_cast<u32x4 *>(colbuf) + ((size_t)par * G + t) * colld;
-                if (myp != 0xffffffffu && tid >= 64)
-                {
-                    const double *srcc = tile + (myj - t * PTC) * ldt + counter;
-                    for (uint32_t i = tid - 64; i < R; i += 192)
-                    {
-                        const double v0 = srcc[i];
-                        u32x4 q;
-                        q.x = (unsigned)__double2loint(v0), q.y = (unsigned)__double2hiint(v0), q.z = tag, q.w = 0u;
-                        st16_sc1(mycol + i, q);
-                    }
-                }
+                cand_p = myp, cand_j = myj;
                 if (tid == 0)
                 {
                     u32x4 q;
-                    q.x = (unsigned)__double2loint(myv), q.y = (unsigned)__double2hiint(myv), q.z = myp, q.w = (tag << 8) | ((myj - t * PTC) & 255u); // (no candidate: pos says so, the index is not looked at)
-                    st16_sc1(cand + ((size_t)par * G + t) * PRS, q);
+                    q.x = (unsigned)__double2loint(myv), q.y = (unsigned)__double2hiint(myv), q.z = myp, q.w = ((cnt + 1u) << 8) | ((myj - t * PTC) & 255u); // (no candidate: pos says so, the index is not looked at)
+                    st16_sc1(cand + ((size_t)(cnt & 1u) * G + t) * PRS, q);
                 }
+            };
+            // the candidate's remaining rows, by the wavefront that owns (and has just updated) the column
+            auto publish_column = [&](uint32_t cnt) {
+                if (cand_p == 0xffffffffu || cand_j - t * PTC != wave) return;
+                const uint32_t Rn  = dim - cnt;
+                u32x4 *mycol       = reinterpret_cast<u32x4 *>(colbuf) + ((size_t)(cnt & 1u) * G + t) * colld;
+                const double *srcc = tile + (cand_j - t * PTC) * ldt + cnt;
+                for (uint32_t i = lane; i < Rn; i += 64)
+                {
+                    const double v0 = srcc[i];
+                    u32x4 q;
+                    q.x = (unsigned)__double2loint(v0), q.y = (unsigned)__double2hiint(v0), q.z = cnt + 1u, q.w = 0u;
+                    st16_sc1(mycol + i, q);
+                }
+            };
+            publish_record(0, c);
+            publish_column(0);
+            for (uint32_t counter = 0; counter < dim; counter++)
+            {
+                const uint32_t R = dim - counter, par = counter & 1u;
+                double *colv     = cv0 + (size_t)par * dim;
+                const uint32_t tag = counter + 1u;
                 flush_pending(); // (the previous pivot's bookkeeping, if it was this workgroup's turn: nobody waits for these stores)
                 PSTAMP(0)
                 // ---- wait for the G records of this pivot and pick the winner: wave 0, lane = workgroup (no counter: a record IS its flag) ----
@@ -1092,13 +1095,13 @@ namespace lexls
                         win_w = bestw;
                     }
                 }
-                __syncthreads();
+                __syncthreads(); // A
                 if (!flag) return; // (uniform per workgroup; the others see `abort`)
                 const uint32_t ppos = win_p, piv = win_i, wwin = win_w;
                 PSTAMP(1)
                 PSTAMP(2)
 
-                // ---- the pivot column (published by its owner), fresh / tail norms, reflector: as in fast_step ----
+                // ---- the pivot column (published by its owner): kept in LDS, partial sums of its fresh / tail norms on the way ----
                 const u32x4 *pcol = reinterpret_cast<const u32x4 *>(colbuf) + ((size_t)par * G + wwin) * colld;
                 double fr = 0.0, tl = 0.0;
                 for (uint32_t i = tid; i < R; i += 256)
@@ -1132,11 +1135,25 @@ namespace lexls
                     sums[wave]     = fr;
                     sums[4 + wave] = tl;
                 }
-                __syncthreads();
-                const double fresh  = (sums[0] + sums[1]) + (sums[2] + sums[3]);
-                const double tailSq = (sums[4] + sums[5]) + (sums[6] + sums[7]);
+                __syncthreads(); // B
                 PSTAMP(3)
                 if (colbad) return; // (a column granule timed out in this workgroup; `abort` is raised, the others see it in their spins)
+
+                // ---- own tile, first half: the dot product of the wave's column with the RAW pivot column — it does not wait for the
+                //      reflector's scalars (sqrt, two divisions), it runs beside them.  (This path's contract is exact pivots and values
+                //      within 1e-10: es^T a = (v^T a) / den is the same number up to rounding.) ----
+                const uint32_t jj = wave, j = t * PTC + jj; // PTC == 4: one column per wavefront
+                double *col        = tile + jj * ldt + counter;
+                // the column swap of this pivot (below) gives `piv` position c and the column that was there position ppos: trailing afterwards
+                // is "not the pivot and not finished before" — read off the map as it was (tid 0 rewrites two entries meanwhile: both stay >= c)
+                const bool trailing = j <= n && ((j == n) || (j != piv && posm[j] >= c));
+                double part         = 0.0;
+                if (trailing)
+                    for (uint32_t i = 1 + lane; i < R; i += 64) part = dfma(colv[i], col[i], part);
+                const double dotraw = wave_sum(part);
+
+                const double fresh  = (sums[0] + sums[1]) + (sums[2] + sums[3]);
+                const double tailSq = (sums[4] + sums[5]) + (sums[6] + sums[7]);
                 if (fresh < a.tol) // rank test (lexlse.h:214): the level ends here, in every workgroup
                 {
                     stop = 1;
@@ -1154,7 +1171,6 @@ namespace lexls
                     den  = c0v - beta;
                     tau  = (beta - c0v) / beta;
                 }
-                for (uint32_t i = 1 + tid; i < R; i += 256) es[i] = degenerate ? 0.0 : colv[i] / den;
                 // the swap of lexlse.h:222-232 on both maps (every workgroup keeps them)
                 if (tid == 0)
                 {
@@ -1167,44 +1183,38 @@ namespace lexls
                         invm[ppos]  = front;
                     }
                 }
-                __syncthreads();
-
-                // ---- own tile ----
-#pragma unroll
-                for (int h = 0; h < PTC / 4; h++)
+                // ---- own tile, second half: the new pivot-row entry and the down-dated norm first — they decide the NEXT pivot's record ----
+                double a0n = 0.0, sc = 0.0;
+                const bool upd = trailing && tau != 0.0;
+                if (trailing)
                 {
-                    const uint32_t jj = wave * (PTC / 4) + h, j = t * PTC + jj;
-                    if (j > n) continue;
-                    const bool trailing = (j == n) || (posm[j] > c);
-                    if (!trailing) continue;
-                    double *col = tile + jj * ldt + counter;
-                    double a0n;
                     const double a0 = col[0];
+                    a0n             = a0;
                     if (tau != 0.0)
                     {
-                        double part = 0.0;
-                        for (uint32_t i = 1 + lane; i < R; i += 64) part = dfma(es[i], col[i], part);
-                        const double tmp = wave_sum(part) + a0;
-                        const double nt  = -tau;
-                        a0n              = dfma(nt, tmp, a0);
-                        for (uint32_t i = 1 + lane; i < R; i += 64) col[i] = dfma(es[i] * nt, tmp, col[i]);
+                        const double tmp = dotraw / den + a0;
+                        a0n              = dfma(-tau, tmp, a0);
+                        sc               = (-tau * tmp) / den;
                         if (lane == 0) col[0] = a0n;
                     }
-                    else
-                        a0n = a0;
                     if (lane == 0 && j < n) nrm[jj] = dfma(-a0n, a0n, nrm[jj]);
                 }
-                // bookkeeping of this pivot: spread over the workgroups (workgroup `counter % G` writes it) so that no single workgroup is
-                // late at every hand-off
                 if (t == counter % G)
                 {
                     pend         = true;
                     pend_counter = counter, pend_c = c, pend_ppos = ppos, pend_R = R;
-                    pend_diag = diag, pend_tau = tau;
+                    pend_diag = diag, pend_tau = tau, pend_den = den;
+                    pend_degenerate = degenerate;
                 }
                 c++;
                 rank++;
-                __syncthreads();
+                __syncthreads(); // C: norms and maps of this pivot are in place
+                const bool last = c == n || counter + 1 == dim;
+                if (!last) publish_record(counter + 1, c);
+                // ---- the rest of the column, then (if it is the candidate) its rows for the others ----
+                if (upd)
+                    for (uint32_t i = 1 + lane; i < R; i += 64) col[i] = dfma(sc, colv[i], col[i]);
+                if (!last) publish_column(counter + 1);
                 PSTAMP(4)
                 if (c == n)
                 {
