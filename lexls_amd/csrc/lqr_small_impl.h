@@ -343,10 +343,14 @@ namespace lexls
 
                 if (dim_rt > 0 && (!exhausted || write_factor))
                 {
+#ifdef LEXLS_WAVE_NO_FULL
+                    factor_level(std::false_type{});
+#else
                     if (dim_rt == MD)
                         factor_level(std::true_type{});
                     else
                         factor_level(std::false_type{});
+#endif
                 }
                 const int dim = dim_rt;
 
@@ -493,10 +497,14 @@ namespace lexls
                 };
                 if (k + 1 < nObj && rank > 0)
                 {
+#ifdef LEXLS_WAVE_NO_FULL
+                    gauss(std::false_type{});
+#else
                     if (rank == MD)
                         gauss(std::true_type{});
                     else
                         gauss(std::false_type{});
+#endif
                 }
                 F += dim;
             }
