@@ -259,10 +259,16 @@ namespace lexls
                             }
                         });
                     };
-                    if (elim_uniform)
+#ifdef LEXLS_QUAD_SIZE_PROBE_A // (timing experiment only: the rare paths compiled out to see what the code size costs)
+                    eliminate(std::false_type{});
+#else
+                    // (the hints keep the rare forms out of the hot instruction stream: the kernel is larger than the instruction cache, and
+                    // with the rare blocks laid out in between, the common path cost 11 % more — 68.9 vs 61.1 us with them compiled out)
+                    if (__builtin_expect(elim_uniform, 1))
                         eliminate(std::false_type{});
                     else
                         eliminate(std::true_type{});
+#endif
                     if constexpr (WF)
                     {
                         // the multipliers L = A R^-1 of these rows (lexlse.h:441-446): column c' of the factor, final.  A pivot position's lane
@@ -438,8 +444,14 @@ namespace lexls
                                     e[r]            = gbc<r>(qe);
                                     ett[r]          = gbc<r>(et);
                                 });
-                                // (WF: a row of the wavefront that has stopped must keep its block — dependent rows are part of the factor)
-                                if (__ballot(cont && tau == 0.0) == 0ull && (!WF || __ballot(!cont) == 0ull))
+                                // x only: ONE form.  A row whose reflector is the identity (tau == 0, lexlse.h:239) runs the same stream with zero
+                                // essentials and a zero tau: every fma adds a zero product — its block comes through unchanged (an exact zero may
+                                // change its sign, nothing else can); a row that has stopped computes on data nobody reads again.  Keeping a second,
+                                // select-guarded form next to this one cost 11 % of the kernel through its register pressure alone (825 instead of
+                                // 127 AGPR moves in the code object; 68.9 -> 61.1 us per 4096 problems).
+                                // WF: a stopped row must keep its block bit for bit — dependent rows are part of the factor: guarded form when needed.
+                                const bool plain = !WF || (__ballot(cont && tau == 0.0) == 0ull && __ballot(!cont) == 0ull);
+                                if (plain)
                                 {
 #pragma unroll
                                     for (int s = S0; s < NS; s++)
@@ -453,9 +465,9 @@ namespace lexls
                                         for (int r = counter + 1; r < MD; r++) blk[s][r] = dfma(ett[r], tmp, blk[s][r]);
                                     }
                                 }
-                                else // some row has H = I (lexlse.h:239): there the block must come through bit for bit
+                                else if constexpr (WF)
                                 {
-                                    const bool app = tau != 0.0 && (!WF || cont);
+                                    const bool app = tau != 0.0 && cont;
 #pragma unroll
                                     for (int s = S0; s < NS; s++)
                                     {
