@@ -85,6 +85,8 @@ namespace lexls
 #pragma unroll
             for (int i = 0; i < 4; i++) D(o_emap + 8 * (16 * i + gl)) = 0.0;
             if (gl < kQuadMaxObj) U32(o_dims + 4 * gl) = (live && gl < nObj) ? dims[gl] : 0u; // one global read; a level's dim then costs an LDS read
+#pragma unroll
+            for (int s = 0; s < NS; s++) D(o_xs + 8 * (16 * s + gl)) = 0.0;
             quad_lds_fence();
 
             // The four waves of a CU (one per SIMD) would reach every level's loads together and queue behind each other in the CU's
@@ -109,7 +111,7 @@ namespace lexls
             for (int s = 0; s < NS; s++)
             {
                 idgreg[s] = 0.0;
-                rp[s]     = 0;
+                rp[s]     = o_xs; // (a position that is not a pivot yet "reads" zeros of the x block: see the elimination)
                 rq[s]     = 0x0c0c0c00;
                 em[s]     = 0ull;
                 pos[s]    = 0;
@@ -259,16 +261,14 @@ namespace lexls
                             }
                         });
                     };
-#ifdef LEXLS_QUAD_SIZE_PROBE_A // (timing experiment only: the rare paths compiled out to see what the code size costs)
-                    eliminate(std::false_type{});
-#else
-                    // (the hints keep the rare forms out of the hot instruction stream: the kernel is larger than the instruction cache, and
-                    // with the rare blocks laid out in between, the common path cost 11 % more — 68.9 vs 61.1 us with them compiled out)
-                    if (__builtin_expect(elim_uniform, 1))
+                    // x only: ONE form for all rows of the wavefront.  A row whose own pivots end before Fcmax runs the remaining pivot steps
+                    // with a zero reciprocal diagonal (idgreg of a position that is not a pivot yet) and the zeros of the x block as "U":
+                    // zero multipliers, every fma adds a zero product.  (The per-row guarded form is only kept where the multipliers are
+                    // stored; next to this one it cost 1.5 % through code size and registers.)
+                    if (!WF || elim_uniform)
                         eliminate(std::false_type{});
-                    else
+                    else if constexpr (WF)
                         eliminate(std::true_type{});
-#endif
                     if constexpr (WF)
                     {
                         // the multipliers L = A R^-1 of these rows (lexlse.h:441-446): column c' of the factor, final.  A pivot position's lane
