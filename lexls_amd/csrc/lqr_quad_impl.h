@@ -431,8 +431,10 @@ namespace lexls
                                     idgv = gbc<15>(quo);
                                 else
                                     idgv = 1.0 / diag;
-                                const double tau  = sel(degenerate, 0.0, gbc<0>(quo));
-                                const double qe   = sel(degenerate || !ess_lane, 0.0, quo); // lane r: essential entry of row r
+                                // (WF: a row of the wavefront that has stopped runs this pivot as an identity reflector — see below)
+                                const bool ident  = degenerate || (WF && !cont);
+                                const double tau  = sel(ident, 0.0, gbc<0>(quo));
+                                const double qe   = sel(ident || !ess_lane, 0.0, quo); // lane r: essential entry of row r
                                 const double ntau = -tau;
                                 const double et   = qe * ntau;
                                 STAMP(4)
@@ -444,41 +446,22 @@ namespace lexls
                                     e[r]            = gbc<r>(qe);
                                     ett[r]          = gbc<r>(et);
                                 });
-                                // x only: ONE form.  A row whose reflector is the identity (tau == 0, lexlse.h:239) runs the same stream with zero
-                                // essentials and a zero tau: every fma adds a zero product — its block comes through unchanged (an exact zero may
-                                // change its sign, nothing else can); a row that has stopped computes on data nobody reads again.  Keeping a second,
-                                // select-guarded form next to this one cost 11 % of the kernel through its register pressure alone (825 instead of
-                                // 127 AGPR moves in the code object; 68.9 -> 61.1 us per 4096 problems).
-                                // WF: a stopped row must keep its block bit for bit — dependent rows are part of the factor: guarded form when needed.
-                                const bool plain = !WF || (__ballot(cont && tau == 0.0) == 0ull && __ballot(!cont) == 0ull);
-                                if (plain)
+                                // ONE form for every row of the wavefront.  A row whose reflector is the identity (tau == 0, lexlse.h:239) — or, with the
+                                // factor kept, a row that has stopped: its dependent rows are part of the factor — runs the same stream with zero
+                                // essentials and a zero tau: every fma adds a zero product, the block comes through unchanged (an exact zero may
+                                // change its sign, nothing else can); x only, a stopped row computes on data nobody reads again.  Keeping a second,
+                                // select-guarded form next to this one cost 11 % of the x-only kernel through its register pressure alone (825
+                                // instead of 127 AGPR moves in the code object; 68.9 -> 61.1 us per 4096 problems).
+#pragma unroll
+                                for (int s = S0; s < NS; s++)
                                 {
+                                    double tmp = 0.0;
 #pragma unroll
-                                    for (int s = S0; s < NS; s++)
-                                    {
-                                        double tmp = 0.0;
+                                    for (int r = counter + 1; r < MD; r++) tmp = dfma(e[r], blk[s][r], tmp);
+                                    tmp += blk[s][counter];
+                                    blk[s][counter] = dfma(ntau, tmp, blk[s][counter]);
 #pragma unroll
-                                        for (int r = counter + 1; r < MD; r++) tmp = dfma(e[r], blk[s][r], tmp);
-                                        tmp += blk[s][counter];
-                                        blk[s][counter] = dfma(ntau, tmp, blk[s][counter]);
-#pragma unroll
-                                        for (int r = counter + 1; r < MD; r++) blk[s][r] = dfma(ett[r], tmp, blk[s][r]);
-                                    }
-                                }
-                                else if constexpr (WF)
-                                {
-                                    const bool app = tau != 0.0 && cont;
-#pragma unroll
-                                    for (int s = S0; s < NS; s++)
-                                    {
-                                        double tmp = 0.0;
-#pragma unroll
-                                        for (int r = counter + 1; r < MD; r++) tmp = dfma(e[r], blk[s][r], tmp);
-                                        tmp += blk[s][counter];
-                                        blk[s][counter] = sel(app, dfma(ntau, tmp, blk[s][counter]), blk[s][counter]);
-#pragma unroll
-                                        for (int r = counter + 1; r < MD; r++) blk[s][r] = sel(app, dfma(ett[r], tmp, blk[s][r]), blk[s][r]);
-                                    }
+                                    for (int r = counter + 1; r < MD; r++) blk[s][r] = dfma(ett[r], tmp, blk[s][r]);
                                 }
 #pragma unroll
                                 for (int s = S0; s < NS; s++) blk[s][counter] = sel(isp[s] && (!WF || cont), diag, blk[s][counter]);
