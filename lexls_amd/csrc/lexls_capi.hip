@@ -661,12 +661,13 @@ extern "C"
         HIP_TRY(hipSetDevice(h->device));
         const char *variant = "";
         const LseArgs a     = h->args();
-        const bool shape_kernels = h->force_generic != 1 && h->reg_type == 0; // the regularization family lives in the generic kernel only
+        const bool shape_kernels = h->force_generic != 1;
+        // (the regularization family lives in the register-resident wave kernel's REG instantiations and in the generic kernel)
         if (shape_kernels && wave_kernel_supports(a, h->max_rows, h->max_level_dim, h->has_fixed))
         {
             HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, h->force_generic == 2 ? -1 : (h->force_generic == 3 ? 1 : (h->force_generic == 4 ? 2 : 0)), h->stream, &variant)); // always solves as well
         }
-        else if (shape_kernels && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
+        else if (shape_kernels && h->reg_type == 0 && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
         {
             if (h->force_generic == 5) // the bit-exact multi-launch path (ordered chains: parity tests, reference for the fast path)
             {

@@ -12,6 +12,8 @@ namespace lexls
     hipError_t launch_wave_41x12_f(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_64x16_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_64x16_f(const LseArgs &a, hipStream_t s);
+    hipError_t launch_wave_41x12_fR(const LseArgs &a, hipStream_t s);
+    hipError_t launch_wave_64x16_fR(const LseArgs &a, hipStream_t s);
 
     hipError_t launch_lwave_41x12e_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_lwave_41x12e_f(const LseArgs &a, hipStream_t s);
@@ -49,6 +51,7 @@ namespace lexls
     bool wave_dispatch_is_register_resident(const LseArgs &a, uint32_t max_level_dim, bool has_fixed, int left_looking)
     {
         (void)max_level_dim;
+        if (a.reg_type != 0) return true;
         if (left_looking > 0) return false;
         const bool lwave_pays = left_looking == 0 && a.batch > resident_wave_capacity();
         return has_fixed || !lwave_pays;
@@ -58,6 +61,16 @@ namespace lexls
                                const char **variant)
     {
         const uint32_t nc = a.nVar + 1;
+        if (a.reg_type != 0) // the regularization family: the register-resident kernel's REG instantiations (factor always kept)
+        {
+            if (max_level_dim <= 12 && nc <= 41)
+            {
+                *variant = "lqr_wave<41,12,regularized>";
+                return launch_wave_41x12_fR(a, s);
+            }
+            *variant = "lqr_wave<64,16,regularized>";
+            return launch_wave_64x16_fR(a, s);
+        }
         // left-looking form (lqr_lwave_impl.h): one level block live per wave, 4 waves/SIMD; no fixed variables.  Measured on MI355X
         // (scripts/latency_scan.py, n = 40, 5 x 12): while the batch fits one round of the register-resident kernel (<= 2048 problems)
         // that kernel has the shorter latency (factor kept: 66-72 us vs 97-101 us; x only: equal); beyond that the left-looking kernel

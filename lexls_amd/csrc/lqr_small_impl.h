@@ -23,6 +23,7 @@
 // images the back-substitution needs (~10 KB), so ~12 waves fit a CU.
 #pragma once
 #include "lqr_wave_common.h"
+#include "lexls_regularize.h"
 
 namespace lexls
 {
@@ -37,7 +38,11 @@ namespace lexls
 #ifndef LEXLS_WAVE_OCC
 #define LEXLS_WAVE_OCC 2
 #endif
-        template <int NC, int MD, bool EXACT, bool WF>
+        // REG: the regularization family (lexlse.h:277-411) on this kernel: after a level is factorised its transformed right-hand side is
+        // damped by lexls_regularize.h's routines — the same ones, in the same order, the generic kernel calls — working on the level's
+        // compact LDS image [R T | rhs] as their matrix view; the accumulated null-space basis lives in the handle's scratch and follows
+        // the column swaps.  Own instantiations (lqr_small_*_fR.hip): the common path does not carry the calls.
+        template <int NC, int MD, bool EXACT, bool WF, bool REG = false>
         __global__ __launch_bounds__(64, LEXLS_WAVE_OCC) void lqr_wave_kernel(LseArgs a, uint32_t img_doubles)
         {
             constexpr bool write_factor = WF; // factor kept in HBM (get_lexqr / dual solve) or x-only traffic
@@ -93,6 +98,11 @@ namespace lexls
             if (lane < 16) ZB[lane] = 0.0;
             for (uint32_t i = lane; i < img_doubles; i += 64) IMG[i] = 0.0; // (the trailing update of a ragged level reads past a column's rank)
 
+            if constexpr (REG) // initialize(): null_space.setZero() (lexlse.h:1686)
+            {
+                double *NS = a.reg_scratch + (size_t)b * reg_scratch_doubles((uint32_t)n);
+                for (int e = lane; e < n * (n + 1); e += 64) NS[e] = 0.0;
+            }
             int pos        = (lane < n) ? lane : (lane == n ? n : 0x3fffffff);
             int rowlim     = 64; // factor output: rows of this lane's physical column that the row-per-lane image T still owns (all, until it is pivoted)
             double *fac_out = a.fac + b * pstride;
@@ -235,6 +245,19 @@ namespace lexls
                         // -- column "swap": update the position map (lexlse.h:222-232) --
                         const int ppos = __builtin_amdgcn_readlane(pos, pl);
                         if (lane == 0) perm_s[ColIndex] = (uint32_t)ppos;
+                        if constexpr (REG)
+                        {
+                            if (ppos != ColIndex) // lexlse.h:229-231: the rows of the null-space basis above this level's first column swap too
+                            {
+                                double *NS = a.reg_scratch + (size_t)b * reg_scratch_doubles((uint32_t)n);
+                                for (int i = lane; i < Fc; i += 64)
+                                {
+                                    const double t0               = NS[i + (size_t)ColIndex * n];
+                                    NS[i + (size_t)ColIndex * n] = NS[i + (size_t)ppos * n];
+                                    NS[i + (size_t)ppos * n]     = t0;
+                                }
+                            }
+                        }
                         {
                             const unsigned long long mc = __ballot(lane < n && pos == ColIndex);
                             const int lc                = (int)__builtin_ctzll(mc);
@@ -376,6 +399,21 @@ namespace lexls
                             if (r < stride) img[(slot - Fc) * stride + r] = (r < rank) ? hh[r] : 0.0; // padding row zeroed
                     }
                     imgp += (uint32_t)((n + 1 - Fc) * stride);
+                }
+                if constexpr (REG) // lexlse.h:277-411: the level's transformed right-hand side is damped before the Gauss step
+                {
+                    __syncthreads(); // the image is in place (and so is everything the swaps wrote to the null-space basis)
+                    __threadfence_block();
+                    // matrix view of the routines: w(F + r, Fc + c) = img[c * stride + r] (columns in position order, the rhs at position n)
+                    double *Wv = img - ((size_t)F + (size_t)Fc * (size_t)stride);
+                    regularize_level<64>(a, b, Wv, (size_t)(stride > 0 ? stride : 1), (uint32_t)nf, (uint32_t)k, (uint32_t)F, (uint32_t)Fc, (uint32_t)rank, (uint32_t)(n - ColIndex), (uint32_t)lane);
+                    __syncthreads();
+                    if (rank > 0 && lane == n) // the damped right-hand side is what the factor keeps (and what the Gauss step below subtracts)
+                    {
+#pragma unroll
+                        for (int r = 0; r < MD; r++)
+                            if (r < rank) hh[r] = img[(n - Fc) * stride + r];
+                    }
                 }
                 slotmap[k * 64 + lane] = (uint8_t)((lane < n) ? pos : n);
                 if (write_factor && dim > 0) // the level's final rows go back into the row-per-lane image (factor output)
@@ -577,7 +615,7 @@ namespace lexls
 
     namespace
     {
-        template <int NC, int MD, bool EXACT, bool WF>
+        template <int NC, int MD, bool EXACT, bool WF, bool REG = false>
         hipError_t launch_wave_t2(const LseArgs &a, hipStream_t s)
         {
             // worst case of sum_k (n+1-Fc_k) * even(rank_k) over rank distributions with rank_k <= MD
@@ -587,10 +625,11 @@ namespace lexls
             if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
             if (lds > 64 * 1024)
             {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_wave_kernel<NC, MD, EXACT, WF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_wave_kernel<NC, MD, EXACT, WF, REG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
             }
-            hipLaunchKernelGGL((lqr_wave_kernel<NC, MD, EXACT, WF>), dim3(a.batch), dim3(64), lds, s, a, img);
+            if (REG && !a.reg_scratch) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((lqr_wave_kernel<NC, MD, EXACT, WF, REG>), dim3(a.batch), dim3(64), lds, s, a, img);
             return hipGetLastError();
         }
 
@@ -600,3 +639,5 @@ namespace lexls
 // One translation unit per instantiation (parallel builds): LEXLS_WAVE_INSTANCE(name, NC, MD, EXACT, WF)
 #define LEXLS_WAVE_INSTANCE(NAME, NC, MD, EXACT, WF) \
     namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_wave_t2<NC, MD, EXACT, WF>(a, s); } }
+#define LEXLS_WAVE_INSTANCE_REG(NAME, NC, MD) \
+    namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_wave_t2<NC, MD, false, true, true>(a, s); } }

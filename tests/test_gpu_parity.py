@@ -562,10 +562,13 @@ def test_least_norm_normal_equations(hip, oracle):
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
+@pytest.mark.parametrize("policy", [0, 1], ids=["wave-kernel", "generic-kernel"])
 @pytest.mark.parametrize("reg_type", [1, 2, 3, 4, 5, 6, 8, 9])
-def test_regularization_family_bit_exact(hip, oracle, reg_type):
-    """lexlse.h:277-411 on the device (generic kernel): bit-identical to the oracle for every implemented type, on a hierarchy that
-    takes both Tikhonov branches (tikhonov_1 and tikhonov_2), with fixed variables, per-problem factors and a rank-deficient level."""
+def test_regularization_family_bit_exact(hip, oracle, reg_type, policy):
+    """lexlse.h:277-411 on the device — in the register-resident wave kernel's REG instantiation (default for these shapes: the routines of
+    lexls_regularize.h work on the level's LDS image) and in the generic kernel: bit-identical to the oracle for every implemented type,
+    on a hierarchy that takes both Tikhonov branches (tikhonov_1 and tikhonov_2), with fixed variables, per-problem factors and a
+    rank-deficient level."""
     n, dims, batch = 12, [3, 4, 2], 6
     lod = P.lse_batch(7, batch, n, dims)
     lod[3:, :, 5] = lod[3:, :, 4]  # duplicated row in level 1 of half of the problems
@@ -580,15 +583,17 @@ def test_regularization_family_bit_exact(hip, oracle, reg_type):
         ref = oracle.lse_run(lod[b:b + 1], dims, n, reg_type=reg_type, reg_factors=fac[b], nfixed=nfixed[b:b + 1], fixed_idx=idx[b:b + 1],
                              fixed_val=val[b:b + 1])
         s = hip.BatchedLexLSE(1, n, dims)
+        s.set_kernel_policy(policy)
         s.setRegularization(reg_type, fac[b])
         s.fixVariables(nfixed[b:b + 1], idx[b:b + 1], val[b:b + 1])
         s.setProblem(lod[b:b + 1])
         s.factorize_solve()
-        assert s.last_kernel().startswith("lqr_generic")
+        assert s.last_kernel().startswith("lqr_generic" if policy == 1 else "lqr_wave<41,12,regularized>")
         assert_factor_equal(s, ref, dims, n)
         np.testing.assert_array_equal(s.get_x(), ref["x"])
     # the whole batch at once with per-problem factors gives the same solutions
     s = hip.BatchedLexLSE(batch, n, dims)
+    s.set_kernel_policy(policy)
     s.setRegularization(reg_type, fac)
     s.fixVariables(nfixed, idx, val)
     s.setProblem(lod)
@@ -597,6 +602,32 @@ def test_regularization_family_bit_exact(hip, oracle, reg_type):
         ref = oracle.lse_run(lod[b:b + 1], dims, n, reg_type=reg_type, reg_factors=fac[b], nfixed=nfixed[b:b + 1], fixed_idx=idx[b:b + 1],
                              fixed_val=val[b:b + 1])
         np.testing.assert_array_equal(s.get_x()[b], ref["x"][0])
+
+
+@pytest.mark.parametrize("reg_type", [1, 8, 3, 2])
+def test_regularization_on_the_wave_kernel_ik_shapes(hip, oracle, reg_type):
+    """the regularized wave kernel on the IK shape (n = 40, 5 x 12; columns run out in level 3: both Tikhonov branches) and on a wide one
+    served by lqr_wave<64,16,regularized>, ragged levels included: factor, pivots, x bit-identical to the oracle, and to the generic kernel"""
+    for (n, dims, seed, kernel) in ((40, [12] * 5, 4100, "lqr_wave<41,12,regularized>"), (55, [14, 9, 16, 5], 4200, "lqr_wave<64,16,regularized>")):
+        batch = 5
+        lod = P.lse_batch(seed, batch, n, dims)
+        fac = np.abs(P.normal(seed + 1, batch * len(dims))).reshape(batch, len(dims)) * 0.3 + 0.01
+        s = hip.BatchedLexLSE(batch, n, dims)
+        s.setRegularization(reg_type, fac)
+        s.setProblem(lod)
+        s.factorize_solve()
+        assert s.last_kernel() == kernel
+        g = hip.BatchedLexLSE(batch, n, dims)
+        g.set_kernel_policy(1)
+        g.setRegularization(reg_type, fac)
+        g.setProblem(lod)
+        g.factorize_solve()
+        np.testing.assert_array_equal(s.get_x(), g.get_x())
+        np.testing.assert_array_equal(s.get_lexqr(), g.get_lexqr())
+        for b in range(batch):
+            ref = oracle.lse_run(lod[b:b + 1], dims, n, reg_type=reg_type, reg_factors=fac[b])
+            np.testing.assert_array_equal(s.get_x()[b], ref["x"][0])
+            np.testing.assert_array_equal(s.get_column_permutations()[b], ref["perm"][0])
 
 
 def test_regularization_variable_factor_and_least_norm_3(hip, oracle):
