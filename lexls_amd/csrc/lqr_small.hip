@@ -7,7 +7,6 @@ namespace lexls
 {
     hipError_t launch_wave_41x12e_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_41x12e_f(const LseArgs &a, hipStream_t s);
-    hipError_t launch_wave_41x12e_fr(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_41x12_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_41x12_f(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_64x16_x(const LseArgs &a, hipStream_t s);
@@ -108,11 +107,6 @@ namespace lexls
             }
             *variant = "lqr_lwave<41,12>";
             return write_factor ? launch_lwave_41x12_f(a, s) : launch_lwave_41x12_x(a, s);
-        }
-        if (max_level_dim <= 12 && nc == 41 && write_factor && a.g_cdata) // rows by reference = a lock-step LexLSI stage: ragged levels
-        {
-            *variant = "lqr_wave<41,12,exact,ragged>";
-            return launch_wave_41x12e_fr(a, s);
         }
         if (max_level_dim <= 12 && nc == 41)
         {

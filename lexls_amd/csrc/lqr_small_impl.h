@@ -25,6 +25,14 @@
 #include "lqr_wave_common.h"
 #include "lexls_regularize.h"
 
+// Ragged levels (dim < MD) run the static stream of a full level on a zero-padded block (see factor_level).  The earlier form — the same code
+// under run-time guards per element — made `v_mov_b64` the most frequent instruction of the ragged path (the compiler copies a register array
+// around every conditional update of one of its elements) and doubled the code (112 KB against a 64 KB instruction cache):
+// 1024 LSI-like problems 88.8 -> 78.1 us, lock-step LSI stages 76 -> 64 us.  -DLEXLS_WAVE_UNPADDED brings the guarded form back (A/B builds).
+#ifndef LEXLS_WAVE_UNPADDED
+#define LEXLS_WAVE_PADDED
+#endif
+
 namespace lexls
 {
     namespace
@@ -169,11 +177,29 @@ namespace lexls
                 // =====================================================================================
                 auto factor_level = [&](auto full_c) {
                     constexpr bool FULL = decltype(full_c)::value;
-                    const int dim       = FULL ? MD : dim_rt;
+#ifdef LEXLS_WAVE_PADDED
+                    // PADDED: a ragged level (dim < MD) runs the static, branch-free stream of a full one on a block whose rows >= dim are
+                    // zero — every extra fma adds a zero product, the last real row meets a zero tail (tau = 0, R_jj = the entry itself:
+                    // lexlse.h:239's "no reflector" outcome).  Only what is structural keeps the run-time dimension: which lanes are the
+                    // level's rows, how many pivot steps run, where a pivoted column's factor rows end.
+                    static_assert(FULL, "padded levels run the full form");
+                    const int dim  = MD;
+                    const int dimS = dim_rt;
+#else
+                    const int dim  = FULL ? MD : dim_rt;
+                    const int dimS = dim;
+#endif
 
                     // transpose the level's rows: row-per-lane T -> column-per-lane hh (through LDS)
+#ifdef LEXLS_WAVE_PADDED
+                    if (lane < MD) // pivots this level does not reach: lane 0 and a zero reciprocal diagonal (zero multipliers in the Gauss step)
+                    {
+                        pivl_s[lane] = 0;
+                        idg_s[lane]  = 0.0;
+                    }
+#endif
                     __syncthreads();
-                    if (lane >= F && lane < F + dim)
+                    if (lane >= F && lane < F + dimS)
                     {
 #pragma unroll
                         for (int j = 0; j < NC; j++)
@@ -182,9 +208,14 @@ namespace lexls
                     __syncthreads();
                     if (lane <= n)
                     {
+#ifdef LEXLS_WAVE_PADDED
+#pragma unroll
+                        for (int r = 0; r < MD; r++) hh[r] = (r < dimS) ? X[lane * MD + r] : 0.0;
+#else
 #pragma unroll
                         for (int r = 0; r < MD; r++)
                             if (r < dim) hh[r] = X[lane * MD + r];
+#endif
                     }
 
                     // initial squared norms of the level's columns (lexlse.h:193-196); rows >= dim are zero: fma(0,0,s) == s
@@ -197,7 +228,7 @@ namespace lexls
 #pragma unroll
                     for (int counter = 0; counter < MD; counter++)
                     {
-                        if (!(go && counter < dim)) continue;
+                        if (!(go && counter < dimS)) continue;
                         const int R   = dim - counter; // compile-time when FULL
                         const int row = F + counter;
 
@@ -263,7 +294,7 @@ namespace lexls
                             const int lc                = (int)__builtin_ctzll(mc);
                             if (lane == lc) pos = ppos;
                             if (lane == pl) pos = ColIndex;
-                            if (write_factor && lane == pl) rowlim = F + dim; // below this level the column holds Gauss multipliers, stored directly
+                            if (write_factor && lane == pl) rowlim = F + dimS; // below this level the column holds Gauss multipliers, stored directly
                         }
 
                         const double c0 = rdlane(hh[counter], pl);
@@ -366,7 +397,9 @@ namespace lexls
 
                 if (dim_rt > 0 && (!exhausted || write_factor))
                 {
-#ifdef LEXLS_WAVE_NO_FULL
+#if defined(LEXLS_WAVE_PADDED)
+                    factor_level(std::true_type{});
+#elif defined(LEXLS_WAVE_NO_FULL)
                     factor_level(std::false_type{});
 #else
                     if (dim_rt == MD)
@@ -473,7 +506,11 @@ namespace lexls
                                 if (q > p2) acc[q] = dfma(-Lv[p2], rrow[q], acc[q]);
                             // factor output: the multipliers go straight to their final place (pivot p2 of this level sits at position Fc + p2;
                             // lanes = consecutive rows: one coalesced store) instead of into T through a dynamic register index
+#ifdef LEXLS_WAVE_PADDED
+                            if (write_factor && below && p2 < rank) fac_out[lane + (size_t)(Fc + p2) * cap] = Lv[p2];
+#else
                             if (write_factor && below) fac_out[lane + (size_t)(Fc + p2) * cap] = Lv[p2];
+#endif
                         }
                     }
 #pragma unroll
@@ -527,7 +564,11 @@ namespace lexls
                             }
                         }
                     };
+#ifdef LEXLS_WAVE_PADDED
+                    if (stride > MD / 2 + (MD / 2) % 2)
+#else
                     if (FULL || stride > MD / 2 + (MD / 2) % 2)
+#endif
                         trailing(std::integral_constant<int, MD / 2>{});
                     else
                         trailing(std::integral_constant<int, (MD / 2 + 1) / 2>{}); // rank <= MD / 2 (rounded up to a pair): half the stream
@@ -535,7 +576,9 @@ namespace lexls
                 };
                 if (k + 1 < nObj && rank > 0)
                 {
-#ifdef LEXLS_WAVE_NO_FULL
+#if defined(LEXLS_WAVE_PADDED)
+                    gauss(std::true_type{});
+#elif defined(LEXLS_WAVE_NO_FULL)
                     gauss(std::false_type{});
 #else
                     if (rank == MD)
@@ -620,7 +663,7 @@ namespace lexls
         {
             // worst case of sum_k (n+1-Fc_k) * even(rank_k) over rank distributions with rank_k <= MD
             const uint32_t n   = a.nVar;
-            const uint32_t img = (n * n) / 2 + n + (n * MD) / 2 + a.nObj * (n + 1) + 64;
+            const uint32_t img = (n * n) / 2 + n + (n * MD) / 2 + a.nObj * (n + 1) + 64 + MD * MD; // (+ zeros behind the last image: a padded level reads MD columns of it)
             const size_t lds   = 8 * ((size_t)NC * MD + 128 + img + 64) + 4 * (64 + 4 * (size_t)a.nObj) + 64 + 64 * (size_t)a.nObj + 128 + 16;
             if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
             if (lds > 64 * 1024)
