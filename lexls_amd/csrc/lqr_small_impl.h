@@ -32,6 +32,12 @@
 #ifndef LEXLS_WAVE_UNPADDED
 #define LEXLS_WAVE_PADDED
 #endif
+// The pivot's lane hands its column to the wave through LDS and the scalars of the reflector travel by DPP row broadcasts (as in
+// lqr_quad_impl.h) instead of ~60 v_readlane / 20 v_writelane per pivot: 78.0 -> 75.5 us per 1024 LSI-like problems.
+// -DLEXLS_WAVE_LANE_HANDOFF brings the v_readlane form back (A/B builds).
+#ifndef LEXLS_WAVE_LANE_HANDOFF
+#define LEXLS_WAVE_LDS_HANDOFF
+#endif
 
 namespace lexls
 {
@@ -256,6 +262,143 @@ namespace lexls
                         pl = uni(pl);
                         STAMP(2)
 
+#ifdef LEXLS_WAVE_LDS_HANDOFF
+                        // -- fresh norm of the pivot column and the Householder tail norm (lexlse.h:210-211, :241), every lane on its own column;
+                        //    the pivot's lane hands [fresh, tail | its column] to the wave through LDS (one write burst, two reads: in-order
+                        //    within the wave, no barrier) — it replaced ~60 v_readlane / 20 v_writelane per pivot with their SGPR hazards --
+                        double fr = 0.0, tl = 0.0;
+#pragma unroll
+                        for (int r = 0; r < MD; r++)
+                        {
+                            if (r >= counter) fr = dfma(hh[r], hh[r], fr);
+                            if (r > counter) tl = dfma(hh[r], hh[r], tl);
+                        }
+                        {
+                            const int ce = counter & ~1; // (folds: the pivot loop is unrolled)
+                            if (lane == pl)
+                            {
+                                *reinterpret_cast<double2 *>(EX) = make_double2(fr, tl);
+#pragma unroll
+                                for (int r = 0; r < MD; r += 2)
+                                    if (r >= ce) *reinterpret_cast<double2 *>(EX + 2 + r) = make_double2(hh[r], hh[r + 1]);
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        asm volatile("" ::: "memory");
+                        const int l16       = lane & 15;
+                        const double2 ft    = *reinterpret_cast<const double2 *>(EX);
+                        const double fresh  = ft.x;
+                        const double c0     = EX[2 + counter];
+                        const double spread = EX[2 + (l16 < MD ? l16 : MD - 1)];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        asm volatile("" ::: "memory");
+                        if (lane == pl) nrm = fresh;
+                        if (fresh < a.tol) // rank test on the squared norm (lexlse.h:214)
+                        {
+                            go = false;
+                            continue;
+                        }
+                        STAMP(3)
+
+                        // -- column "swap": update the position map (lexlse.h:222-232) --
+                        const int ppos = __builtin_amdgcn_readlane(pos, pl);
+                        if (lane == 0) perm_s[ColIndex] = (uint32_t)ppos;
+                        if constexpr (REG)
+                        {
+                            if (ppos != ColIndex) // lexlse.h:229-231: the rows of the null-space basis above this level's first column swap too
+                            {
+                                double *NS = a.reg_scratch + (size_t)b * reg_scratch_doubles((uint32_t)n);
+                                for (int i = lane; i < Fc; i += 64)
+                                {
+                                    const double t0               = NS[i + (size_t)ColIndex * n];
+                                    NS[i + (size_t)ColIndex * n] = NS[i + (size_t)ppos * n];
+                                    NS[i + (size_t)ppos * n]     = t0;
+                                }
+                            }
+                        }
+                        {
+                            const unsigned long long mc = __ballot(lane < n && pos == ColIndex);
+                            const int lc                = (int)__builtin_ctzll(mc);
+                            if (lane == lc) pos = ppos;
+                            if (lane == pl) pos = ColIndex;
+                            if (write_factor && lane == pl) rowlim = F + dimS; // below this level the column holds Gauss multipliers, stored directly
+                        }
+
+                        if (R > 1)
+                        {
+                            const double tailSq   = ft.y;
+                            const bool degenerate = tailSq <= DBL_MIN;
+                            double beta           = sqrt(dfma(c0, c0, tailSq));
+                            if (c0 >= 0.0) beta = -beta;
+                            const double diag = degenerate ? c0 : beta;
+                            const double den  = c0 - beta;
+                            // every 16-lane row holds the pivot column (lane r of the row: v_r): ONE division sequence gives tau (lane 0 of a
+                            // row), the essential part (lanes counter+1 .. dim-1) and 1 / R_jj (the other lanes) in every row, and the DPP row
+                            // broadcasts hand them to all lanes
+                            const bool ess_lane = l16 > counter && l16 < dim;
+                            double num          = ess_lane ? spread : 1.0;
+                            double dnm          = ess_lane ? den : diag;
+                            if (l16 == 0)
+                            {
+                                num = beta - c0;
+                                dnm = beta;
+                            }
+                            const double quo = num / dnm;
+                            if constexpr (MD < 16)
+                            {
+                                if (lane == 63) idg_s[counter] = quo; // (lane 15 of a row has no other role)
+                            }
+                            else
+                            {
+                                const double rd = 1.0 / diag;
+                                if (lane == 63) idg_s[counter] = rd;
+                            }
+                            STAMP(4)
+                            const double tau  = degenerate ? 0.0 : gbc<0>(quo);
+                            const double qe   = (degenerate || !ess_lane) ? 0.0 : quo; // lane r of a row: essential entry of row r
+                            const double ntau = -tau;
+                            double e[MD], ett[MD];
+#pragma unroll
+                            for (int r = 0; r < MD; r++) e[r] = ett[r] = 0.0;
+                            for_each_index<1, MD>([&](auto rc) {
+                                constexpr int r = decltype(rc)::value;
+                                if (r > counter)
+                                {
+                                    e[r]   = gbc<r>(qe);
+                                    ett[r] = e[r] * ntau;
+                                }
+                            });
+
+                            // the pivot column now holds beta and the essential part (zeros if degenerate)
+                            if (lane == pl)
+                            {
+                                hh[counter] = diag;
+#pragma unroll
+                                for (int r = 0; r < MD; r++)
+                                    if (r > counter) hh[r] = e[r];
+                            }
+                            // apply H to the trailing columns and the RHS (lexlse.h:243-246); zero essentials are no-ops
+                            const bool trailing = ((lane < n) && (pos > ColIndex)) || (lane == n);
+                            if (tau != 0.0 && trailing)
+                            {
+                                double tmp = 0.0;
+#pragma unroll
+                                for (int r = 0; r < MD; r++)
+                                    if (r > counter) tmp = dfma(e[r], hh[r], tmp);
+                                tmp += hh[counter];
+                                hh[counter] = dfma(ntau, tmp, hh[counter]);
+#pragma unroll
+                                for (int r = 0; r < MD; r++)
+                                    if (r > counter) hh[r] = dfma(ett[r], tmp, hh[r]);
+                            }
+                            if (lane == 0) hhs[row] = tau;
+                        }
+                        else
+                        {
+                            const double rd = 1.0 / c0;
+                            if (lane == 63) idg_s[counter] = rd;
+                        }
+#else
                         // -- fresh norm of the pivot column and the Householder tail norm (lexlse.h:210-211, :241) --
                         double fr = 0.0, tl = 0.0;
 #pragma unroll
@@ -378,6 +521,7 @@ namespace lexls
                         {
                             if (lane == 63) idg_s[counter] = 1.0 / c0;
                         }
+#endif
                         if (lane == 0) pivl_s[counter] = pl;
 
                         ColIndex++;
