@@ -1339,9 +1339,11 @@ namespace lexls
 
         constexpr int SWEEP_MD = 16, SWEEP_T = 2; // rows per level; objective registers per DPP row (4 rows x 2 = 8 objectives)
 
+        template <int MD> // rows per level the unrolled reflector loops cover (12 for the IK shapes: a quarter fewer wave-uniform tests than 16)
         __global__ __launch_bounds__(64) void sensitivity_sweep_kernel(LseArgs a, const int32_t *obj_index, int32_t obj_all, double tolW, double tolC, int scan_up)
         {
-            constexpr int MD = SWEEP_MD, TT = SWEEP_T;
+            static_assert(MD <= SWEEP_MD, "row layout: one level row per lane of a 16-lane DPP row");
+            constexpr int TT = SWEEP_T;
             extern __shared__ double smem[];
             const uint32_t b = blockIdx.x, lane = threadIdx.x;
             const int rho = (int)(lane >> 4), il = (int)(lane & 15u);
@@ -1624,7 +1626,10 @@ namespace lexls
         if (sweep_level_dim_hint > 0 && sweep_level_dim_hint <= (uint32_t)SWEEP_MD && a.nObj <= 8 && a.nVar <= 64 && lds_sweep <= 64 * 1024 && a.batch <= 4u * (uint32_t)cus &&
             !std::getenv("LEXLS_SENS_NO_SWEEP"))
         {
-            hipLaunchKernelGGL(sensitivity_sweep_kernel, dim3(a.batch), dim3(64), lds_sweep, s, a, d_obj_index, obj_all, tolW, tolC, scan_up ? 1 : 0);
+            if (sweep_level_dim_hint <= 12)
+                hipLaunchKernelGGL(sensitivity_sweep_kernel<12>, dim3(a.batch), dim3(64), lds_sweep, s, a, d_obj_index, obj_all, tolW, tolC, scan_up ? 1 : 0);
+            else
+                hipLaunchKernelGGL(sensitivity_sweep_kernel<SWEEP_MD>, dim3(a.batch), dim3(64), lds_sweep, s, a, d_obj_index, obj_all, tolW, tolC, scan_up ? 1 : 0);
             return hipGetLastError();
         }
         if (lds_staged <= 40 * 1024 && a.batch <= 4u * (uint32_t)cus)
