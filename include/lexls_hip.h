@@ -178,9 +178,9 @@ int lexls_lse_device_ptr(lexls_lse_t h, int which, void **d_ptr);
 
 /* name of the kernel variant the last factorize/factorize_solve call dispatched to (diagnostics) */
 const char *lexls_lse_last_kernel(lexls_lse_t h);
-/* diagnostics (parity tests run every path): policy 0 = automatic dispatch (small shapes: the register-resident wave kernel while the batch
- * fits one round of it; beyond that the four-problems-per-wavefront kernel for x-only solves and the left-looking wave kernel when the
- * factor is kept; problems beyond one CU's LDS: the step-per-pivot path with the trailing update on the matrix cores — pivots / ranks
+/* diagnostics (parity tests run every path): policy 0 = automatic dispatch (small shapes: x-only solves without fixed variables take the
+ * four-problems-per-wavefront kernel at every batch size; with the factor kept the register-resident wave kernel while the batch fits one
+ * round of it, beyond that the four-per-wavefront kernel's factor-keeping form (the left-looking wave kernel where that does not fit); problems beyond one CU's LDS: the step-per-pivot path with the trailing update on the matrix cores — pivots / ranks
  * exact, values within 1e-10 of the ordered-chain arithmetic); 1 = only the generic one-workgroup-per-problem kernel; 2 = automatic, but
  * never the left-looking / four-per-wavefront kernels; 3 = the left-looking wave kernel whenever the shape allows it, whatever the batch
  * size; 4 = the four-problems-per-wavefront kernel whenever the shape allows it (x-only solves; else as 3); 5 = automatic, but large

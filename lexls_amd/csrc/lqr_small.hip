@@ -53,7 +53,7 @@ namespace lexls
         if (a.reg_type != 0) return true;
         if (left_looking > 0) return false;
         const bool lwave_pays = left_looking == 0 && a.batch > resident_wave_capacity();
-        return has_fixed || !lwave_pays;
+        return has_fixed || !lwave_pays; // (callers keep the factor: an x-only solve without fixed variables takes the four-per-wavefront kernel)
     }
 
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
@@ -77,8 +77,11 @@ namespace lexls
         const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
         // four problems per wavefront (lqr_quad_impl.h): x-only, no fixed variables; one wave per SIMD serves 4 x 4 x CUs problems per round.
         // left_looking == 2 forces it (parity tests), automatic dispatch takes it wherever the left-looking kernel would have been taken
+        // Measured on MI355X (scripts/crossover.py, n = 40, 5 x 12, us per batch, register-resident / four-per-wavefront): x only — 512: 58 / 53,
+        // 1024: 62 / 54, 2048: 78 / 58, 4096: 146 / 63: the four-per-wavefront kernel at every batch size; factor kept — 1024: 71 / 98,
+        // 2048: 89 / 103, 3072: 144 / 109, 4096: 166 / 115: the register-resident kernel while the batch fits one round of it.
         const bool quad_ok = !has_fixed;
-        if (quad_ok && (left_looking == 2 || (left_looking == 0 && lwave_pays)))
+        if (quad_ok && (left_looking == 2 || (left_looking == 0 && (lwave_pays || !write_factor))))
         {
             size_t lds = (max_level_dim <= 12) ? quad_lds_bytes(3, 12, a.nVar, a.nObj) : 0;
             if (lds && lds <= kMaxLdsBytes)

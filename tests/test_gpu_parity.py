@@ -669,7 +669,12 @@ def test_full_size_batch_4096(hip, oracle):
     small = hip.BatchedLexLSE(1024, n, dims)
     small.setProblem(lod[:1024])
     small.factorize_solve(keep_factor=False)
-    assert small.last_kernel() == "lqr_wave<41,12,exact>"  # latency-bound batch sizes: the register-resident kernel
+    assert small.last_kernel() == "lqr_quad<3,12,shift 7>"  # x only: four per wavefront at every batch size (scripts/crossover.py)
+    kept = hip.BatchedLexLSE(1024, n, dims)
+    kept.setProblem(lod[:1024])
+    kept.factorize_solve(keep_factor=True)
+    assert kept.last_kernel() == "lqr_wave<41,12,exact>"  # factor kept, one round of it: the register-resident kernel
+    np.testing.assert_array_equal(kept.get_x(), ref["x"][:1024])
     np.testing.assert_array_equal(small.get_x(), ref["x"][:1024])
 
 
