@@ -510,9 +510,75 @@ namespace lexls
                 for (uint32_t i = tid; i < rank; i += NT)
                 {
                     double s = W[F + i + n * ld];
-                    for (uint32_t j = 0; j < acc; j++) s = dfma(-W[F + i + (c0 + j) * ld], xs[c0 + j], s);
+                    uint32_t j = 0;
+                    if constexpr (NT >= 256) // (large levels: sixteen entries of the row requested together; the chain itself stays in order)
+                    {
+                        for (; j + 16 <= acc; j += 16)
+                        {
+                            double w16[16];
+#pragma unroll
+                            for (uint32_t u = 0; u < 16; u++) w16[u] = W[F + i + (c0 + j + u) * ld];
+#pragma unroll
+                            for (uint32_t u = 0; u < 16; u++) s = dfma(-w16[u], xs[c0 + j + u], s);
+                        }
+                    }
+                    for (; j < acc; j++) s = dfma(-W[F + i + (c0 + j) * ld], xs[c0 + j], s);
                     xs[Fc + i] = s;
                 }
+                if constexpr (NT >= 256)
+                {
+                    // Large levels: the triangular solve in blocks of 64 rows from the bottom.  ONE wavefront solves a diagonal block staged in
+                    // LDS (lane = row; x_j by v_readlane: no workgroup barrier per variable), then every thread applies the block's 64 columns
+                    // to a row above it.  Every x_i absorbs its columns in the same descending order as the unblocked loop: bit-identical.
+                    constexpr uint32_t BS = 64, BL = 65;
+                    double *Rb = xs + 2 * (size_t)n + 2; // BS x BL: the diagonal block, column-major, odd leading dimension
+                    for (uint32_t jb = ((rank - 1) / BS) * BS;; jb -= BS)
+                    {
+                        const uint32_t nb = rank - jb < BS ? rank - jb : BS;
+                        for (uint32_t e = tid; e < nb * nb; e += NT)
+                        {
+                            const uint32_t i = e % nb, j = e / nb;
+                            Rb[i + j * BL] = W[F + jb + i + (Fc + jb + j) * ld];
+                        }
+                        __syncthreads();
+                        if (tid < 64)
+                        {
+                            double sv   = tid < nb ? xs[Fc + jb + tid] : 0.0;
+                            double rcur = Rb[tid + (nb - 1) * BL], dcur = Rb[(nb - 1) + (nb - 1) * BL]; // (column and diagonal one step ahead of their use)
+                            for (uint32_t j = nb; j--;)
+                            {
+                                const uint32_t jn  = j ? j - 1 : 0;
+                                const double rnext = Rb[tid + jn * BL], dnext = Rb[jn + jn * BL];
+                                const double xj    = rdlane(sv, (int)j) / dcur;
+                                if (tid == j) sv = xj;
+                                if (tid < j) sv = dfma(-rcur, xj, sv);
+                                rcur = rnext;
+                                dcur = dnext;
+                            }
+                            if (tid < nb) xs[Fc + jb + tid] = sv;
+                        }
+                        __syncthreads();
+                        for (uint32_t i = tid; i < jb; i += NT) // rows above the block: its columns, last first
+                        {
+                            double sv = xs[Fc + i];
+                            uint32_t j = nb;
+                            for (; j >= 8; j -= 8)
+                            {
+                                double w8[8];
+#pragma unroll
+                                for (uint32_t u = 0; u < 8; u++) w8[u] = W[F + i + (Fc + jb + j - 1 - u) * ld];
+#pragma unroll
+                                for (uint32_t u = 0; u < 8; u++) sv = dfma(-w8[u], xs[Fc + jb + j - 1 - u], sv);
+                            }
+                            for (; j--;) sv = dfma(-W[F + i + (Fc + jb + j) * ld], xs[Fc + jb + j], sv);
+                            xs[Fc + i] = sv;
+                        }
+                        __syncthreads();
+                        if (jb == 0) break;
+                    }
+                }
+                else
+                {
                 // the diagonal of R_k once into LDS; the column of the NEXT step is requested before the current step's division, so that a
                 // step costs one division + one barrier instead of two dependent trips to the stored factor (same operations, same order)
                 double *dgl = xs + n;
@@ -533,6 +599,7 @@ namespace lexls
                 }
                 if (tid == 0) xs[Fc] = xprev;
                 __syncthreads();
+                }
                 acc += rank;
             }
             if (tid == 0)
@@ -1265,7 +1332,7 @@ namespace lexls
 
     hipError_t launch_solve_generic(const LseArgs &a, hipStream_t s)
     {
-        const size_t lds = 16 * (size_t)a.nVar + 16; // x by position + the diagonal of the level being solved
+        const size_t lds = 16 * (size_t)a.nVar + 16 + (a.nVar + 1 <= 64 ? 0 : 8 * 64 * 65); // x by position + the diagonal of the level being solved (+ the 64 x 64 block of the blocked form)
         if (a.nVar + 1 <= 64)
         {
             hipError_t e = set_lds(solve_generic_kernel<64>, lds);
