@@ -40,7 +40,11 @@ namespace lexls
         /// SIG: position P sits in slot (P + SIG) / 16, lane (P + SIG) % 16.  With SIG = 16 NS - (n + 1) the right-hand side is the last lane of
         /// the last slot, so the live columns of a level fill the UPPER slots completely and the lower ones drop out of the Householder
         /// loop as early as possible (n = 40: 3, 2, 2, 1 live slots instead of 3, 3, 2, 1); SIG = 0 serves every n <= 16 NS - 1
-        template <int NS, int MD, bool WF, int SIG>
+        /// FIX: fixed variables (lexlse.h:132-156) — own instantiations, so that the common path does not carry them.  The fixed columns take
+        /// the first positions by the reference's chained swap rule (an edit of the position -> physical-column map before the first level
+        /// is loaded), every level block moves their contribution to its right-hand side when it is loaded (ordered chain over the fixed
+        /// positions, row-broadcast operands), and from then on a fixed position behaves like a pivot with a zero reciprocal diagonal.
+        template <int NS, int MD, bool WF, int SIG, bool FIX = false>
         __global__ __launch_bounds__(64) void lqr_quad_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes)
         {
             static_assert(NS >= 1 && NS <= 4 && MD <= 16 && (MD % 2) == 0, "shape limits of the row layout");
@@ -123,6 +127,36 @@ namespace lexls
             int F         = 0;
             int imgoff    = 0; // doubles
             bool exh      = false;
+            int nfix      = 0;
+            if constexpr (FIX)
+            {
+                nfix = (live && a.nfixed) ? (int)a.nfixed[bb] : 0;
+                for (int k = gl; k < nfix; k += 16)
+                {
+                    B8(o_perm + k)    = (uint8_t)a.fixed_idx[(size_t)bb * n + k]; // working copy of fixed_var_index; ends as column_permutations
+                    D(o_xs + 8 * k)   = a.fixed_val[(size_t)bb * n + k];          // x.head(nVarFixed) = fixed values (lexlse.h:1384), by position
+                }
+                quad_lds_fence();
+                if (gl == 0)
+                    for (int kf = 0; kf < nfix; kf++)
+                    {
+                        const int coeff = (int)B8(o_perm + kf);
+                        for (int j = kf + 1; j < nfix; j++) // the first later entry that refers to position kf now refers to coeff (lexlse.h:146-153)
+                            if ((int)B8(o_perm + j) == kf)
+                            {
+                                B8(o_perm + j) = (uint8_t)coeff;
+                                break;
+                            }
+                        const uint8_t t0    = B8(o_phys + kf); // swap the columns at positions kf and coeff (lexlse.h:141-144)
+                        B8(o_phys + kf)     = B8(o_phys + coeff);
+                        B8(o_phys + coeff)  = t0;
+                    }
+                quad_lds_fence();
+                ColIndex  = nfix;
+                TotalRank = nfix;
+                exh       = nfix >= n; // lexlse.h:164-175: nothing left to factorise
+            }
+            const bool all_fixed = FIX && nfix >= n;
             STAMP_DECL
             STAMP(0)
 
@@ -194,6 +228,35 @@ namespace lexls
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     STAMP(8)
 #endif
+                    if constexpr (FIX)
+                    {
+                        // RHS -= sum_k LOD(:, position k) * x_k over the fixed positions, k ascending (lexlse.h:155); a row of the wavefront with
+                        // fewer fixed variables meets zeros in its x block
+                        const int nfmax = rows_max(work ? nfix : 0);
+                        if (nfmax > 0)
+                        {
+                            double shift[MD];
+#pragma unroll
+                            for (int r = 0; r < MD; r++) shift[r] = 0.0;
+                            for_each_index<0, 16 * NS - SIG - 1>([&](auto kk) __attribute__((always_inline)) {
+                                constexpr int K  = decltype(kk)::value;
+                                constexpr int sk = (K + SIG) / 16, lk = (K + SIG) % 16;
+                                if (K < nfmax) // wave-uniform
+                                {
+                                    const double xk = D(o_xs + 8 * K);
+#pragma unroll
+                                    for (int r = 0; r < MD; r++) shift[r] = dfma(gbc<lk>(blk[sk][r]), xk, shift[r]);
+                                }
+                            });
+#pragma unroll
+                            for (int s = 0; s < NS; s++)
+                            {
+                                const bool isr = (16 * s + gl - SIG) == n;
+#pragma unroll
+                                for (int r = 0; r < MD; r++) blk[s][r] = sel(isr, blk[s][r] - shift[r], blk[s][r]);
+                            }
+                        }
+                    }
                     // =====================================================================================
                     // Gauss elimination of these rows by every finished pivot c' (lexlse.h:431-471, left-looking)
                     // =====================================================================================
@@ -280,16 +343,17 @@ namespace lexls
                             if (work && P0 >= 0 && P0 < Fc)
                             {
                                 double *dst = out + F + (size_t)P0 * cap;
+                                const double sc = (FIX && P0 < nfix) ? 1.0 : idgreg[s]; // (a fixed variable's column stays what it is: lexlse.h keeps it in place)
                                 if (wf_aligned)
                                 {
 #pragma unroll
-                                    for (int r = 0; r < MD; r += 2) *reinterpret_cast<double2 *>(dst + r) = make_double2(blk[s][r] * idgreg[s], blk[s][r + 1] * idgreg[s]);
+                                    for (int r = 0; r < MD; r += 2) *reinterpret_cast<double2 *>(dst + r) = make_double2(blk[s][r] * sc, blk[s][r + 1] * sc);
                                 }
                                 else
                                 {
 #pragma unroll
                                     for (int r = 0; r < MD; r++)
-                                        if (r < dim) dst[r] = blk[s][r] * idgreg[s];
+                                        if (r < dim) dst[r] = blk[s][r] * sc;
                                 }
                             }
                         }
@@ -549,7 +613,7 @@ namespace lexls
                 STAMP(6)
                 if (gl == 0)
                 {
-                    U32(o_meta + 16 * k)      = (uint32_t)Fc;
+                    U32(o_meta + 16 * k)      = all_fixed ? 0u : (uint32_t)Fc; // (the reference leaves first_col_index at 0 when it returns early)
                     U32(o_meta + 16 * k + 4)  = (uint32_t)rank;
                     U32(o_meta + 16 * k + 8)  = (uint32_t)imgoff;
                     U32(o_meta + 16 * k + 12) = (uint32_t)(n + 1 - Fc);
@@ -562,7 +626,8 @@ namespace lexls
 
             // ---- solve(): block back-substitution on the images (lexlse.h:1015-1045); lane p <-> row p of a level ----
 #pragma unroll
-            for (int s = 0; s < NS; s++) D(o_xs + 8 * (16 * s + gl)) = 0.0; // (by LDS slot, not by position: all 16 NS entries)
+            for (int s = 0; s < NS; s++)
+                if (!(FIX && 16 * s + gl < nfix)) D(o_xs + 8 * (16 * s + gl)) = 0.0; // (by LDS slot, not by position: all 16 NS entries; fixed values stay)
             quad_lds_fence();
             for (int k = nObj; k--;)
             {
@@ -708,7 +773,7 @@ namespace lexls
             return (8 * ((size_t)quad_image_doubles(n, nObj, md) + 16 * NS + 18) + 64 + 64 + 16 * kQuadMaxObj + 512 + 4 * kQuadMaxObj + 15) & ~(size_t)15;
         }
 
-        template <int NS, int MD, bool WF, int SIG>
+        template <int NS, int MD, bool WF, int SIG, bool FIX = false>
         hipError_t launch_quad_t(const LseArgs &a, hipStream_t s)
         {
             const uint32_t img = quad_image_doubles(a.nVar, a.nObj, MD);
@@ -717,11 +782,11 @@ namespace lexls
             if (lds > kMaxLdsBytes || a.nObj > (uint32_t)kQuadMaxObj || a.nVar + 1 + SIG > 16u * NS || a.nVar > 63u) return hipErrorInvalidValue;
             if (lds > 64 * 1024)
             {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_quad_kernel<NS, MD, WF, SIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_quad_kernel<NS, MD, WF, SIG, FIX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
             }
             const uint32_t blocks = (a.batch + 3u) / 4u;
-            hipLaunchKernelGGL((lqr_quad_kernel<NS, MD, WF, SIG>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes);
+            hipLaunchKernelGGL((lqr_quad_kernel<NS, MD, WF, SIG, FIX>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes);
             return hipGetLastError();
         }
     } // namespace
@@ -730,3 +795,5 @@ namespace lexls
 // One translation unit per instantiation (parallel builds): LEXLS_QUAD_INSTANCE(name, NS, MD, WF)
 #define LEXLS_QUAD_INSTANCE(NAME, NS, MD, WF, SIG) \
     namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_quad_t<NS, MD, WF, SIG>(a, s); } }
+#define LEXLS_QUAD_INSTANCE_FIX(NAME, NS, MD, WF, SIG) \
+    namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_quad_t<NS, MD, WF, SIG, true>(a, s); } }

@@ -24,6 +24,11 @@ namespace lexls
     hipError_t launch_quad_3x12s7_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12_f(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12s7_f(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_3x12_xF(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_3x12s7_xF(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_4x16_xF(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_3x12_fF(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_3x12s7_fF(const LseArgs &a, hipStream_t s);
     size_t quad_lds_bytes(uint32_t slots, uint32_t md, uint32_t nVar, uint32_t nObj);
 
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed)
@@ -45,15 +50,31 @@ namespace lexls
         return cap;
     }
 
-    /// true when launch_lqr_wave (same arguments) takes the register-resident lqr_wave_kernel — the one whose load can gather the rows by
-    /// reference (LseArgs::g_cdata); the left-looking and four-per-wave kernels read an assembled problem
+    /// which four-per-wavefront instantiation (0: none) automatic dispatch / the policies take for these arguments
+    static int quad_choice(const LseArgs &a, uint32_t max_level_dim, bool write_factor, int left_looking)
+    {
+        if (a.reg_type != 0) return 0;
+        // Measured on MI355X (scripts/crossover.py, n = 40, 5 x 12, us per batch, register-resident / four-per-wavefront): x only — 512: 58 / 53,
+        // 1024: 62 / 54, 2048: 78 / 58, 4096: 146 / 63: the four-per-wavefront kernel at every batch size; factor kept — 1024: 71 / 98,
+        // 2048: 89 / 103, 3072: 144 / 109, 4096: 166 / 115: the register-resident kernel while the batch fits one round of it.
+        const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
+        if (!(left_looking == 2 || (left_looking == 0 && (lwave_pays || !write_factor)))) return 0;
+        size_t lds = (max_level_dim <= 12) ? quad_lds_bytes(3, 12, a.nVar, a.nObj) : 0;
+        if (lds && lds <= kMaxLdsBytes) return a.nVar == 40 ? 2 : 1; // 2: the IK shape, columns right-aligned in the slots (see SIG in lqr_quad_impl.h)
+        lds = (max_level_dim <= 16 && !write_factor) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0; // n + 1 <= 64, level dims <= 16 (x-only)
+        if (lds && lds <= kMaxLdsBytes) return 3;
+        return 0;
+    }
+
+    /// true when launch_lqr_wave (same arguments, factor kept) takes the register-resident lqr_wave_kernel — the one whose load can gather
+    /// the rows by reference (LseArgs::g_cdata); the left-looking and four-per-wavefront kernels read an assembled problem
     bool wave_dispatch_is_register_resident(const LseArgs &a, uint32_t max_level_dim, bool has_fixed, int left_looking)
     {
-        (void)max_level_dim;
         if (a.reg_type != 0) return true;
-        if (left_looking > 0) return false;
-        const bool lwave_pays = left_looking == 0 && a.batch > resident_wave_capacity();
-        return has_fixed || !lwave_pays; // (callers keep the factor: an x-only solve without fixed variables takes the four-per-wavefront kernel)
+        if (quad_choice(a, max_level_dim, true, left_looking) != 0) return false;
+        const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
+        const uint32_t nc     = a.nVar + 1;
+        return !(lwave_pays && !has_fixed && max_level_dim <= 12 && nc <= 41 && a.nObj <= 8);
     }
 
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
@@ -75,31 +96,23 @@ namespace lexls
         // that kernel has the shorter latency (factor kept: 66-72 us vs 97-101 us; x only: equal); beyond that the left-looking kernel
         // still runs in one round (4096: 115 us vs 158 us).  left_looking: 0 = decide by batch size, > 0 = always, < 0 = never
         const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
-        // four problems per wavefront (lqr_quad_impl.h): x-only, no fixed variables; one wave per SIMD serves 4 x 4 x CUs problems per round.
-        // left_looking == 2 forces it (parity tests), automatic dispatch takes it wherever the left-looking kernel would have been taken
-        // Measured on MI355X (scripts/crossover.py, n = 40, 5 x 12, us per batch, register-resident / four-per-wavefront): x only — 512: 58 / 53,
-        // 1024: 62 / 54, 2048: 78 / 58, 4096: 146 / 63: the four-per-wavefront kernel at every batch size; factor kept — 1024: 71 / 98,
-        // 2048: 89 / 103, 3072: 144 / 109, 4096: 166 / 115: the register-resident kernel while the batch fits one round of it.
-        const bool quad_ok = !has_fixed;
-        if (quad_ok && (left_looking == 2 || (left_looking == 0 && (lwave_pays || !write_factor))))
+        // four problems per wavefront (lqr_quad_impl.h): one wave per SIMD serves 4 x 4 x CUs problems per round; fixed variables in the FIX
+        // instantiations.  left_looking == 2 forces it (parity tests)
+        switch (quad_choice(a, max_level_dim, write_factor, left_looking))
         {
-            size_t lds = (max_level_dim <= 12) ? quad_lds_bytes(3, 12, a.nVar, a.nObj) : 0;
-            if (lds && lds <= kMaxLdsBytes)
-            {
-                if (a.nVar == 40) // the IK shape: columns right-aligned in the slots (see SIG in lqr_quad_impl.h)
-                {
-                    *variant = write_factor ? "lqr_quad<3,12,shift 7,factor>" : "lqr_quad<3,12,shift 7>";
-                    return write_factor ? launch_quad_3x12s7_f(a, s) : launch_quad_3x12s7_x(a, s);
-                }
-                *variant = write_factor ? "lqr_quad<3,12,factor>" : "lqr_quad<3,12>";
-                return write_factor ? launch_quad_3x12_f(a, s) : launch_quad_3x12_x(a, s);
-            }
-            lds = (max_level_dim <= 16 && !write_factor) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0; // n + 1 <= 64, level dims <= 16 (x-only)
-            if (lds && lds <= kMaxLdsBytes)
-            {
-                *variant = "lqr_quad<4,16>";
-                return launch_quad_4x16_x(a, s);
-            }
+        case 2:
+            *variant = has_fixed ? (write_factor ? "lqr_quad<3,12,shift 7,factor,fixed>" : "lqr_quad<3,12,shift 7,fixed>")
+                                 : (write_factor ? "lqr_quad<3,12,shift 7,factor>" : "lqr_quad<3,12,shift 7>");
+            if (has_fixed) return write_factor ? launch_quad_3x12s7_fF(a, s) : launch_quad_3x12s7_xF(a, s);
+            return write_factor ? launch_quad_3x12s7_f(a, s) : launch_quad_3x12s7_x(a, s);
+        case 1:
+            *variant = has_fixed ? (write_factor ? "lqr_quad<3,12,factor,fixed>" : "lqr_quad<3,12,fixed>") : (write_factor ? "lqr_quad<3,12,factor>" : "lqr_quad<3,12>");
+            if (has_fixed) return write_factor ? launch_quad_3x12_fF(a, s) : launch_quad_3x12_xF(a, s);
+            return write_factor ? launch_quad_3x12_f(a, s) : launch_quad_3x12_x(a, s);
+        case 3:
+            *variant = has_fixed ? "lqr_quad<4,16,fixed>" : "lqr_quad<4,16>";
+            return has_fixed ? launch_quad_4x16_xF(a, s) : launch_quad_4x16_x(a, s);
+        default: break;
         }
         if (lwave_pays && !has_fixed && max_level_dim <= 12 && nc <= 41 && a.nObj <= 8)
         {

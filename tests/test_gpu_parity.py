@@ -271,7 +271,37 @@ def test_fixed_variables(hip, oracle, force_generic):
     s, ref = run_both(hip, oracle, lod, dims, n, force_generic=force_generic, nfixed=nfixed, fixed_idx=idx, fixed_val=val, fixed_type=typ)
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
-    assert s.last_kernel().startswith("lqr_generic" if force_generic == 1 else "lqr_wave")
+    assert s.last_kernel().startswith({1: "lqr_generic", 4: "lqr_quad<3,12,factor,fixed>"}.get(force_generic, "lqr_wave"))
+    if force_generic in (0, 4):  # x only: automatic dispatch and policy 4 take the four-per-wavefront kernel's fixed-variable form
+        s.factorize_solve(keep_factor=False)
+        assert s.last_kernel() == "lqr_quad<3,12,fixed>"
+        np.testing.assert_array_equal(s.get_x(), ref["x"])
+        np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+        np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
+
+
+@pytest.mark.parametrize("keep", [False, True], ids=["x-only", "factor"])
+def test_quad_kernel_fixed_variables_ik_shape(hip, oracle, keep):
+    """the four-per-wavefront kernel with fixed variables (FIX instantiations) on the IK shape (right-aligned layout), ragged numbers of fixed
+    variables inside a wavefront (0 .. 9 and all 40), chained indices, rank-deficient problems: bit-identical to the oracle"""
+    n, dims, batch = 40, [12] * 5, 23
+    lod = np.concatenate([P.lse_batch(3300, batch - 6, n, dims), np.stack([P.rank_deficient_problem(3400 + b, n, dims, [7, 12, 3, 9, 2]) for b in range(6)])])
+    nfixed = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 40, 3, 1, 2, 12, 5, 0, 4, 6, 2, 3, 1, 7], np.uint32)
+    idx = np.zeros((batch, n), np.uint32)
+    val = np.zeros((batch, n))
+    for b in range(batch):
+        perm = np.argsort(P.uniform(3500 + b, n))
+        idx[b, :nfixed[b]] = perm[:nfixed[b]]
+        val[b, :nfixed[b]] = P.normal(3600 + b, n)[:nfixed[b]]
+    idx[11, :3] = [5, 0, 1]  # chained: position 0 is taken by the first swap
+    s, ref = run_both(hip, oracle, lod, dims, n, keep_factor=keep, force_generic=4, nfixed=nfixed, fixed_idx=idx, fixed_val=val)
+    assert s.last_kernel() == ("lqr_quad<3,12,shift 7,factor,fixed>" if keep else "lqr_quad<3,12,shift 7,fixed>")
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
+    np.testing.assert_array_equal(s.getRanks()[1], ref["fcol"])
+    if keep:
+        assert_factor_equal(s, ref, dims, n)
 
 
 def test_fixed_variables_chained_indices(hip, oracle):
