@@ -324,14 +324,19 @@ namespace lexls
                             }
                         });
                     };
-                    // x only: ONE form for all rows of the wavefront.  A row whose own pivots end before Fcmax runs the remaining pivot steps
-                    // with a zero reciprocal diagonal (idgreg of a position that is not a pivot yet) and the zeros of the x block as "U":
-                    // zero multipliers, every fma adds a zero product.  (The per-row guarded form is only kept where the multipliers are
-                    // stored; next to this one it cost 1.5 % through code size and registers.)
-                    if (!WF || elim_uniform)
+                    // ONE form for all rows of the wavefront.  A row whose own pivots end before Fcmax runs the remaining pivot steps with a zero
+                    // reciprocal diagonal (idgreg of a position that is not a pivot yet) and the zeros of the x block as "U": zero
+                    // multipliers, every fma adds a zero product.  (A per-row guarded form next to this one cost 1.5 % of the x-only kernel
+                    // through code size and registers; the factor-keeping kernel stores the multipliers of the row's OWN pivots below.)
+#ifdef LEXLS_QUAD_MASKED_ELIMINATION
+                    if (elim_uniform)
                         eliminate(std::false_type{});
-                    else if constexpr (WF)
+                    else
                         eliminate(std::true_type{});
+#else
+                    (void)elim_uniform;
+                    eliminate(std::false_type{});
+#endif
                     if constexpr (WF)
                     {
                         // the multipliers L = A R^-1 of these rows (lexlse.h:441-446): column c' of the factor, final.  A pivot position's lane
