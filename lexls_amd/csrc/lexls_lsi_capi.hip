@@ -1119,7 +1119,14 @@ namespace
 
     private:
         double spin_seconds = 300e-6;
-        static void relax() { __builtin_ia32_pause(); }
+        static void relax()
+        {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
+        }
         static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
         void work()
         {
