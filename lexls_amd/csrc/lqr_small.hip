@@ -24,6 +24,10 @@ namespace lexls
     hipError_t launch_quad_3x12s7_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12_f(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12s7_f(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_2x12_x(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_1x12_x(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_2x12_f(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_1x12_f(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12_xF(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12s7_xF(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_4x16_xF(const LseArgs &a, hipStream_t s);
@@ -51,7 +55,7 @@ namespace lexls
     }
 
     /// which four-per-wavefront instantiation (0: none) automatic dispatch / the policies take for these arguments
-    static int quad_choice(const LseArgs &a, uint32_t max_level_dim, bool write_factor, int left_looking)
+    static int quad_choice(const LseArgs &a, uint32_t max_level_dim, bool write_factor, int left_looking, bool has_fixed)
     {
         if (a.reg_type != 0) return 0;
         // Measured on MI355X (scripts/crossover.py, n = 40, 5 x 12, us per batch, register-resident / four-per-wavefront): x only — 512: 58 / 53,
@@ -60,7 +64,12 @@ namespace lexls
         const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
         if (!(left_looking == 2 || (left_looking == 0 && (lwave_pays || !write_factor)))) return 0;
         size_t lds = (max_level_dim <= 12) ? quad_lds_bytes(3, 12, a.nVar, a.nObj) : 0;
-        if (lds && lds <= kMaxLdsBytes) return a.nVar == 40 ? 2 : 1; // 2: the IK shape, columns right-aligned in the slots (see SIG in lqr_quad_impl.h)
+        if (lds && lds <= kMaxLdsBytes)
+        {
+            if (!has_fixed && a.nVar + 1 <= 16) return 5; // one slot
+            if (!has_fixed && a.nVar + 1 <= 32) return 4; // two slots
+            return a.nVar == 40 ? 2 : 1; // 2: the IK shape, columns right-aligned in the slots (see SIG in lqr_quad_impl.h)
+        }
         lds = (max_level_dim <= 16 && !write_factor) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0; // n + 1 <= 64, level dims <= 16 (x-only)
         if (lds && lds <= kMaxLdsBytes) return 3;
         return 0;
@@ -71,7 +80,7 @@ namespace lexls
     bool wave_dispatch_is_register_resident(const LseArgs &a, uint32_t max_level_dim, bool has_fixed, int left_looking)
     {
         if (a.reg_type != 0) return true;
-        if (quad_choice(a, max_level_dim, true, left_looking) != 0) return false;
+        if (quad_choice(a, max_level_dim, true, left_looking, has_fixed) != 0) return false;
         const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
         const uint32_t nc     = a.nVar + 1;
         return !(lwave_pays && !has_fixed && max_level_dim <= 12 && nc <= 41 && a.nObj <= 8);
@@ -98,8 +107,14 @@ namespace lexls
         const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
         // four problems per wavefront (lqr_quad_impl.h): one wave per SIMD serves 4 x 4 x CUs problems per round; fixed variables in the FIX
         // instantiations.  left_looking == 2 forces it (parity tests)
-        switch (quad_choice(a, max_level_dim, write_factor, left_looking))
+        switch (quad_choice(a, max_level_dim, write_factor, left_looking, has_fixed))
         {
+        case 5:
+            *variant = write_factor ? "lqr_quad<1,12,factor>" : "lqr_quad<1,12>";
+            return write_factor ? launch_quad_1x12_f(a, s) : launch_quad_1x12_x(a, s);
+        case 4:
+            *variant = write_factor ? "lqr_quad<2,12,factor>" : "lqr_quad<2,12>";
+            return write_factor ? launch_quad_2x12_f(a, s) : launch_quad_2x12_x(a, s);
         case 2:
             *variant = has_fixed ? (write_factor ? "lqr_quad<3,12,shift 7,factor,fixed>" : "lqr_quad<3,12,shift 7,fixed>")
                                  : (write_factor ? "lqr_quad<3,12,shift 7,factor>" : "lqr_quad<3,12,shift 7>");

@@ -150,10 +150,16 @@ def test_wave_kernel_shapes(hip, oracle, n, dims, policy):
     np.testing.assert_array_equal(s.get_x(), ref["x"])
 
 
+def _quad_name(n, factor=False):
+    """the four-per-wavefront instantiation level dims <= 12 dispatch to: one / two / three slots of sixteen columns (n = 40: right-aligned)"""
+    slots = 1 if n + 1 <= 16 else (2 if n + 1 <= 32 else 3)
+    return f"lqr_quad<{slots},12{',shift 7' if n == 40 else ''}{',factor' if factor else ''}>"
+
+
 def _quad_x_only(hip, oracle, lod, dims, n, maxdim=None, kernel="lqr_quad<3,12>"):
     """x-only solve on the four-problems-per-wavefront kernel: x, ranks, first columns and pivots bit for bit against the oracle"""
     s, ref = run_both(hip, oracle, lod, dims, n, maxdim=maxdim, keep_factor=False, force_generic=4)
-    assert s.last_kernel() == ("lqr_quad<3,12,shift 7>" if (n == 40 and kernel == "lqr_quad<3,12>") else kernel)
+    assert s.last_kernel() == (_quad_name(n) if kernel == "lqr_quad<3,12>" else kernel)
     r, fc, tr = s.getRanks()
     np.testing.assert_array_equal(r, ref["rank"])
     np.testing.assert_array_equal(fc, ref["fcol"])
@@ -183,7 +189,7 @@ def test_quad_kernel_factor_output(hip, oracle, n, dims):
     """the factor-keeping instantiation: get_lexqr layout (multipliers, R / T blocks, essential parts, eliminated rows of the levels after the
     columns ran out), Householder scalars, pivots and x bit for bit"""
     s, ref = run_both(hip, oracle, P.lse_batch(4000 + n, 11, n, dims), dims, n, keep_factor=True, force_generic=4)
-    assert s.last_kernel() == ("lqr_quad<3,12,shift 7,factor>" if n == 40 else "lqr_quad<3,12,factor>")
+    assert s.last_kernel() == _quad_name(n, factor=True)
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
     np.testing.assert_array_equal(s.get_v(), ref["v"])  # the residual kernel reads the stored factor
@@ -195,7 +201,7 @@ def test_quad_kernel_factor_output_rank_deficient_and_ragged(hip, oracle):
     n, dims = 15, [5, 5, 5, 5]
     lod = np.stack([P.rank_deficient_problem(500 + b, n, dims, [3, 3, 3, 3] if b % 2 else [5, 2, 4, 1]) for b in range(14)])
     s, ref = run_both(hip, oracle, lod, dims, n, keep_factor=True, force_generic=4)
-    assert s.last_kernel() == "lqr_quad<3,12,factor>"
+    assert s.last_kernel() == _quad_name(n, factor=True)
     assert_factor_equal(s, ref, dims, n)
     np.testing.assert_array_equal(s.get_x(), ref["x"])
     n3, cap3 = 20, [8, 8, 8]
