@@ -1321,7 +1321,6 @@ struct lexls_lsi_batch_s
             ctx.reg_cg_iters = par.max_number_of_CG_iterations;
             ctx.reg_dirty.store(ctx.reg_type != 0);
             if (ctx.reg_type == 0) hip_check(lexls_lse_set_regularization(ctx.h, 0, NULL, 0, 0.0));
-            if (run_gather) hip_check(lexls_lse_set_constraint_data(ctx.h, h_data + (size_t)lo[g] * per_data, per_data));
             if (run_gather && ctx.device_step)
             {
                 ctx.shape.tol_feasibility = par.tol_feasibility;
@@ -1334,6 +1333,27 @@ struct lexls_lsi_batch_s
                 }
             }
         }
+        // the constraint data goes to the device (16 MB for 1024 IK instances: ~0.4 ms) while the worker pool builds the instances' host
+        // objects and runs their phase 1: nothing of that touches the handles; joined before the first stage
+        int upload_rc = LEXLS_OK;
+        std::string upload_err;
+        std::thread uploader;
+        if (run_gather)
+            uploader = std::thread([&]() {
+                for (uint32_t g = 0; g < nGroups && upload_rc == LEXLS_OK; g++)
+                {
+                    upload_rc = lexls_lse_set_constraint_data(grp[g]->h, h_data + (size_t)lo[g] * per_data, per_data);
+                    if (upload_rc != LEXLS_OK) upload_err = lexls_last_error();
+                }
+            });
+        struct Joiner // (the setup below may throw)
+        {
+            std::thread &t;
+            ~Joiner()
+            {
+                if (t.joinable()) t.join();
+            }
+        } joiner{uploader};
         // whole iterations on the device: plain runs only (cycling handling edits the host's bounds; a regularized equality problem has
         // per-run factors the host posts)
         const bool run_resident = run_gather && resident_ok && grp[0]->resident && par.regularization_type == REGULARIZATION_NONE &&
@@ -1380,6 +1400,8 @@ struct lexls_lsi_batch_s
             }
             lsi[b]->begin();
         });
+        if (uploader.joinable()) uploader.join();
+        if (upload_rc != LEXLS_OK) throw Exception(std::string("liblexls_hip: ") + upload_err);
         const double t_setup = BatchCtx::now() - t_begin;
         double t_host        = 0.0;
 
@@ -1480,11 +1502,19 @@ struct lexls_lsi_batch_s
             // stages are enqueued in chunks; after each chunk ONE word comes back (instances that have stopped).  Stages past an
             // instance's end skip it in every kernel; a chunk that turns out not to be needed costs a few launches of early-exit kernels
             const int chunk = 8;
+            bool freed = false;
             while (more)
             {
                 more = false;
                 for (uint32_t g = 0; g < nGroups; g++)
                     if (going[g]) grp[g]->enqueue_resident(chunk, par.tol_wrong_sign_lambda, par.tol_correct_sign_lambda, static_cast<int32_t>(par.max_number_of_factorizations));
+                if (!freed) // the handed-over instances' host objects (a thousand LexLSI instances, dozens of vectors each) are not needed any
+                {           // more: they are freed now, while the GPU works on the first chunk, instead of on the caller's time at the end
+                    freed = true;
+                    pool.run(batch, [&](uint32_t b) {
+                        if (grp[group_of[b]]->is_resident[b - lo[group_of[b]]]) lsi[b].reset();
+                    });
+                }
                 for (uint32_t g = 0; g < nGroups; g++)
                     if (going[g])
                     {
@@ -1504,23 +1534,24 @@ struct lexls_lsi_batch_s
                     throw Exception("download of the final state failed");
             }
         pool.run(batch, [&](uint32_t b) {
-            runner::LsiInfo info;
-            runner::collect(*lsi[b], prob[b], h_x + (size_t)b * nVar, &info, h_active ? h_active + (size_t)b * total : NULL,
-                            h_v ? h_v + (size_t)b * total : NULL);
-            if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
             if (run_resident)
             {
                 BatchCtx &ctx    = *grp[group_of[b]];
                 const uint32_t k = b - lo[group_of[b]];
-                if (ctx.is_resident[k]) // x, v, working set and counters as the device left them
+                if (ctx.is_resident[k]) // x, v, working set and counters as the device left them (its host object is gone already)
                 {
                     const double *st = ctx.rstate_host.data() + (size_t)k * ctx.rshape.SD;
                     std::copy(st, st + nVar, h_x + (size_t)b * nVar);
                     if (h_v) std::copy(st + nVar, st + nVar + total, h_v + (size_t)b * total);
                     if (h_active) std::copy(ctx.r_ctr_state(k), ctx.r_ctr_state(k) + total, h_active + (size_t)b * total);
                     if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, ctx.r_info_of(k), 6 * sizeof(int32_t));
+                    return;
                 }
             }
+            runner::LsiInfo info;
+            runner::collect(*lsi[b], prob[b], h_x + (size_t)b * nVar, &info, h_active ? h_active + (size_t)b * total : NULL,
+                            h_v ? h_v + (size_t)b * total : NULL);
+            if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
             if (run_step)
             {
                 BatchCtx &ctx    = *grp[group_of[b]];
