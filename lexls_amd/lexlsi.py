@@ -20,6 +20,46 @@ REG_PARAM_DEFAULTS = [0, 0.0, 10]
 INFO_KEYS = ["status", "iterations", "activations", "deactivations", "factorizations", "total_rank"]
 
 
+class InfoRows(list):
+    """the per-instance info records of a batch run: behaves like a list of dicts (status, iterations, ...), built from the (batch, 6)
+    int32 array the library fills — lazily, on first access: a thousand small dicts are a third of a millisecond nobody has to pay who only
+    looks at the solutions"""
+
+    def __init__(self, array):
+        super().__init__()
+        self.array = array  # (batch, 6) int32, columns = INFO_KEYS
+        self._built = False
+
+    def _build(self):
+        if not self._built:
+            self._built = True
+            super().extend(dict(zip(INFO_KEYS, row)) for row in self.array.tolist())
+
+    def __len__(self):
+        return self.array.shape[0]
+
+    def __getitem__(self, i):
+        self._build()
+        return super().__getitem__(i)
+
+    def __iter__(self):
+        self._build()
+        return super().__iter__()
+
+    def __eq__(self, other):
+        self._build()
+        if isinstance(other, InfoRows):
+            other._build()
+        return list.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __repr__(self):
+        self._build()
+        return list.__repr__(self)
+
+
 def pack_params(**kw) -> np.ndarray:
     vals = list(PARAM_DEFAULTS)
     for k, v in kw.items():
@@ -184,7 +224,7 @@ class LsiBatch:
             self._h, _p(pk.data, C.c_double), _p(pk.var_index, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(v0a, C.c_double), _p(rfa, C.c_double),
             _p(par, C.c_double), C.c_uint32(len(par)), _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8), _p(v, C.c_double),
             _p(rounds, C.c_int32)))
-        return dict(x=x, info=[dict(zip(INFO_KEYS, row)) for row in info.tolist()], active=active, v=v,
+        return dict(x=x, info=InfoRows(info), active=active, v=v,
                     rounds=dict(factorize_solve=int(rounds[0]), sensitivity=int(rounds[1])), dims=self.dims)
 
 
