@@ -649,7 +649,7 @@ namespace lexls
         template <int NT>
         __device__ __forceinline__ void stage_factor(const double *__restrict__ G, double *L, uint32_t cap, uint32_t ncol, uint32_t ldl, uint32_t tid)
         {
-            constexpr uint32_t U = 8; // loads in flight per thread
+            constexpr uint32_t U = NT <= 64 ? 20 : 8; // loads in flight per thread (one wavefront staging for itself: the rounds are latency, not bandwidth)
             const uint32_t total = cap * ncol;
             for (uint32_t base = tid; base < total; base += NT * U)
             {
@@ -1410,6 +1410,12 @@ namespace lexls
         __global__ __launch_bounds__(64) void sensitivity_sweep_kernel(LseArgs a, const int32_t *obj_index, int32_t obj_all, double tolW, double tolC, int scan_up)
         {
             static_assert(MD <= SWEEP_MD, "row layout: one level row per lane of a 16-lane DPP row");
+#ifdef LEXLS_SWEEP_STAMPS
+            long long sst[6] = {0, 0, 0, 0, 0, 0}, sst0 = clock64();
+#define SSTAMP(i) { const long long t_ = clock64(); sst[i] += t_ - sst0; sst0 = t_; }
+#else
+#define SSTAMP(i)
+#endif
             constexpr int TT = SWEEP_T;
             extern __shared__ double smem[];
             const uint32_t b = blockIdx.x, lane = threadIdx.x;
@@ -1429,8 +1435,16 @@ namespace lexls
                 return;
             }
             const int last = scan_up ? (int)nObj - 1 : oi; // objectives oi .. last are swept
-            const uint32_t *dims = a.dims + (size_t)b * nObj;
-            const uint32_t *rk = a.rank + (size_t)b * nObj, *fc = a.fcol + (size_t)b * nObj;
+            // the level descriptors once into LDS (at most 8 objectives per sweep): the loops below ask for them again and again, and a global
+            // load per question is a trip to the vector cache each time (the compiler cannot keep them across the LDS / global stores in between)
+            __shared__ uint32_t dims[8], rk[8], fc[8];
+            if (lane < 8)
+            {
+                dims[lane] = lane < nObj ? a.dims[(size_t)b * nObj + lane] : 0u;
+                rk[lane]   = lane < nObj ? a.rank[(size_t)b * nObj + lane] : 0u;
+                fc[lane]   = lane < nObj ? a.fcol[(size_t)b * nObj + lane] : 0u;
+            }
+            __syncthreads();
             const uint32_t nf  = a.nfixed ? a.nfixed[b] : 0;
             const uint32_t ld  = cap | 1u;
 
@@ -1447,6 +1461,7 @@ namespace lexls
             for (uint32_t i = lane; i < n; i += 64) types[cap + i] = a.fixed_type[(size_t)b * n + i];
             for (uint32_t i = lane; i < 4u * TT * (cap + 2 * n); i += 64) LamAll[i] = 0.0;
             stage_factor<64>(a.fac + (size_t)b * cap * (n + 1), Wl, cap, n + 1, ld, lane); // ends with a barrier
+            SSTAMP(0)
 
             // ---- the sweep: level k serves every objective L >= k ----
             uint32_t Fend = 0;
@@ -1513,6 +1528,7 @@ namespace lexls
                     }
                 });
                 // keep the level's multipliers (decisions are taken after the sweep)
+                SSTAMP(1)
 #pragma unroll
                 for (int t = 0; t < TT; t++)
                 {
@@ -1554,6 +1570,7 @@ namespace lexls
                     }
                 }
                 __syncthreads();
+                SSTAMP(2)
             }
 
             // ---- fixed variables: lambda_fixed = -LOD[0:nLambda, 0:nf]^T lambda (lexlse.h:742-758) ----
@@ -1579,6 +1596,7 @@ namespace lexls
             }
             __syncthreads();
 
+            SSTAMP(3)
             // ---- decisions, objective by objective (findDescentDirection, lexlse.h:935-987): sequential semantics — the most negative
             //      sign-adjusted multiplier wins, the first one among equals; marks are in place before the next group is looked at ----
             double best   = 0.0;
@@ -1607,7 +1625,9 @@ namespace lexls
                         found = 1;
                     }
                 }
-                __syncthreads(); // marks visible to the scans that follow
+                // (marks visible to the scans that follow: one wavefront, LDS accesses of a wavefront are served in order — a compiler fence is all)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                asm volatile("" ::: "memory");
             };
             for (int L = oi; L <= last; L++)
             {
@@ -1628,6 +1648,7 @@ namespace lexls
                 if (found) break;
             }
 
+            SSTAMP(4)
             // ---- results of the objective the search stopped at (getWorkspace: [lambda_fixed; lambda], lexlse.h:636-639) ----
             {
                 uint32_t nLam = 0;
@@ -1654,6 +1675,12 @@ namespace lexls
             }
             for (uint32_t i = lane; i < cap; i += 64) a.ctr_type[(size_t)b * cap + i] = types[i];
             for (uint32_t i = lane; i < n; i += 64) a.fixed_type[(size_t)b * n + i] = types[cap + i];
+            SSTAMP(5)
+#ifdef LEXLS_SWEEP_STAMPS
+            __syncthreads();
+            if (lane == 0)
+                for (int i_ = 0; i_ < 6; i_++) a.lambda[(size_t)b * (n + cap) + (n + cap - 6) + i_] = (double)sst[i_];
+#endif
         }
     } // namespace
 
