@@ -674,6 +674,37 @@ namespace lexls
             __syncthreads();
         }
 
+        /// stage_factor for the first `rows` rows of every column only (a problem of a ragged batch uses fewer rows than the capacity; the
+        /// rest of a column is never read by its chains)
+        template <int NT>
+        __device__ __forceinline__ void stage_factor_rows(const double *__restrict__ G, double *L, uint32_t cap, uint32_t ncol, uint32_t ldl, uint32_t rows, uint32_t tid)
+        {
+            constexpr uint32_t U = 20;
+            const uint32_t total = rows * ncol;
+            for (uint32_t base = tid; base < total; base += NT * U)
+            {
+                double v[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++)
+                {
+                    const uint32_t e = base + u * NT;
+                    const uint32_t j = e / rows;
+                    v[u]             = e < total ? G[(e - j * rows) + (size_t)j * cap] : 0.0;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++)
+                {
+                    const uint32_t e = base + u * NT;
+                    if (e < total)
+                    {
+                        const uint32_t j = e / rows;
+                        L[(e - j * rows) + j * ldl] = v[u];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
         // -----------------------------------------------------------------------------------------
         // ObjectiveSensitivity (lexlse.h:611-762) + findDescentDirection (:935-987)
         // -----------------------------------------------------------------------------------------
@@ -1460,7 +1491,11 @@ namespace lexls
             for (uint32_t i = lane; i < cap; i += 64) types[i] = a.ctr_type[(size_t)b * cap + i];
             for (uint32_t i = lane; i < n; i += 64) types[cap + i] = a.fixed_type[(size_t)b * n + i];
             for (uint32_t i = lane; i < 4u * TT * (cap + 2 * n); i += 64) LamAll[i] = 0.0;
-            stage_factor<64>(a.fac + (size_t)b * cap * (n + 1), Wl, cap, n + 1, ld, lane); // ends with a barrier
+            {
+                uint32_t Mrows = 0; // rows of the levels the sweep can touch
+                for (int k = 0; k <= last; k++) Mrows += dims[k];
+                stage_factor_rows<64>(a.fac + (size_t)b * cap * (n + 1), Wl, cap, n + 1, ld, Mrows ? Mrows : 1u, lane); // ends with a barrier
+            }
             SSTAMP(0)
 
             // ---- the sweep: level k serves every objective L >= k ----
