@@ -679,7 +679,7 @@ namespace lexls
         template <int NT>
         __device__ __forceinline__ void stage_factor_rows(const double *__restrict__ G, double *L, uint32_t cap, uint32_t ncol, uint32_t ldl, uint32_t rows, uint32_t tid)
         {
-            constexpr uint32_t U = 20;
+            constexpr uint32_t U = 32; // (the IK shapes in ONE round: 35 rows x 41 columns / 64 lanes = 23 loads per lane)
             const uint32_t total = rows * ncol;
             for (uint32_t base = tid; base < total; base += NT * U)
             {
@@ -1469,11 +1469,20 @@ namespace lexls
             // the level descriptors once into LDS (at most 8 objectives per sweep): the loops below ask for them again and again, and a global
             // load per question is a trip to the vector cache each time (the compiler cannot keep them across the LDS / global stores in between)
             __shared__ uint32_t dims[8], rk[8], fc[8];
+            // every small global read of the prologue is issued before the first of them is needed (one trip to memory instead of five in a row)
+            const uint32_t g_dim = (lane < 8 && lane < nObj) ? a.dims[(size_t)b * nObj + lane] : 0u;
+            const uint32_t g_rk  = (lane < 8 && lane < nObj) ? a.rank[(size_t)b * nObj + lane] : 0u;
+            const uint32_t g_fc  = (lane < 8 && lane < nObj) ? a.fcol[(size_t)b * nObj + lane] : 0u;
+            const double g_hh0   = lane < cap ? a.hh[(size_t)b * cap + lane] : 0.0;
+            const double g_hh1   = lane + 64 < cap ? a.hh[(size_t)b * cap + lane + 64] : 0.0;
+            const uint8_t g_ct0  = lane < cap ? a.ctr_type[(size_t)b * cap + lane] : (uint8_t)0;
+            const uint8_t g_ct1  = lane + 64 < cap ? a.ctr_type[(size_t)b * cap + lane + 64] : (uint8_t)0;
+            const uint8_t g_ft0  = lane < n ? a.fixed_type[(size_t)b * n + lane] : (uint8_t)0;
             if (lane < 8)
             {
-                dims[lane] = lane < nObj ? a.dims[(size_t)b * nObj + lane] : 0u;
-                rk[lane]   = lane < nObj ? a.rank[(size_t)b * nObj + lane] : 0u;
-                fc[lane]   = lane < nObj ? a.fcol[(size_t)b * nObj + lane] : 0u;
+                dims[lane] = g_dim;
+                rk[lane]   = g_rk;
+                fc[lane]   = g_fc;
             }
             __syncthreads();
             const uint32_t nf  = a.nfixed ? a.nfixed[b] : 0;
@@ -1487,9 +1496,10 @@ namespace lexls
             double *RhsAll = LamAll + (size_t)4 * TT * cap;
             double *FixAll = RhsAll + (size_t)4 * TT * n;
             uint8_t *types = reinterpret_cast<uint8_t *>(FixAll + (size_t)4 * TT * n);
-            for (uint32_t i = lane; i < cap; i += 64) hhl[i] = a.hh[(size_t)b * cap + i];
-            for (uint32_t i = lane; i < cap; i += 64) types[i] = a.ctr_type[(size_t)b * cap + i];
-            for (uint32_t i = lane; i < n; i += 64) types[cap + i] = a.fixed_type[(size_t)b * n + i];
+            if (lane < cap) hhl[lane] = g_hh0, types[lane] = g_ct0;
+            if (lane + 64 < cap) hhl[lane + 64] = g_hh1, types[lane + 64] = g_ct1;
+            for (uint32_t i = 128 + lane; i < cap; i += 64) hhl[i] = a.hh[(size_t)b * cap + i], types[i] = a.ctr_type[(size_t)b * cap + i]; // (capacities beyond 128 rows)
+            if (lane < n) types[cap + lane] = g_ft0; // (nVar <= 64 on this kernel)
             for (uint32_t i = lane; i < 4u * TT * (cap + 2 * n); i += 64) LamAll[i] = 0.0;
             {
                 uint32_t Mrows = 0; // rows of the levels the sweep can touch
