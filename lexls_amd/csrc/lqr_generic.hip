@@ -1674,6 +1674,12 @@ namespace lexls
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 asm volatile("" ::: "memory");
             };
+            // The levels of ONE objective are disjoint groups of constraints: their scans do not see each other's marks, only their order matters
+            // for ties (own level first, then upwards, strict '<').  So the four DPP rows take FOUR levels at a time — row q the q-th level in scan
+            // order — leave {minimum, first index} in LDS, and every lane folds the four in scan order: the same decisions as one level after
+            // the other at a quarter of the trips (level dims <= 16 on this kernel: one trip per level).  Fixed variables: as before.
+            __shared__ double gm[4];
+            __shared__ uint32_t gi[4];
             for (int L = oi; L <= last; L++)
             {
                 best  = 0.0;
@@ -1682,12 +1688,46 @@ namespace lexls
                 found = 0;
                 Lout  = L;
                 const double *lm = LamAll + (size_t)(L - oi) * cap;
-                uint32_t Fk = 0;
-                for (int k = 0; k <= L; k++) Fk += dims[k];
-                for (int k = L; k >= 0; k--) // own level first, then upwards (lexlse.h:664, :706-730)
+                for (int k0 = L; k0 >= 0; k0 -= 4)
                 {
-                    Fk -= dims[k];
-                    scan_group(types + Fk, lm + Fk, dims[k], k);
+                    const int k       = k0 - rho; // this row's level
+                    uint32_t Fk       = 0;
+                    for (int q = 0; q < k; q++) Fk += dims[q];
+                    const uint32_t count = k >= 0 ? dims[k] : 0u;
+                    const uint32_t kx    = (uint32_t)il;
+                    const bool in        = kx < count;
+                    uint8_t *ty          = types + Fk;
+                    const uint8_t t      = in ? ty[kx] : (uint8_t)CTR_ACTIVE_EQ;
+                    double al            = in ? lm[Fk + kx] : 0.0;
+                    if (t == CTR_ACTIVE_LB) al = -al;
+                    const bool look = in && t != CTR_ACTIVE_EQ && t != CORRECT_SIGN_OF_LAMBDA;
+                    if (look && al > tolC) ty[kx] = CORRECT_SIGN_OF_LAMBDA;
+                    const bool cand   = look && !(al > tolC) && al < -tolW;
+                    const double key  = cand ? al : 1.0; // candidates are negative
+                    const double m    = row_minf16(key);
+                    const unsigned ik = (cand && key == m) ? (unsigned)il : 0xffu;
+                    const unsigned fi = row_min16(ik);
+                    if (il == 0)
+                    {
+                        gm[rho] = m;
+                        gi[rho] = fi;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                    {
+                        const double mq = gm[q];
+                        if (k0 - q >= 0 && mq < 0.0 && mq < best) // (wave-uniform)
+                        {
+                            best  = mq;
+                            bctr  = gi[q];
+                            bobj  = k0 - q;
+                            found = 1;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    asm volatile("" ::: "memory");
                 }
                 if (nf > 0) scan_group(types + cap, FixAll + (size_t)(L - oi) * n, nf, -1);
                 if (found) break;
