@@ -1532,13 +1532,19 @@ namespace lexls
                         v = (il < rank) ? RhsAll[(size_t)(L - oi) * n + Fc + il] : 0.0; // lexlse.h:716
                     lam[t] = v;
                 }
-                // Householder sequence of the level, last reflector first (applyOnTheLeft.m:11-14); all control flow is wave-uniform
+                // Householder sequence of the level, last reflector first (applyOnTheLeft.m:11-14); all control flow is wave-uniform.
+                // The essential parts of ALL the level's reflectors and their scalars are read from LDS up front (one batch of reads instead of
+                // one exposed LDS round trip per reflector); tau_J then travels by a row broadcast
+                double eall[MD];
+#pragma unroll
+                for (int J = 0; J < MD; J++) eall[J] = (J < rank && il > J && il < dim) ? Wl[F + il + (size_t)(Fc + J) * ld] : 0.0;
+                const double tauv = il < dim ? hhl[F + il] : 0.0;
                 for_each_index<0, MD>([&](auto jj) __attribute__((always_inline)) {
                     constexpr int J = MD - 1 - decltype(jj)::value;
                     if (J < rank)
                     {
                         const int rows   = dim - J;
-                        const double tau = hhl[F + J];
+                        const double tau = gbc<J>(tauv);
                         if (rows == 1)
                         {
 #pragma unroll
@@ -1547,7 +1553,7 @@ namespace lexls
                         else if (tau != 0.0)
                         {
                             const bool tail = il > J && il < dim;
-                            const double e  = tail ? Wl[F + il + (size_t)(Fc + J) * ld] : 0.0;
+                            const double e  = eall[J];
                             double tt[TT];
 #pragma unroll
                             for (int t = 0; t < TT; t++) tt[t] = 0.0;
