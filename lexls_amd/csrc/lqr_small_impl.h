@@ -173,6 +173,7 @@ namespace lexls
                 const int dim_rt = (int)dims[k];
                 const int Fc     = all_fixed ? 0 : ColIndex; // the reference leaves first_col_index at 0 when it returns early
                 int rank         = 0;
+                const bool entered = !exhausted; // the reference reaches this level's body (lexlse.h:164-175, :475-490: it returns / breaks once the columns are exhausted)
 
                 double hh[MD];
 #pragma unroll
@@ -577,7 +578,7 @@ namespace lexls
                     }
                     imgp += (uint32_t)((n + 1 - Fc) * stride);
                 }
-                if constexpr (REG) // lexlse.h:277-411: the level's transformed right-hand side is damped before the Gauss step
+                if (REG && entered) // lexlse.h:277-411: the level's transformed right-hand side is damped before the Gauss step
                 {
                     __syncthreads(); // the image is in place (and so is everything the swaps wrote to the null-space basis)
                     __threadfence_block();

@@ -1,0 +1,78 @@
+"""Soak test (not part of the suite): the random draw of tests/test_gpu_random_sweep.py::test_random_sweep run for a time budget, policy 4 (the
+four-per-wavefront kernels: one / two / three / four slots, fixed-variable forms) and regularization types included; every case bit-identical to
+the oracle.  usage: python scripts/soak_lse.py [seconds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import lexls_amd as hip
+from lexls_amd import problems as P
+from oracle import oracle_ctypes as oracle
+from test_gpu_random_sweep import _draw
+from test_gpu_parity import assert_factor_equal
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(20261005)
+t0, cases, kernels = time.time(), 0, {}
+while time.time() - t0 < budget:
+    n, cap_dims, dims, batch = _draw(rng)
+    batch = batch if rng.random() < 0.7 else int(rng.integers(5, 40))
+    if dims.shape[0] != batch:
+        dims = np.repeat(dims[:1], batch, axis=0)
+    cap = int(cap_dims.sum())
+    lod = np.zeros((batch, n + 1, cap))
+    for b in range(batch):
+        m = int(dims[b].sum())
+        lod[b, :, :m] = P.normal(int(rng.integers(1, 2**31)), (n + 1) * m).reshape(n + 1, m)
+        if m > 2 and rng.random() < 0.4:
+            i, j = rng.integers(0, m, 2)
+            lod[b, :, i] = lod[b, :, j] if rng.random() < 0.7 else 0.0
+        if n > 2 and rng.random() < 0.3:
+            i, j = rng.integers(0, n, 2)
+            lod[b, i, :] = lod[b, j, :]
+    fixed = {}
+    if rng.random() < 0.4:
+        nf = rng.integers(0, min(n, 6) + 1, batch).astype(np.uint32)
+        idx = np.zeros((batch, n), np.uint32)
+        val = np.zeros((batch, n))
+        for b in range(batch):
+            idx[b, :nf[b]] = rng.choice(n, int(nf[b]), replace=False)
+            val[b, :nf[b]] = rng.normal(size=int(nf[b]))
+        fixed = dict(nfixed=nf, fixed_idx=idx, fixed_val=val)
+    policy = int(rng.choice([0, 4, 3, 1, 2]))
+    keep = bool(rng.random() < 0.5)
+    reg = int(rng.choice([1, 8, 3, 5, 9])) if rng.random() < 0.15 else 0
+    kw = {}
+    fac = None
+    if reg:
+        fac = np.abs(rng.normal(size=len(cap_dims))) * 0.3 + 0.01
+        kw = dict(reg_type=reg, reg_factors=fac)
+    if os.environ.get("SOAK_LOG"):
+        with open(os.environ["SOAK_LOG"], "a") as fh:
+            fh.write(f"case {cases}: n={n} cap={cap_dims.tolist()} batch={batch} dims0={dims[0].tolist()} policy={policy} keep={keep} "
+                     f"nfixed={fixed['nfixed'].tolist() if fixed else None} reg={reg}\n")
+    ref = oracle.lse_run(lod, dims, n, maxdim=cap_dims, **fixed, **kw)
+    s = hip.BatchedLexLSE(batch, n, cap_dims)
+    s.set_kernel_policy(policy)
+    s.setObjDim(dims)
+    if reg:
+        s.setRegularization(reg, fac)
+    if fixed:
+        s.fixVariables(fixed["nfixed"], fixed["fixed_idx"], fixed["fixed_val"])
+    s.setProblem(lod)
+    s.factorize_solve(keep_factor=keep)
+    k = s.last_kernel()
+    kernels[k] = kernels.get(k, 0) + 1
+    ctx = f"case {cases}: n={n} cap={cap_dims.tolist()} dims={dims.tolist()} policy={policy} keep={keep} fixed={bool(fixed)} reg={reg} kernel={k}"
+    np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"], err_msg=ctx)
+    np.testing.assert_array_equal(s.getRanks()[0], ref["rank"], err_msg=ctx)
+    if keep:
+        if s.last_kernel().startswith("lqr_large"):
+            pass
+        else:
+            assert_factor_equal(s, ref, dims, n)
+    s.close()
+    cases += 1
+print(f"soak ok: {cases} random cases in {time.time() - t0:.0f} s; kernels: " + ", ".join(f"{k} x{v}" for k, v in sorted(kernels.items())))

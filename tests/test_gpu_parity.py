@@ -666,6 +666,38 @@ def test_regularization_on_the_wave_kernel_ik_shapes(hip, oracle, reg_type):
             np.testing.assert_array_equal(s.get_column_permutations()[b], ref["perm"][0])
 
 
+@pytest.mark.parametrize("reg_type", [8, 1, 3])
+def test_regularization_levels_the_reference_never_enters(hip, oracle, reg_type):
+    """the reference returns before the first level when every variable is fixed (lexlse.h:164-175) and leaves the level loop once the columns are
+    exhausted (:475-490): such levels are not regularized either — on the wave kernel as in the generic one (found by scripts/soak_lse.py:
+    a problem with nVarFixed == nVar next to regular ones in one batch)"""
+    n, cap_dims = 3, np.array([14, 16, 1, 13, 8, 1], np.uint32)
+    dims = np.array([[3, 5, 1, 5, 5, 1], [14, 16, 1, 13, 8, 1], [2, 0, 1, 4, 8, 1]], np.uint32)
+    batch = 3
+    lod = np.zeros((batch, n + 1, int(cap_dims.sum())))
+    for b in range(batch):
+        m = int(dims[b].sum())
+        lod[b, :, :m] = P.normal(7100 + b, (n + 1) * m).reshape(n + 1, m)
+    nfixed = np.array([2, 3, 1], np.uint32)  # problem 1: all variables fixed
+    idx = np.zeros((batch, n), np.uint32)
+    idx[:, :3] = [2, 0, 1]
+    val = np.zeros((batch, n))
+    val[:, :3] = P.normal(7200, 3)
+    fac = np.abs(P.normal(7300, 6)) * 0.3 + 0.01
+    ref = oracle.lse_run(lod, dims, n, maxdim=cap_dims, nfixed=nfixed, fixed_idx=idx, fixed_val=val, reg_type=reg_type, reg_factors=fac)
+    for policy in (0, 1):
+        s = hip.BatchedLexLSE(batch, n, cap_dims)
+        s.set_kernel_policy(policy)
+        s.setObjDim(dims)
+        s.setRegularization(reg_type, fac)
+        s.fixVariables(nfixed, idx, val)
+        s.setProblem(lod)
+        s.factorize_solve(keep_factor=True)
+        assert s.last_kernel().startswith("lqr_generic" if policy == 1 else "lqr_wave<64,16,regularized>")
+        np.testing.assert_array_equal(s.get_x(), ref["x"])
+        assert_factor_equal(s, ref, dims, n)
+
+
 def test_regularization_variable_factor_and_least_norm_3(hip, oracle):
     n, dims, batch = 40, [6] * 5, 4
     lod = P.lse_batch(61, batch, n, dims)
