@@ -31,7 +31,7 @@
 //
 // Differences a caller can observe: Eigen types are replaced by the containers of typedefs.h
 // (dMatrixConstRef is a (ptr, rows, cols, ld) view); setCtr takes a pointer to nVar doubles;
-// REGULARIZATION_TIKHONOV_1 and solveGeneralNorm throw.
+// solveGeneralNorm throws (no caller in the reference).
 #pragma once
 
 #include <lexls/typedefs.h>
@@ -112,7 +112,7 @@ namespace LexLS
                 for (Index i = nVarFixed; i < nVar; i++) x(i) = 0.0;
             }
 
-            /// lexlse.h:1467.  Every regularization type has a device path except the experimental TIKHONOV_1 (throws)
+            /// lexlse.h:1467.  Every regularization type of typedefs.h:34-43 has a device path
             void setParameters(const ParametersLexLSE &p)
             {
                 switch (p.regularization_type)
@@ -124,9 +124,10 @@ namespace LexLS
                 case REGULARIZATION_R_NO_Z:
                 case REGULARIZATION_RT_NO_Z:
                 case REGULARIZATION_RT_NO_Z_CG:
+                case REGULARIZATION_TIKHONOV_1:
                 case REGULARIZATION_TIKHONOV_2:
                 case REGULARIZATION_TEST: break;
-                default: throw Exception("lexls_hip: REGULARIZATION_TIKHONOV_1 (experimental) has no device path");
+                default: throw Exception("lexls_hip: unknown regularization type");
                 }
                 parameters = p;
                 if (h) check(lexls_lse_set_tolerance(h, p.tol_linear_dependence));
@@ -298,10 +299,22 @@ namespace LexLS
                 for (Index i = 0; i < nVarFixed; i++) v(i) = fixed_idx[i];
                 return v;
             }
-            /// lexlse.h:1636-1650: filled only by REGULARIZATION_TIKHONOV_1 (regularize_tikhonov_1_test), which has no device path
-            const dMatrixType &get_X_mu() const { throw Exception("lexls_hip: X_mu is produced by REGULARIZATION_TIKHONOV_1 only, which has no device path"); }
-            const dMatrixType &get_X_mu_rhs() const { throw Exception("lexls_hip: X_mu_rhs is produced by REGULARIZATION_TIKHONOV_1 only, which has no device path"); }
-            const dVectorType &get_residual_mu() const { throw Exception("lexls_hip: residual_mu is produced by REGULARIZATION_TIKHONOV_1 only, which has no device path"); }
+            /// lexlse.h:1636-1650: the by-products of REGULARIZATION_TIKHONOV_1 (regularize_tikhonov_1_test); other types leave them unset
+            const dMatrixType &get_X_mu()
+            {
+                fetch_mu();
+                return X_mu;
+            }
+            const dMatrixType &get_X_mu_rhs()
+            {
+                fetch_mu();
+                return X_mu_rhs;
+            }
+            const dVectorType &get_residual_mu()
+            {
+                fetch_mu();
+                return residual_mu;
+            }
             /// lexlse.h:770-861: the debug overload that prints every multiplier; use getWorkspace() after the overloads above
             void ObjectiveSensitivity(Index) { throw Exception("lexls_hip: the printing overload of ObjectiveSensitivity is not provided"); }
             const dVectorType &getWorkspace() const { return dWorkspace; }
@@ -342,6 +355,16 @@ namespace LexLS
                                                    parameters.variable_regularization_factor));
             }
 
+            void fetch_mu()
+            {
+                if (parameters.regularization_type != REGULARIZATION_TIKHONOV_1)
+                    throw Exception("lexls_hip: X_mu, X_mu_rhs and residual_mu are produced by REGULARIZATION_TIKHONOV_1 only");
+                X_mu.resize(nVar, nObj);
+                X_mu_rhs.resize(nVar, nObj);
+                residual_mu.resize(cap);
+                check(lexls_lse_get_mu(h, X_mu.data(), X_mu_rhs.data(), residual_mu.data()));
+            }
+
             lexls_lse_t h;
             Index nVar, nObj, nCtr, cap, nVarFixed, nVarFixedInit, TotalRank;
             int device;
@@ -351,8 +374,8 @@ namespace LexLS
             std::vector<Index> dims, first_row, rank, first_col, fixed_idx;
             std::vector<double> fixed_val, reg_factor;
             std::vector<uint8_t> fixed_type, ctr_type;
-            dMatrixType LOD, PROBLEM_DATA, FACTOR;
-            dVectorType x, dWorkspace;
+            dMatrixType LOD, PROBLEM_DATA, FACTOR, X_mu, X_mu_rhs;
+            dVectorType x, dWorkspace, residual_mu;
         };
     } // namespace internal
 

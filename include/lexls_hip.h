@@ -137,8 +137,9 @@ int lexls_lse_factorize_solve(lexls_lse_t h, int keep_factor);
 int lexls_lse_solve_least_norm(lexls_lse_t h);
 /* replaces setParameters(regularization_type, variable_regularization_factor) + setRegularizationFactor (lexlse.h:1467, :1477;
  * dispatch lexlse.h:277-411).  type: LexLS::RegularizationType — NONE 0, TIKHONOV 1, R 3, R_NO_Z 4, RT_NO_Z 5, TIKHONOV_2 8, TEST 9
- * and the CGLS variants TIKHONOV_CG 2, RT_NO_Z_CG 6 (the experimental TIKHONOV_1 7 returns LEXLS_ERR_UNSUPPORTED).  h_factors: one factor per level
- * (per_problem == 0) or batch x nObj (per_problem != 0); NULL = all zero.  With a type != 0 the factorization runs on the generic kernel. */
+ * the CGLS variants TIKHONOV_CG 2, RT_NO_Z_CG 6, and TIKHONOV_1 7 (the type the reference marks experimental: regularize_tikhonov_1_test
+ * lexlse.h:1774-1886; its ObjectiveSensitivity then returns the multipliers of the regularized problem, :647-651; generic kernel only;
+ * by-products: lexls_lse_get_mu).  h_factors: one factor per level (per_problem == 0) or batch x nObj (per_problem != 0); NULL = all zero. */
 int lexls_lse_set_regularization(lexls_lse_t h, int type, const double *h_factors, int per_problem, double variable_factor);
 /* max_number_of_CG_iterations (typedefs.h:111, default 10): iteration cap of the two CGLS variants */
 int lexls_lse_set_cg_iterations(lexls_lse_t h, uint32_t max_iterations);
@@ -168,6 +169,10 @@ int lexls_lse_get_hh_scalars(lexls_lse_t h, double *h_hh);
 int lexls_lse_get_permutation(lexls_lse_t h, uint32_t *h_perm);
 int lexls_lse_get_ranks(lexls_lse_t h, uint32_t *h_rank, uint32_t *h_first_col, uint32_t *h_total_rank); /* getRank/getTotalRank :1503,:1603 */
 int lexls_lse_get_v(lexls_lse_t h, double *h_v);                    /* get_v()      lexlse.h:1560 */
+/* replaces get_X_mu() / get_X_mu_rhs() / get_residual_mu() (lexlse.h:1636-1650), filled with regularization type 7 only: h_x_mu and
+ * h_x_mu_rhs are batch x nObj x nVar (column k of the reference's nVar x nObj matrix is contiguous), h_residual_mu is batch x cap;
+ * NULL = not wanted.  X_mu_rhs columns are written by lexls_lse_sensitivity (initialize_rhs, :1921-1959). */
+int lexls_lse_get_mu(lexls_lse_t h, double *h_x_mu, double *h_x_mu_rhs, double *h_residual_mu);
 int lexls_lse_get_lambda(lexls_lse_t h, double *h_lambda);          /* getWorkspace() after ObjectiveSensitivity, lexlse.h:1621 */
 /* h_found_ctr_obj: batch x 3 int32 {found, CtrIndex2Remove, ObjIndex2Remove}; h_max_abs: batch */
 int lexls_lse_get_sensitivity(lexls_lse_t h, int32_t *h_found_ctr_obj, double *h_max_abs);

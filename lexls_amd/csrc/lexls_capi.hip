@@ -70,7 +70,7 @@ struct lexls_lse_s
     uint32_t reg_type;    // LexLS::RegularizationType, 0 = none
     uint32_t reg_cg_iters;
     double reg_variable;
-    double *d_reg_factor, *d_reg_scratch;
+    double *d_reg_factor, *d_reg_scratch, *d_reg_mu;
     bool sens_scan; // lexls_lse_set_sensitivity_scan
     char *d_round_in, *d_round_out; // the per-round arrays live in two slabs (lexls_lse_round_layout): one copy each way per round
     lexls_round_layout lay;
@@ -109,6 +109,7 @@ struct lexls_lse_s
         a.reg_variable = reg_variable;
         a.reg_factor   = d_reg_factor;
         a.reg_scratch  = d_reg_scratch;
+        a.reg_mu       = d_reg_mu;
         a.g_cdata      = fused_gather ? d_cdata : nullptr;
         a.g_per        = cdata_per_problem;
         a.g_row_src    = d_row_src;
@@ -171,7 +172,7 @@ extern "C"
         h->reg_type    = 0;
         h->reg_cg_iters = 10; // typedefs.h:170
         h->reg_variable = 0.0;
-        h->d_reg_factor = h->d_reg_scratch = nullptr;
+        h->d_reg_factor = h->d_reg_scratch = h->d_reg_mu = nullptr;
         h->deferred_sync = false;
         h->h_dims_pinned = nullptr;
         h->dims_event = nullptr;
@@ -253,7 +254,7 @@ extern "C"
         if (!h) return LEXLS_OK;
         (void)hipSetDevice(h->device);
         void *ptrs[] = {h->d_in_owned, h->d_fac, h->d_hh, h->d_v, h->d_lambda, h->d_scratch, h->d_perm, h->d_rank, h->d_fcol, h->d_round_in, h->d_round_out,
-                        h->d_large_state, h->d_large_ws, h->d_norms, h->d_cdata, h->d_reg_factor, h->d_reg_scratch};
+                        h->d_large_state, h->d_large_ws, h->d_norms, h->d_cdata, h->d_reg_factor, h->d_reg_scratch, h->d_reg_mu};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (h->h_dims_pinned) (void)hipHostFree(h->h_dims_pinned);
@@ -282,8 +283,8 @@ extern "C"
         CHECK_HANDLE(h);
         switch (type)
         {
-        case 0: case 1: case 2: case 3: case 4: case 5: case 6: case 8: case 9: break;
-        default: return fail(LEXLS_ERR_UNSUPPORTED, "set_regularization: REGULARIZATION_TIKHONOV_1 (7, experimental) has no device path");
+        case 0: case 1: case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: break;
+        default: return fail(LEXLS_ERR_INVALID, "set_regularization: unknown regularization type");
         }
         HIP_TRY(hipSetDevice(h->device));
         h->factor_valid = false;
@@ -301,6 +302,12 @@ extern "C"
             const size_t bytes = 8 * B * reg_scratch_doubles(h->nVar);
             HIP_TRY(hipMalloc((void **)&h->d_reg_scratch, bytes));
             HIP_TRY(hipMemsetAsync(h->d_reg_scratch, 0, bytes, h->stream));
+        }
+        if (type == 7 && !h->d_reg_mu) // X_mu, X_mu_rhs, residual_mu of the reference's experimental type (lexlse.h:96-99)
+        {
+            const size_t bytes = 8 * B * reg_mu_doubles(h->nVar, h->nObj, h->cap);
+            HIP_TRY(hipMalloc((void **)&h->d_reg_mu, bytes));
+            HIP_TRY(hipMemsetAsync(h->d_reg_mu, 0, bytes, h->stream));
         }
         HIP_TRY(hipMemcpyAsync(h->d_reg_factor, f.data(), 8 * B * nObj, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream)); // f is a temporary
@@ -755,7 +762,7 @@ extern "C"
     int lexls_lse_solve_least_norm_3(lexls_lse_t h)
     {
         if (int rc = need_factor(h, "lexls_lse_solve_least_norm_3")) return rc;
-        if (h->reg_type != 1 && h->reg_type != 2 && h->reg_type != 8 && h->reg_type != 3)
+        if (h->reg_type != 1 && h->reg_type != 2 && h->reg_type != 8 && h->reg_type != 3 && h->reg_type != 7)
             return fail(LEXLS_ERR_INVALID, "lexls_lse_solve_least_norm_3: needs a factorization with a regularization type that accumulates the null-space basis (lexlse.h:1217-1221)");
         HIP_TRY(hipSetDevice(h->device));
         if (!h->d_scratch) HIP_TRY(hipMalloc((void **)&h->d_scratch, 8 * (size_t)h->batch * 2 * h->nVar * h->nVar));
@@ -835,6 +842,18 @@ extern "C"
         if (!rc && h_first_col) rc = download(h, h_first_col, h->d_fcol, 4 * (size_t)h->batch * h->nObj);
         if (!rc && h_total_rank) rc = download(h, h_total_rank, h->d_totalrank, 4 * (size_t)h->batch);
         return rc;
+    }
+    int lexls_lse_get_mu(lexls_lse_t h, double *h_x_mu, double *h_x_mu_rhs, double *h_residual_mu)
+    {
+        CHECK_HANDLE(h);
+        if (h->reg_type != 7 || !h->d_reg_mu) return fail(LEXLS_ERR_INVALID, "lexls_lse_get_mu: X_mu / X_mu_rhs / residual_mu exist with REGULARIZATION_TIKHONOV_1 (7) only");
+        HIP_TRY(hipSetDevice(h->device));
+        const size_t n = h->nVar, nObj = h->nObj, cap = h->cap, per = reg_mu_doubles(h->nVar, h->nObj, h->cap);
+        if (h_x_mu) HIP_TRY(hipMemcpy2DAsync(h_x_mu, 8 * nObj * n, h->d_reg_mu, 8 * per, 8 * nObj * n, h->batch, hipMemcpyDeviceToHost, h->stream));
+        if (h_x_mu_rhs) HIP_TRY(hipMemcpy2DAsync(h_x_mu_rhs, 8 * nObj * n, h->d_reg_mu + nObj * n, 8 * per, 8 * nObj * n, h->batch, hipMemcpyDeviceToHost, h->stream));
+        if (h_residual_mu) HIP_TRY(hipMemcpy2DAsync(h_residual_mu, 8 * cap, h->d_reg_mu + 2 * nObj * n, 8 * per, 8 * cap, h->batch, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return LEXLS_OK;
     }
     int lexls_lse_get_v(lexls_lse_t h, double *h_v) { return h ? download(h, h_v, h->d_v, 8 * (size_t)h->batch * h->cap) : fail(LEXLS_ERR_INVALID, "null handle"); }
     int lexls_lse_get_lambda(lexls_lse_t h, double *h_lambda)

@@ -45,6 +45,7 @@ namespace lexls
         double reg_variable;             // variable_regularization_factor (typedefs.h:116), 0 = constant factors
         const double *reg_factor;        // batch x nObj regularization factors (lexlse.h:1477)
         double *reg_scratch;             // batch x reg_scratch_doubles(nVar): null-space basis + work matrices (lexls_regularize.h)
+        double *reg_mu;                  // batch x reg_mu_doubles(nVar, nObj, cap): X_mu, X_mu_rhs, residual_mu of reg_type 7 (else NULL)
         const uint8_t *skip;             // batch flags: non-zero = leave this problem untouched (NULL: none); lock-step LSI batches
         // Row gather fused into the load of lqr_wave_kernel (NULL: `in` holds the assembled problems).  Row r of problem b is row
         // row_src[b*cap+r] of the resident constraint data: element j at g_cdata[b*g_per + row_src + j*ld], right-hand side at column

@@ -925,7 +925,6 @@ namespace
         }
         void setParameters(const ParametersLexLSE &p)
         {
-            if (p.regularization_type == REGULARIZATION_TIKHONOV_1) throw Exception("lexls_hip: REGULARIZATION_TIKHONOV_1 (experimental) has no device path");
             tol = p.tol_linear_dependence; // tolerance and regularization type of the batch handle are set once by the batch driver
         }
         void setRegularizationFactor(Index ObjIndex, RealScalar factor)

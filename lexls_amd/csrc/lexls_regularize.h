@@ -1,6 +1,7 @@
 // Regularization family of LexLSE::factorize (lexlse.h:277-411, :1700-2251, :2592-2625) for the generic kernel: executed by the
 // whole workgroup right after a level's QR, before its Gauss step.  Implemented: TIKHONOV (1), TIKHONOV_CG (2), R (3), R_NO_Z (4),
-// RT_NO_Z (5), RT_NO_Z_CG (6), TIKHONOV_2 (8), TEST (9) and the variable factor; not: the experimental TIKHONOV_1 (7).
+// RT_NO_Z (5), RT_NO_Z_CG (6), TIKHONOV_2 (8), TEST (9) and the variable factor; the reference's experimental TIKHONOV_1 (7,
+// regularize_tikhonov_1_test :1774-1886 with its X_mu / residual_mu by-products) in the generic kernel only.
 // Arithmetic order = oracle/lexlse_oracle.h (regularize_* there), so the results are bit-identical to the oracle's.
 //
 // Per problem the scratch holds (doubles): NS n x (n+1) [the accumulated null-space basis, lexlse.h:93; it survives the
@@ -15,6 +16,19 @@ namespace lexls
         __device__ __forceinline__ double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
         __host__ __device__ inline size_t reg_scratch_doubles(uint32_t n) { return (size_t)n * (n + 1) + 2 * (size_t)n * n + 2 * (size_t)n + 8 + 10 * (size_t)n; }
+
+        /// by-products of the experimental type 7 per problem (lexlse.h:96-99): X_mu nObj x n (a column per level, contiguous),
+        /// X_mu_rhs nObj x n, residual_mu cap, one work vector cap
+        __host__ __device__ inline size_t reg_mu_doubles(uint32_t n, uint32_t nObj, uint32_t cap) { return 2 * (size_t)nObj * n + 2 * (size_t)cap; }
+
+        /// what regularize_tikhonov_1_test reads besides the level itself: first rows / first columns / ranks of the levels so far,
+        /// the column transpositions, the Householder scalars
+        struct RegLevels
+        {
+            const uint32_t *fr, *fc, *rk, *perm;
+            const double *hh;
+            uint32_t dim;
+        };
 
         struct RegView
         {
@@ -458,10 +472,90 @@ namespace lexls
             __syncthreads();
         }
 
+        /// Eigen applyHouseholderOnTheLeft on one vector (oracle: apply_householder)
+        __device__ inline void reg_apply_householder(const double *ess, double tau, double *x, uint32_t len)
+        {
+            if (len == 1)
+                x[0] *= (1.0 - tau);
+            else if (tau != 0.0)
+            {
+                double tmp = 0.0;
+                for (uint32_t i = 1; i < len; i++) tmp = rfma(ess[i - 1], x[i], tmp);
+                tmp += x[0];
+                x[0] = rfma(-tau, tmp, x[0]);
+                for (uint32_t i = 1; i < len; i++) x[i] = rfma(-(tau * ess[i - 1]), tmp, x[i]);
+            }
+        }
+
+        /// lexlse.h:1774-1886 (oracle: regularize_tikhonov_1_test): regularize_tikhonov_1, then the residual of the regularized level
+        /// and the regularized solution of the levels 0..ObjIndex (get_intermediate_x :2010-2071).  The by-products are a few hundred
+        /// flops of strictly ordered chains: one thread.
+        template <int NT>
+        __device__ void reg_tikhonov_1_test(const RegView &v, const LseArgs &a, uint32_t b, const RegLevels &lv, uint32_t ObjIndex, uint32_t F, uint32_t Fc,
+                                            uint32_t rank, uint32_t RC, double f, uint32_t tid)
+        {
+            reg_tikhonov_1<NT>(v, F, Fc, rank, RC, f, tid); // leaves the solution of the normal equations in v.d, ends with a barrier
+            if (tid == 0)
+            {
+                const uint32_t n = v.n, N = RC + rank, dim = lv.dim;
+                double *mu  = a.reg_mu + (size_t)b * reg_mu_doubles(n, a.nObj, a.cap);
+                double *X   = mu + (size_t)ObjIndex * n;
+                double *res = mu + 2 * (size_t)a.nObj * n;
+                double *w   = res + a.cap;
+                for (uint32_t i = 0; i < dim; i++) w[i] = i < rank ? v.w(F + i, n) : 0.0; // Q1 [R T] d - b (:1848-1854)
+                for (uint32_t j = rank; j--;) reg_apply_householder(&v.w(F + j + 1, Fc + j), lv.hh[F + j], w + j, dim - j);
+                for (uint32_t i = 0; i < dim; i++) res[F + i] = w[i] - res[F + i];
+
+                for (uint32_t i = 0; i < N; i++) X[n - N + i] = v.d[i]; // :1857
+                for (uint32_t i = 0; i < ObjIndex; i++)                 // :2026-2040
+                {
+                    const uint32_t Fi = lv.fr[i], Fci = lv.fc[i], ri = lv.rk[i];
+                    for (uint32_t r = 0; r < ri; r++)
+                    {
+                        double acc = 0.0;
+                        for (uint32_t c = 0; c < N; c++) acc = rfma(v.w(Fi + r, n - N + c), X[n - N + c], acc);
+                        X[Fci + r] = v.w(Fi + r, n) - acc;
+                    }
+                }
+                uint32_t acc_ranks = 0;
+                for (uint32_t k = ObjIndex; k--;) // :2046-2070
+                {
+                    const uint32_t Fk = lv.fr[k], Fck = lv.fc[k], rk = lv.rk[k];
+                    if (rk == 0) continue;
+                    if (acc_ranks > 0)
+                    {
+                        const uint32_t c0 = lv.fc[k + 1];
+                        for (uint32_t i = 0; i < rk; i++)
+                        {
+                            double s = X[Fck + i];
+                            for (uint32_t j = 0; j < acc_ranks; j++) s = rfma(-v.w(Fk + i, c0 + j), X[c0 + j], s);
+                            X[Fck + i] = s;
+                        }
+                    }
+                    for (uint32_t j = rk; j--;)
+                    {
+                        X[Fck + j] = X[Fck + j] / v.w(Fk + j, Fck + j);
+                        for (uint32_t i = 0; i < j; i++) X[Fck + i] = rfma(-v.w(Fk + i, Fck + j), X[Fck + j], X[Fck + i]);
+                    }
+                    acc_ranks += rk;
+                }
+                uint32_t total = rank; // :1863-1874 (ranks without the fixed variables, as the reference counts them)
+                for (uint32_t k = 0; k < ObjIndex; k++) total += lv.rk[k];
+                for (uint32_t k = total; k--;)
+                {
+                    const uint32_t j = lv.perm[k];
+                    const double t   = X[k];
+                    X[k]             = X[j];
+                    X[j]             = t;
+                }
+            }
+            __syncthreads();
+        }
+
         /// dispatch of lexlse.h:277-395 for one level; called by every thread of the workgroup (uniform arguments)
         template <int NT>
         __device__ void regularize_level(const LseArgs &a, uint32_t b, double *W, size_t ld, uint32_t nf, uint32_t ObjIndex, uint32_t F, uint32_t Fc,
-                                         uint32_t rank, uint32_t RC, uint32_t tid)
+                                         uint32_t rank, uint32_t RC, uint32_t tid, const RegLevels *lv = nullptr)
         {
             const RegView v = reg_view(a, b, W, ld, nf);
             if (tid == 0) // lexlse.h:277-311: constant or conditioning-dependent factor
@@ -510,6 +604,10 @@ namespace lexls
                     else
                         reg_tikhonov_1<NT>(v, F, Fc, rank, RC, f, tid);
                 }
+                reg_accumulate_nullspace<NT>(v, F, Fc, rank, RC, tid);
+                break;
+            case 7: // REGULARIZATION_TIKHONOV_1 (experimental in the reference; the generic kernel passes the level lists)
+                if (nonzero && lv) reg_tikhonov_1_test<NT>(v, a, b, *lv, ObjIndex, F, Fc, rank, RC, f, tid);
                 reg_accumulate_nullspace<NT>(v, F, Fc, rank, RC, tid);
                 break;
             case 8: // REGULARIZATION_TIKHONOV_2

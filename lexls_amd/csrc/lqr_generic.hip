@@ -201,6 +201,13 @@ namespace lexls
                 double *NS = a.reg_scratch + (size_t)b * reg_scratch_doubles(n);
                 for (uint32_t e = tid; e < n * (n + 1); e += NT) NS[e] = 0.0;
             }
+            double *mu_x = nullptr, *mu_res = nullptr; // by-products of the experimental type 7 (lexlse.h:96-99, zeroed by initialize() :1687-1689)
+            if (a.reg_type == 7)
+            {
+                mu_x   = a.reg_mu + (size_t)b * reg_mu_doubles(n, nObj, cap);
+                mu_res = mu_x + 2 * (size_t)nObj * n;
+                for (size_t e = tid; e < reg_mu_doubles(n, nObj, cap); e += NT) mu_x[e] = 0.0;
+            }
             __syncthreads();
 
             // ---- fixed variables: their columns go first, their contribution goes to the RHS (lexlse.h:132-156) ----
@@ -256,6 +263,9 @@ namespace lexls
                 {
                     const uint32_t F = fr_s[ObjIndex], Fc = ColIndex, dim = dims[ObjIndex];
                     if (tid == 0) fc_s[ObjIndex] = Fc;
+
+                    if (mu_res) // lexlse.h:191: the level's right-hand side after the eliminations, before its reflectors
+                        for (uint32_t i = tid; i < dim; i += NT) mu_res[F + i] = W[F + i + n * ld];
 
                     // initial squared column norms of the level (lexlse.h:193-196): one ordered chain per column
                     for (uint32_t k = ColIndex + tid; k < n; k += NT)
@@ -384,7 +394,8 @@ namespace lexls
                     if (a.reg_type) // lexlse.h:277-411: the level's transformed right-hand side is damped before the Gauss step
                     {
                         __syncthreads();
-                        regularize_level<NT>(a, b, W, ld, nf, ObjIndex, F, Fc, rank, n - ColIndex, tid);
+                        const RegLevels lv = {fr_s, fc_s, rk_s, perm_s, hh, dim};
+                        regularize_level<NT>(a, b, W, ld, nf, ObjIndex, F, Fc, rank, n - ColIndex, tid, &lv);
                     }
 
                     // Gauss step (lexlse.h:431-471)
@@ -417,6 +428,20 @@ namespace lexls
                     {
                         if (tid == 0)
                             for (uint32_t k = ObjIndex + 1; k < nObj; k++) fc_s[k] = fc_s[k - 1] + rk_s[k - 1];
+                        if (mu_x) // lexlse.h:483-486
+                        {
+                            __syncthreads();
+                            for (uint32_t k = ObjIndex + 1; k < nObj; k++)
+                            {
+                                for (uint32_t i = tid; i < n; i += NT)
+                                {
+                                    mu_x[(size_t)k * n + i]          = mu_x[(size_t)(k - 1) * n + i];
+                                    mu_x[(size_t)(nObj + k) * n + i] = mu_x[(size_t)(nObj + k - 1) * n + i];
+                                }
+                                for (uint32_t i = tid; i < dims[k]; i += NT) mu_res[fr_s[k] + i] = -W[fr_s[k] + i + n * ld];
+                                __syncthreads();
+                            }
+                        }
                         break;
                     }
                 }
@@ -812,12 +837,65 @@ namespace lexls
             __syncthreads();
 
             uint32_t F = Fobj, Fc = fc[ObjIndex], dim = dims[ObjIndex], rank = rk[ObjIndex];
+            if (a.reg_type == 7) // lexlse.h:647-651, :688-690 ("WARNING: TESTING" there): multipliers of the REGULARIZED problem
+            {
+                double *mu        = a.reg_mu + (size_t)b * reg_mu_doubles(n, nObj, cap);
+                const double *res = mu + 2 * (size_t)nObj * n;
+                if (tid == 0) // initialize_rhs (:1921-1959; oracle: initialize_rhs): ordered chains over at most nVar entries
+                {
+                    const double *X      = mu + (size_t)ObjIndex * n;
+                    double *c            = mu + (size_t)(nObj + ObjIndex) * n; // X_mu_rhs.col(ObjIndex)
+                    const uint32_t *perm = a.perm + (size_t)b * n;
+                    const uint32_t TotalRank = a.totalrank[b];
+                    const double f           = a.reg_factor[(size_t)b * nObj + ObjIndex];
+                    for (uint32_t i = 0; i < n; i++) c[i] = X[i];
+                    for (uint32_t k = 0; k < TotalRank; k++) // P' * .
+                    {
+                        const uint32_t j = perm[k];
+                        const double t   = c[k];
+                        c[k]             = c[j];
+                        c[j]             = t;
+                    }
+                    for (uint32_t i = 0; i < n; i++) c[i] *= -f * f;
+                    const uint32_t last = Fc + rank;
+                    uint32_t Fk = 0, Fp = 0, nRank = 0;
+                    for (uint32_t k = 0; k <= ObjIndex; k++)
+                    {
+                        const uint32_t Fck = fc[k], rkk = rk[k];
+                        if (k > 0)
+                        {
+                            const uint32_t Fcp = fc[k - 1], rp = rk[k - 1], remain = last - Fck;
+                            for (uint32_t j = 0; j < remain; j++)
+                            {
+                                double s = c[Fck + j];
+                                for (uint32_t i = 0; i < rp; i++) s = dfma(-W[Fp + i + (Fck + j) * ld], c[Fcp + i], s);
+                                c[Fck + j] = s;
+                            }
+                        }
+                        for (uint32_t j = 0; j < rkk; j++) // R_k' z = c
+                        {
+                            double s = c[Fck + j];
+                            for (uint32_t i = 0; i < j; i++) s = dfma(-W[Fk + i + (Fck + j) * ld], c[Fck + i], s);
+                            c[Fck + j] = s / W[Fk + j + (Fck + j) * ld];
+                        }
+                        if (k < ObjIndex) nRank += rkk;
+                        Fp = Fk;
+                        Fk += dims[k];
+                    }
+                    for (uint32_t i = 0; i < nRank + nf; i++) rhs[i] = c[i];
+                }
+                for (uint32_t i = tid; i < dim; i += NT) Lambda[F + i] = res[F + i];
+                __syncthreads();
+            }
+            else
+            {
             for (uint32_t i = rank + tid; i < dim; i += NT) Lambda[F + i] = -W[F + i + n * ld];
             __syncthreads();
             if (STAGE && NT == 64 && dim <= 64)
                 apply_q_wave(W, ld, hh, F, Fc, dim, rank, Lambda + F, tid);
             else
                 apply_q_block<NT>(W, ld, hh, F, Fc, dim, rank, Lambda + F, bcast, tid);
+            }
             if (tid == 0) find_descent(ctr_type + F, Lambda + F, dim, tolW, tolC, (int)ObjIndex, st);
 
             if (ObjIndex > 0)
@@ -1808,7 +1886,7 @@ namespace lexls
         // the single-sweep form (sensitivity_sweep_kernel): level dims <= 16, at most 8 objectives per sweep, one wavefront per problem with
         // the factor staged in LDS — what a lock-step LSI stage asks for.  max_level_dim comes from the caller (0 = unknown: not taken)
         const size_t lds_sweep = 8 * ((size_t)(a.cap | 1u) * (a.nVar + 1) + a.cap + 8 * ((size_t)a.cap + 2 * a.nVar)) + (((size_t)a.cap + a.nVar + 15) & ~(size_t)15);
-        if (sweep_level_dim_hint > 0 && sweep_level_dim_hint <= (uint32_t)SWEEP_MD && a.nObj <= 8 && a.nVar <= 64 && lds_sweep <= 64 * 1024 && a.batch <= 4u * (uint32_t)cus &&
+        if (a.reg_type != 7 && sweep_level_dim_hint > 0 && sweep_level_dim_hint <= (uint32_t)SWEEP_MD && a.nObj <= 8 && a.nVar <= 64 && lds_sweep <= 64 * 1024 && a.batch <= 4u * (uint32_t)cus &&
             !std::getenv("LEXLS_SENS_NO_SWEEP"))
         {
             if (sweep_level_dim_hint <= 12)

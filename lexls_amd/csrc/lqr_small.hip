@@ -38,6 +38,7 @@ namespace lexls
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed)
     {
         (void)has_fixed; // fixed variables are handled in-kernel
+        if (a.reg_type == 7) return false; // the experimental type's by-products need the level lists: generic kernel (lexls_regularize.h)
         return a.nVar + 1 <= 64 && max_rows <= 64 && max_level_dim <= 16 && a.nObj <= 16;
     }
 

@@ -219,6 +219,15 @@ class BatchedLexLSE:
         capi.check(capi.lib().lexls_lse_get_v(self._h, _ptr(v, C.c_double)))
         return v
 
+    def get_mu(self):
+        """(X_mu, X_mu_rhs, residual_mu) of REGULARIZATION_TIKHONOV_1 (lexlse.h:1636-1650): (batch, nObj, nVar) twice — row k is the
+        reference's column k — and (batch, cap)."""
+        xm = np.zeros((self.batch, self.nObj, self.nVar))
+        xr = np.zeros((self.batch, self.nObj, self.nVar))
+        rm = np.zeros((self.batch, self.cap))
+        capi.check(capi.lib().lexls_lse_get_mu(self._h, _ptr(xm, C.c_double), _ptr(xr, C.c_double), _ptr(rm, C.c_double)))
+        return xm, xr, rm
+
     def getWorkspace(self):
         """[lambda_fixed; lambda] of the last ObjectiveSensitivity call, shape (batch, nVar+cap)."""
         lam = np.zeros((self.batch, self.nVar + self.cap))

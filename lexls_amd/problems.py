@@ -95,6 +95,67 @@ def rank_deficient_problem(seed: int, nvar: int, dims, ranks) -> np.ndarray:
     return np.ascontiguousarray(stacked.T)
 
 
+def lexlse_suite_problem(seed: int, nvar: int, dims, ranks, fixed_variables: bool):
+    """The random problem of the reference's manual lexlse suite (interfaces/matlab-octave/tests/lexlse/define_problem.m:29-55):
+    as rank_deficient_problem, but with `fixed_variables` the first level fixes dims[0] distinct variables to random values.
+    Returns (blocks, fixed): blocks = [A_k | b_k] of the general levels, fixed = (indices, values) or None."""
+    dims, ranks = list(dims), list(ranks)
+    C = np.zeros((0, nvar))
+    blocks, fixed, stream = [], None, 0
+    for k, (m_k, r_k) in enumerate(zip(dims, ranks)):
+        if fixed_variables and k == 0:
+            idx = np.argsort(uniform(seed, nvar, 1000), kind="stable")[:m_k]
+            A = np.zeros((m_k, nvar))
+            A[np.arange(m_k), idx] = 1.0
+            fixed = (idx.astype(np.uint32), normal(seed, m_k, 1001))
+            C = np.vstack([C, A])
+            continue
+        g = normal(seed, m_k * (C.shape[0] + r_k), stream).reshape(m_k, C.shape[0] + r_k)
+        fresh = normal(seed, r_k * nvar, stream + 1).reshape(r_k, nvar)
+        b = normal(seed, m_k, stream + 2)
+        stream += 3
+        A = g @ np.vstack([C, fresh])
+        blocks.append(np.hstack([A, b[:, None]]))
+        C = np.vstack([C, A])
+        s = np.abs(C).max()
+        if s > 1:
+            C = C / s
+    return blocks, fixed
+
+
+def lexlse_suite_options():
+    """The 42 option sets of test_lexlse_define.m: (get_least_norm_solution, enable_fixed_variables, regularization_type, factors).
+    Types: TIKHONOV 1, TIKHONOV_1 7, TIKHONOV_2 8 with least-norm options 0-3; R 3, R_NO_Z 4, RT_NO_Z 5 with options 0-2."""
+    out = []
+    for t in (1, 7, 8):
+        out.append((0, 0, t, (1, 2, 3, 4)))
+        out += [(ln, fx, t, (0, 2, 3, 4)) for ln, fx in ((0, 1), (1, 1), (1, 0), (2, 1), (2, 0), (3, 1), (3, 0))]
+    for t in (3, 4, 5):
+        out += [(ln, fx, t, (0, 2, 3, 4)) for ln in (0, 1, 2) for fx in (1, 0)]
+    return out
+
+
+def lexlse_suite_general_form(nvar: int, blocks, fixed, factors, least_norm: int):
+    """fixed2general.m + append_terminal_objective.m: the fixed variables as a first level of unit rows, and — when a least-norm solution
+    is asked for — a terminal level I x = 0 with factor 0.  Returns (blocks, factors) of the equivalent general problem, which is solved
+    with solve()."""
+    gblocks, gfac = list(blocks), list(factors)
+    if fixed is not None:
+        A1 = np.zeros((len(fixed[0]), nvar + 1))
+        A1[np.arange(len(fixed[0])), fixed[0]] = 1.0
+        A1[:, nvar] = fixed[1]
+        gblocks = [A1] + gblocks
+    if least_norm:
+        gblocks = gblocks + [np.hstack([np.eye(nvar), np.zeros((nvar, 1))])]
+        gfac = gfac + [0.0]
+    return gblocks, gfac
+
+
+def stack_levels(blocks) -> np.ndarray:
+    """[A_k | b_k] blocks -> one (nVar+1, cap) problem in the layout of this package."""
+    return np.ascontiguousarray(np.vstack(blocks).T)
+
+
 def levels_of(lod: np.ndarray, dims):
     """Split an (nVar+1, cap) problem into [(A_k, b_k)]."""
     out, r = [], 0

@@ -12,7 +12,10 @@
 //   * tests/golden/test_01.dat `#Solution` (the reference's own fixture): x* of a 5-level LexLSI
 //     problem, reproduced through this class + the host driver (tests/test_oracle_golden.py);
 //   * the reference's closed-form multiplier KAT (interfaces/matlab-octave/tests/lexlsi/lambda_test.m);
-//   * an independent numpy solver that does not follow the l-QR algorithm (oracle/oracle_np.py).
+//   * an independent numpy solver that does not follow the l-QR algorithm (oracle/oracle_np.py);
+//   * the reference's manual acceptance suite of the equality solver (interfaces/matlab-octave/tests/lexlse/test_lexlse_main.m, 42 option
+//     sets of test_lexlse_define.m, tol 1e-10): fixed variables, solveLeastNorm_1/2/3 and six regularization types (1, 3, 4, 5, 7, 8)
+//     against the equivalent general formulation, and Tikhonov against seq_lexls.m (tests/test_oracle_golden.py::test_reference_lexlse_suite).
 // Factor internals (pivot order, Householder scalars, Gauss multipliers) are "parity unpinned":
 // this file DEFINES them.  Eigen primitive semantics follow the reference's in-tree MATLAB
 // restatements (interfaces/matlab-octave/tests/implementation/lexqr/eigen_like_syntax/*.m).
@@ -142,6 +145,9 @@ namespace lexls_oracle
             PROBLEM_DATA.resize(cap, nVar + 1);
             dWorkspace.resize(2 * std::max(cap, nVar) + nVar + 1);
             null_space.resize(nVar, nVar + 1);
+            X_mu.resize(nVar, nObj);     // :96-99
+            X_mu_rhs.resize(nVar, nObj);
+            residual_mu.resize(cap);
             column_permutations.resize(nVar);
             nCtr      = 0;
             TotalRank = 0;
@@ -272,6 +278,8 @@ namespace lexls_oracle
                 const Index Fc  = obj_info[ObjIndex].first_col_index = ColIndex;
                 const Index dim = obj_info[ObjIndex].dim;
 
+                for (Index i = 0; i < dim; i++) residual_mu(F + i) = LOD(F + i, n); // :191 (after the eliminations, before the reflectors)
+
                 for (Index k = ColIndex; k < n; k++) ColNorms[k] = sqnorm(&LOD(F, k), dim); // :193-196
 
                 for (Index counter = 0; counter < dim; counter++) // :199
@@ -345,7 +353,16 @@ namespace lexls_oracle
 
                 if (RemainingColumns == 0) // :475-490
                 {
-                    for (Index k = ObjIndex + 1; k < nObj; k++) obj_info[k].first_col_index = obj_info[k - 1].first_col_index + obj_info[k - 1].rank;
+                    for (Index k = ObjIndex + 1; k < nObj; k++)
+                    {
+                        obj_info[k].first_col_index = obj_info[k - 1].first_col_index + obj_info[k - 1].rank;
+                        for (Index i = 0; i < n; i++) // :483-486
+                        {
+                            X_mu(i, k)     = X_mu(i, k - 1);
+                            X_mu_rhs(i, k) = X_mu_rhs(i, k - 1);
+                        }
+                        for (Index i = 0; i < obj_info[k].dim; i++) residual_mu(obj_info[k].first_row_index + i) = -LOD(obj_info[k].first_row_index + i, n);
+                    }
                     break;
                 }
             }
@@ -683,6 +700,9 @@ namespace lexls_oracle
         const iVectorType &getFixedVarIndex() const { return fixed_var_index; }
         const dVectorType &getWorkspace() const { return dWorkspace; }
         const dMatrixType &get_lexqr() const { return LOD; }
+        const dMatrixType &get_X_mu() const { return X_mu; }         // :1636-1650
+        const dMatrixType &get_X_mu_rhs() const { return X_mu_rhs; }
+        const dVectorType &get_residual_mu() const { return residual_mu; }
         const dMatrixType &get_data() const { return PROBLEM_DATA; }
         const dVectorType &get_hh_scalars() const { return hh_scalars; }
         const iVectorType &get_column_permutations() const { return column_permutations; }
@@ -708,12 +728,16 @@ namespace lexls_oracle
             }
             hh_scalars.setZero();
             null_space.setZero(); // :1686
+            X_mu.setZero();       // :1687-1689
+            X_mu_rhs.setZero();
+            residual_mu.setZero();
             for (Index i = nVarFixed; i < nVar; i++) x(i) = 0.0;
         }
 
         // ------------------------------------------------------------------------------------------
         // Regularization family (lexlse.h:277-411, :1700-2554, :2592-2625).  Restated: TIKHONOV (1), TIKHONOV_CG (2), R (3), R_NO_Z (4),
-        // RT_NO_Z (5), RT_NO_Z_CG (6), TIKHONOV_2 (8), TEST (9); the experimental TIKHONOV_1 (7) is not.
+        // RT_NO_Z (5), RT_NO_Z_CG (6), TIKHONOV_1 (7, the reference's experimental type: regularize_tikhonov_1_test with the X_mu /
+        // residual_mu by-products that its ObjectiveSensitivity then uses, :647-651, :799-803), TIKHONOV_2 (8), TEST (9).
         // Arithmetic contract of what Eigen leaves open: every product entry is an ascending fma chain from 0 over the contraction
         // index; "X += s * P" is fma(s, p, x) on the finished entry p; "X -= A*B" accumulates fma(-a, b, x) into x (as the Gauss
         // update does); right-side triangular solves scale by the reciprocal of the diagonal (as the Gauss TRSM does); Cholesky and
@@ -729,9 +753,10 @@ namespace lexls_oracle
             case REGULARIZATION_R_NO_Z:
             case REGULARIZATION_RT_NO_Z:
             case REGULARIZATION_RT_NO_Z_CG:
+            case REGULARIZATION_TIKHONOV_1:
             case REGULARIZATION_TIKHONOV_2:
             case REGULARIZATION_TEST: return;
-            default: throw Exception("oracle: REGULARIZATION_TIKHONOV_1 (experimental) is not restated");
+            default: throw Exception("oracle: unknown regularization type");
             }
         }
 
@@ -859,6 +884,10 @@ namespace lexls_oracle
                 }
                 accumulate_nullspace_basis(F, Fc, rank, RC);
                 break;
+            case REGULARIZATION_TIKHONOV_1: // :378-387
+                if (nonzero) regularize_tikhonov_1_test(F, Fc, rank, RC, ObjIndex);
+                accumulate_nullspace_basis(F, Fc, rank, RC);
+                break;
             case REGULARIZATION_TIKHONOV_2:
                 if (nonzero) regularize_tikhonov_2(F, Fc, rank, RC);
                 accumulate_nullspace_basis(F, Fc, rank, RC);
@@ -889,7 +918,7 @@ namespace lexls_oracle
         }
 
         /// lexlse.h:1700-1760
-        void regularize_tikhonov_1(Index F, Index Fc, Index rank, Index RC)
+        void regularize_tikhonov_1(Index F, Index Fc, Index rank, Index RC, std::vector<double> *solution = NULL)
         {
             const double mu = aRegularizationFactor * aRegularizationFactor;
             const Index m0 = Fc - nVarFixed, N = RC + rank;
@@ -940,6 +969,90 @@ namespace lexls_oracle
                 out[i] = R_times(F, Fc, rank, i, d) + t;
             }
             for (Index i = 0; i < rank; i++) LOD(F + i, nVar) = out[i];
+            if (solution) solution->swap(d);
+        }
+
+        /// lexlse.h:1774-1886: regularize_tikhonov_1 plus the by-products of the experimental type 7 — the residual of the regularized
+        /// level (residual_mu), the regularized solution of the levels 0..ObjIndex (a column of X_mu, get_intermediate_x :2010-2071).
+        /// The permutation at the end counts the ranks without the fixed variables, as the reference does ("WARNING: how about fixed
+        /// variables", :189).
+        void regularize_tikhonov_1_test(Index F, Index Fc, Index rank, Index RC, Index ObjIndex)
+        {
+            const Index dim = obj_info[ObjIndex].dim, N = RC + rank;
+            std::vector<double> d;
+            regularize_tikhonov_1(F, Fc, rank, RC, &d);
+
+            std::vector<double> w(dim, 0.0); // Q1 [R T] d - b  (:1848-1854)
+            for (Index i = 0; i < rank; i++) w[i] = LOD(F + i, nVar);
+            apply_q(ObjIndex, w.data());
+            for (Index i = 0; i < dim; i++) residual_mu(F + i) = w[i] - residual_mu(F + i);
+
+            for (Index i = 0; i < N; i++) X_mu(nVar - N + i, ObjIndex) = d[i]; // :1857
+            for (Index i = 0; i < ObjIndex; i++)                               // get_intermediate_x, :2026-2040
+            {
+                const Index Fi = obj_info[i].first_row_index, Fci = obj_info[i].first_col_index, ri = obj_info[i].rank;
+                for (Index r = 0; r < ri; r++)
+                {
+                    double acc = 0.0;
+                    for (Index c = 0; c < N; c++) acc = std::fma(LOD(Fi + r, nVar - N + c), X_mu(nVar - N + c, ObjIndex), acc);
+                    X_mu(Fci + r, ObjIndex) = LOD(Fi + r, nVar) - acc;
+                }
+            }
+            Index acc_ranks = 0;
+            for (Index k = ObjIndex; k--;) // :2046-2070
+            {
+                const Index Fk = obj_info[k].first_row_index, Fck = obj_info[k].first_col_index, rk = obj_info[k].rank;
+                if (rk == 0) continue;
+                if (acc_ranks > 0)
+                {
+                    const Index c0 = obj_info[k + 1].first_col_index;
+                    for (Index i = 0; i < rk; i++)
+                    {
+                        double s2 = X_mu(Fck + i, ObjIndex);
+                        for (Index j = 0; j < acc_ranks; j++) s2 = std::fma(-LOD(Fk + i, c0 + j), X_mu(c0 + j, ObjIndex), s2);
+                        X_mu(Fck + i, ObjIndex) = s2;
+                    }
+                }
+                back_substitute(Fk, Fck, rk, &X_mu(Fck, ObjIndex));
+                acc_ranks += rk;
+            }
+            Index total = 0; // :1863-1874
+            for (Index k = 0; k <= ObjIndex; k++) total += obj_info[k].rank;
+            for (Index k = total; k--;) std::swap(X_mu(k, ObjIndex), X_mu(column_permutations(k), ObjIndex));
+        }
+
+        /// lexlse.h:1921-1959: right-hand side of the dual solve of the experimental type 7
+        void initialize_rhs(Index ObjIndex, double *rhs, Index rhs_size)
+        {
+            const double f = obj_info[ObjIndex].regularization_factor;
+            aRegularizationFactor = f;
+            double *c = &X_mu_rhs(0, ObjIndex);
+            for (Index i = 0; i < nVar; i++) c[i] = X_mu(i, ObjIndex);
+            for (Index k = 0; k < TotalRank; k++) std::swap(c[k], c[column_permutations(k)]); // P' * .
+            for (Index i = 0; i < nVar; i++) c[i] *= -f * f;
+            const Index last = obj_info[ObjIndex].first_col_index + obj_info[ObjIndex].rank; // one past the last column of interest
+            for (Index k = 0; k <= ObjIndex; k++)
+            {
+                const Index Fk = obj_info[k].first_row_index, Fck = obj_info[k].first_col_index, rk = obj_info[k].rank;
+                if (k > 0)
+                {
+                    const Index Fp = obj_info[k - 1].first_row_index, Fcp = obj_info[k - 1].first_col_index, rp = obj_info[k - 1].rank;
+                    const Index remain = last - Fck;
+                    for (Index j = 0; j < remain; j++)
+                    {
+                        double s2 = c[Fck + j];
+                        for (Index i = 0; i < rp; i++) s2 = std::fma(-LOD(Fp + i, Fck + j), c[Fcp + i], s2);
+                        c[Fck + j] = s2;
+                    }
+                }
+                for (Index j = 0; j < rk; j++) // R_k' z = c (forward substitution with the transposed upper triangle)
+                {
+                    double s2 = c[Fck + j];
+                    for (Index i = 0; i < j; i++) s2 = std::fma(-LOD(Fk + i, Fck + j), c[Fck + i], s2);
+                    c[Fck + j] = s2 / LOD(Fk + j, Fck + j);
+                }
+            }
+            for (Index i = 0; i < rhs_size; i++) rhs[i] = c[i];
         }
 
         /// lexlse.h:2076-2133
@@ -1208,6 +1321,12 @@ namespace lexls_oracle
             rhs         = w + nVarFixed + nLambda;
 
             const Index F = obj_info[ObjIndex].first_row_index, dim = obj_info[ObjIndex].dim, rank = obj_info[ObjIndex].rank;
+            if (parameters.regularization_type == REGULARIZATION_TIKHONOV_1) // :647-651, :688-690 ("WARNING: TESTING" in the reference)
+            {
+                initialize_rhs(ObjIndex, rhs, nRank + nVarFixed);
+                for (Index i = 0; i < dim; i++) Lambda[F + i] = residual_mu(F + i);
+                return;
+            }
             for (Index i = rank; i < dim; i++) Lambda[F + i] = -LOD(F + i, nVar);
             apply_q(ObjIndex, Lambda + F);
         }
@@ -1290,6 +1409,8 @@ namespace lexls_oracle
         Index nVar, nObj, nCtr, nVarFixed, nVarFixedInit, TotalRank;
         ParametersLexLSE parameters;
         std::vector<internal::ObjectiveInfo> obj_info;
+        dMatrixType X_mu, X_mu_rhs; // by-products of the experimental REGULARIZATION_TIKHONOV_1 (lexlse.h:96-99)
+        dVectorType residual_mu;
         dMatrixType LOD, PROBLEM_DATA, null_space; // null_space: nVar x (nVar+1), basis accumulated for the regularization (lexlse.h:93)
         double aRegularizationFactor = 0.0;
         dVectorType x, hh_scalars, dWorkspace;

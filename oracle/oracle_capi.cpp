@@ -54,6 +54,7 @@ namespace
         std::vector<double> factors;
         double variable = 0.0;
         unsigned cg_iterations = 10; // typedefs.h:170
+        double *x_mu = NULL, *x_mu_rhs = NULL, *residual_mu = NULL; // by-products of type 7 (batch x nObj x nVar, same, batch x cap)
     } g_reg;
 
     void run_one(const LseBatchArgs &a, uint32_t b, OLSE &lse, uint32_t cap)
@@ -128,6 +129,14 @@ namespace
             if (a.ctr_type_out)
                 for (uint32_t i = 0; i < cap; i++) a.ctr_type_out[static_cast<size_t>(b) * cap + i] = static_cast<uint8_t>(lse.get_ctr_type()[i]);
         }
+        for (uint32_t k = 0; k < a.nObj; k++) // after the sensitivity call: its initialize_rhs() fills a column of X_mu_rhs
+            for (uint32_t i = 0; i < n; i++)
+            {
+                if (g_reg.x_mu) g_reg.x_mu[(static_cast<size_t>(b) * a.nObj + k) * n + i] = lse.get_X_mu()(i, k);
+                if (g_reg.x_mu_rhs) g_reg.x_mu_rhs[(static_cast<size_t>(b) * a.nObj + k) * n + i] = lse.get_X_mu_rhs()(i, k);
+            }
+        if (g_reg.residual_mu)
+            for (uint32_t i = 0; i < cap; i++) g_reg.residual_mu[static_cast<size_t>(b) * cap + i] = lse.get_residual_mu()(i);
     }
 
     int run_range(const LseBatchArgs &a, uint32_t b0, uint32_t b1)
@@ -159,6 +168,15 @@ extern "C"
         g_reg.type = type;
         g_reg.factors.assign(factors ? factors : NULL, factors ? factors + nObj : NULL);
         g_reg.variable = variable_factor;
+    }
+
+    /// where the following oracle_lse_run calls leave X_mu / X_mu_rhs (batch x nObj x nVar: column k of problem b is contiguous) and
+    /// residual_mu (batch x cap), lexlse.h:1636-1650; NULL = not wanted
+    void oracle_lse_set_mu_outputs(double *x_mu, double *x_mu_rhs, double *residual_mu)
+    {
+        g_reg.x_mu        = x_mu;
+        g_reg.x_mu_rhs    = x_mu_rhs;
+        g_reg.residual_mu = residual_mu;
     }
 
     /// factorize (+ solve, + residual, + sensitivity) of a batch of equality problems, `nthreads` host threads

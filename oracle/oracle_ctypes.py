@@ -69,6 +69,9 @@ def lse_run(lod, dims, nvar, maxdim=None, tol=1e-12, nfixed=None, fixed_idx=None
     if ctr_type is not None:
         ctr_type = np.ascontiguousarray(ctr_type, np.uint8)
     rf = None if reg_factors is None else np.ascontiguousarray(reg_factors, np.float64)
+    if int(reg_type) == 7:  # the experimental type's by-products (lexlse.h:1636-1650)
+        out.update(x_mu=np.zeros((batch, nobj, nvar)), x_mu_rhs=np.zeros((batch, nobj, nvar)), residual_mu=np.zeros((batch, cap)))
+        lib().oracle_lse_set_mu_outputs(_p(out["x_mu"], _dp), _p(out["x_mu_rhs"], _dp), _p(out["residual_mu"], _dp))
     lib().oracle_lse_set_regularization(C.c_int(int(reg_type)), C.c_uint32(nobj), _p(rf, _dp), C.c_double(var_reg), C.c_uint32(int(cg_iters)))
     rc = lib().oracle_lse_run(
         C.c_uint32(batch), C.c_uint32(nvar), C.c_uint32(nobj), _p(maxdim, _u32p), _p(dims, _u32p), _p(lod, _dp), C.c_double(tol),
@@ -78,6 +81,7 @@ def lse_run(lod, dims, nvar, maxdim=None, tol=1e-12, nfixed=None, fixed_idx=None
         _p(out["fcol"], _u32p), _p(out["totalrank"], _u32p), _p(out["v"], _dp), _p(out["lam"], _dp), _p(out["sens"], _i32p),
         _p(out["maxabs"], _dp), _p(out["ctr_type_out"], _u8p), C.c_int(nthreads))
     lib().oracle_lse_set_regularization(C.c_int(0), C.c_uint32(0), None, C.c_double(0.0), C.c_uint32(10))
+    lib().oracle_lse_set_mu_outputs(None, None, None)
     if rc:
         raise RuntimeError(lib().oracle_last_error().decode())
     return out

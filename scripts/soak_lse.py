@@ -14,7 +14,7 @@ from test_gpu_parity import assert_factor_equal
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(20261005)
-t0, cases, kernels = time.time(), 0, {}
+t0, cases, kernels, sens_checks = time.time(), 0, {}, 0
 while time.time() - t0 < budget:
     n, cap_dims, dims, batch = _draw(rng)
     batch = batch if rng.random() < 0.7 else int(rng.integers(5, 40))
@@ -42,7 +42,7 @@ while time.time() - t0 < budget:
         fixed = dict(nfixed=nf, fixed_idx=idx, fixed_val=val)
     policy = int(rng.choice([0, 4, 3, 1, 2]))
     keep = bool(rng.random() < 0.5)
-    reg = int(rng.choice([1, 8, 3, 5, 9])) if rng.random() < 0.15 else 0
+    reg = int(rng.choice([1, 8, 3, 5, 9, 7, 2, 4, 6])) if rng.random() < 0.15 else 0
     kw = {}
     fac = None
     if reg:
@@ -73,6 +73,20 @@ while time.time() - t0 < budget:
             pass
         else:
             assert_factor_equal(s, ref, dims, n)
+    if reg == 7:  # by-products of the experimental TIKHONOV_1 (generic kernel)
+        xm, _, rm = s.get_mu()
+        np.testing.assert_array_equal(xm, ref["x_mu"], err_msg=ctx)
+        np.testing.assert_array_equal(rm, ref["residual_mu"], err_msg=ctx)
+    if keep and not k.startswith("lqr_large") and rng.random() < 0.3:  # a removal search on the factor just made (type 7: multipliers of the regularized problem)
+        lvl = int(rng.integers(0, len(cap_dims)))
+        types = rng.integers(1, 4, (batch, cap)).astype(np.uint8)  # LB / UB / EQ
+        ref = oracle.lse_run(lod, dims, n, maxdim=cap_dims, sens_obj=lvl, ctr_type=types, **fixed, **kw)
+        s.setCtrType(types)
+        found, ctr, obj, maxabs = s.ObjectiveSensitivity(lvl)
+        np.testing.assert_array_equal(s.getWorkspace(), ref["lam"], err_msg=ctx + f" sens {lvl}")
+        np.testing.assert_array_equal(np.stack([found.astype(np.int32), ctr, obj], 1), ref["sens"], err_msg=ctx + f" sens {lvl}")
+        np.testing.assert_array_equal(maxabs, ref["maxabs"], err_msg=ctx + f" sens {lvl}")
+        sens_checks += 1
     s.close()
     cases += 1
-print(f"soak ok: {cases} random cases in {time.time() - t0:.0f} s; kernels: " + ", ".join(f"{k} x{v}" for k, v in sorted(kernels.items())))
+print(f"soak ok: {cases} random cases ({sens_checks} with a removal search) in {time.time() - t0:.0f} s; kernels: " + ", ".join(f"{k} x{v}" for k, v in sorted(kernels.items())))

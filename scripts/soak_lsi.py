@@ -24,7 +24,7 @@ while time.time() - t0 < budget:
     if mode in (0, 1):
         kw["max_number_of_factorizations"] = int(rng.integers(1, 8))
     elif mode == 2:  # regularized equality problems: host-side active-set logic, the wave kernel's REG instantiation
-        kw["regularization_type"] = int(rng.choice([1, 8, 3, 5]))
+        kw["regularization_type"] = int(rng.choice([1, 8, 3, 5, 7]))
         kw["regularization_factors"] = (np.abs(rng.normal(size=nobj)) * 0.3 + 0.01) * (rng.random(nobj) < 0.8)
     elif mode == 3:  # cycling handling: host-side logic, problems assembled on the host
         kw.update(cycling_handling_enabled=1, cycling_max_counter=int(rng.integers(2, 6)), cycling_relax_step=1e-6)

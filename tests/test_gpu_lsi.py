@@ -428,17 +428,19 @@ def test_speculative_removal_search(hip, oracle, monkeypatch):
         np.testing.assert_array_equal(spec["x"][b], o["x"])
 
 
-def test_lock_step_batch_with_regularization(hip, oracle):
-    """lexls_lsi_batch_solve_ex: the damped hierarchies of a batch run lock-step on the generic kernel; every instance ends exactly where
-    its stand-alone oracle-backed solve with the same regularization ends."""
+@pytest.mark.parametrize("reg_type", [1, 7])
+def test_lock_step_batch_with_regularization(hip, oracle, reg_type):
+    """lexls_lsi_batch_solve_ex: the damped hierarchies of a batch run lock-step (host-side active-set logic, regularized equality
+    kernels); every instance ends exactly where its stand-alone oracle-backed solve with the same regularization ends.  Type 7 is the
+    reference's experimental TIKHONOV_1, whose removal search uses the multipliers of the regularized problem (lexlse.h:647-651)."""
     n, dims, batch = 20, [6, 5, 5, 6], 12
     factors = [0, 0.3, 0.2, 0.4]
     problems = [P.lsi_problem(700 + b, n, dims) for b in range(batch)]
-    r = lexlsi.lsi_batch_solve(n, problems, regularization_type=1, regularization_factors=factors)
+    r = lexlsi.lsi_batch_solve(n, problems, regularization_type=reg_type, regularization_factors=factors)
     plain = lexlsi.lsi_batch_solve(n, problems)
     assert np.abs(plain["x"] - r["x"]).max() > 1e-6
     for b in range(batch):
-        o = oracle.lsi_run(n, problems[b], regularization_type=1, regularization_factors=factors)
+        o = oracle.lsi_run(n, problems[b], regularization_type=reg_type, regularization_factors=factors)
         assert r["info"][b] == o["info"], b
         np.testing.assert_array_equal(r["x"][b], o["x"])
         np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))

@@ -599,7 +599,7 @@ def test_least_norm_normal_equations(hip, oracle):
 
 
 @pytest.mark.parametrize("policy", [0, 1], ids=["wave-kernel", "generic-kernel"])
-@pytest.mark.parametrize("reg_type", [1, 2, 3, 4, 5, 6, 8, 9])
+@pytest.mark.parametrize("reg_type", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_regularization_family_bit_exact(hip, oracle, reg_type, policy):
     """lexlse.h:277-411 on the device — in the register-resident wave kernel's REG instantiation (default for these shapes: the routines of
     lexls_regularize.h work on the level's LDS image) and in the generic kernel: bit-identical to the oracle for every implemented type,
@@ -624,9 +624,14 @@ def test_regularization_family_bit_exact(hip, oracle, reg_type, policy):
         s.fixVariables(nfixed[b:b + 1], idx[b:b + 1], val[b:b + 1])
         s.setProblem(lod[b:b + 1])
         s.factorize_solve()
-        assert s.last_kernel().startswith("lqr_generic" if policy == 1 else "lqr_wave<41,12,regularized>")
+        # (the experimental type 7 needs the level lists for its by-products: generic kernel whatever the policy)
+        assert s.last_kernel().startswith("lqr_generic" if policy == 1 or reg_type == 7 else "lqr_wave<41,12,regularized>")
         assert_factor_equal(s, ref, dims, n)
         np.testing.assert_array_equal(s.get_x(), ref["x"])
+        if reg_type == 7:
+            xm, _, rm = s.get_mu()
+            np.testing.assert_array_equal(xm, ref["x_mu"])
+            np.testing.assert_array_equal(rm, ref["residual_mu"])
     # the whole batch at once with per-problem factors gives the same solutions
     s = hip.BatchedLexLSE(batch, n, dims)
     s.set_kernel_policy(policy)
@@ -720,7 +725,9 @@ def test_regularization_variable_factor_and_least_norm_3(hip, oracle):
     with pytest.raises(hip.LexlsError):
         s.solveLeastNorm_3()
     with pytest.raises(hip.LexlsError):
-        s.setRegularization(7)  # the experimental TIKHONOV_1 has no device path
+        s.setRegularization(10)  # not a LexLS::RegularizationType (typedefs.h:34-43)
+    with pytest.raises(hip.LexlsError):
+        s.get_mu()  # X_mu / residual_mu exist with REGULARIZATION_TIKHONOV_1 only
 
 
 def test_full_size_batch_4096(hip, oracle):
@@ -754,3 +761,80 @@ def test_error_behaviour(hip):
         s.setObjDim([3, 2])  # exceeds capacity
     with pytest.raises(Exception):
         s.solve()  # no factorization
+
+
+# --- the reference's manual lexlse suite on the device (interfaces/matlab-octave/tests/lexlse/test_lexlse_main.m) ---------------------
+def device_lse_run(hip, lod, dims, n, reg_type=0, reg_factors=None, solve_option=0, nfixed=None, fixed_idx=None, fixed_val=None):
+    """the call sequence of the MEX front end (interfaces/matlab-octave/lexlse.cpp:144-199) through the C ABI, one problem"""
+    s = hip.BatchedLexLSE(lod.shape[0], n, dims)
+    if reg_type:
+        s.setRegularization(reg_type, np.asarray(reg_factors, float))
+    if nfixed is not None:
+        s.fixVariables(nfixed, fixed_idx, fixed_val)
+    s.setProblem(lod)
+    s.factorize()
+    [s.solve, s.solveLeastNorm_1, s.solveLeastNorm_2, s.solveLeastNorm_3][solve_option]()
+    return {"x": s.get_x()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("least_norm,fixed_variables,reg_type,factors", P.lexlse_suite_options(),
+                         ids=["ln%d-fix%d-type%d-f%d" % (o[0], o[1], o[2], o[3][0]) for o in P.lexlse_suite_options()])
+def test_reference_lexlse_suite(hip, oracle, least_norm, fixed_variables, reg_type, factors):
+    """The 42 option sets of test_lexlse_define.m (n = 30, m = [9,8,10,6], r = [7,6,8,5]) through the C ABI: the fixed-variable / least-norm
+    formulation equals the general one with a terminal objective to the suite's 1e-10 (test_lexlse_main.m:20, compare_results.m), and both
+    device solutions are bit-identical to the oracle's."""
+    from test_oracle_golden import SUITE_N, SUITE_M, SUITE_R, SUITE_TOL, suite_solve
+    n = SUITE_N
+    for seed in (1, 2):
+        blocks, fixed = P.lexlse_suite_problem(seed, n, SUITE_M, SUITE_R, bool(fixed_variables))
+        gblocks, gfac = P.lexlse_suite_general_form(n, blocks, fixed, factors, least_norm)
+        dev = lambda *a, **k: device_lse_run(hip, *a, **k)
+        f1 = factors[1:] if fixed_variables else factors
+        x1 = suite_solve(dev, n, blocks, fixed, reg_type, f1, least_norm)
+        x2 = suite_solve(dev, n, gblocks, None, reg_type, gfac, 0)
+        np.testing.assert_array_equal(x1, suite_solve(oracle.lse_run, n, blocks, fixed, reg_type, f1, least_norm))
+        np.testing.assert_array_equal(x2, suite_solve(oracle.lse_run, n, gblocks, None, reg_type, gfac, 0))
+        assert np.linalg.norm(x1 - x2) <= SUITE_TOL
+        for g in gblocks:
+            assert np.linalg.norm((g[:, :n] @ x1 - g[:, n]) - (g[:, :n] @ x2 - g[:, n])) <= SUITE_TOL
+
+
+@pytest.mark.gpu
+def test_tikhonov_1_sensitivity_and_byproducts(hip, oracle):
+    """REGULARIZATION_TIKHONOV_1 (type 7, experimental in the reference): X_mu, residual_mu and — after ObjectiveSensitivity, which for
+    this type starts from initialize_rhs and residual_mu (lexlse.h:647-651, :688-690, :1921-1959) — X_mu_rhs, the multipliers, the
+    verdict and the CORRECT_SIGN marks are bit-identical to the oracle; rank-deficient and fixed-variable problems, a level with factor 0,
+    a hierarchy whose columns run out (the copies of lexlse.h:483-486)."""
+    cases = [(12, [4, 5, 3], None, [0.0, 0.7, 0.4], 0), (12, [4, 5, 6], None, [0.5, 0.7, 0.4], 2), (10, [3, 3, 3], [2, 3, 2], [0.3, 0.0, 0.6], 0),
+             (9, [4, 5, 3, 2], None, [0.2, 0.3, 0.4, 0.5], 1)]
+    for (n, dims, ranks, fac, nfix) in cases:
+        batch = 3
+        lod = np.stack([(P.rank_deficient_problem(30 + b, n, dims, ranks) if ranks else P.lse_problem(30 + b, n, dims)) for b in range(batch)])
+        nfixed = np.full(batch, nfix, np.uint32)
+        idx = np.zeros((batch, n), np.uint32)
+        idx[:, :2] = [5, 1]
+        val = np.zeros((batch, n))
+        val[:, :2] = P.normal(31, 2)
+        types = (np.arange(batch * sum(dims)).reshape(batch, -1) % 3 + 1).astype(np.uint8)  # LB / UB / EQ mix
+        for k in range(len(dims)):
+            ref = oracle.lse_run(lod, dims, n, reg_type=7, reg_factors=fac, sens_obj=k, nfixed=nfixed, fixed_idx=idx, fixed_val=val, ctr_type=types)
+            s = hip.BatchedLexLSE(batch, n, dims)
+            s.setRegularization(7, np.asarray(fac))
+            s.fixVariables(nfixed, idx, val)
+            s.setCtrType(types)
+            s.setProblem(lod)
+            s.factorize_solve()
+            assert s.last_kernel().startswith("lqr_generic")
+            np.testing.assert_array_equal(s.get_x(), ref["x"])
+            found, ctr, obj, maxabs = s.ObjectiveSensitivity(k)
+            xm, xr, rm = s.get_mu()
+            np.testing.assert_array_equal(xm, ref["x_mu"])
+            np.testing.assert_array_equal(rm, ref["residual_mu"])
+            np.testing.assert_array_equal(xr, ref["x_mu_rhs"])
+            np.testing.assert_array_equal(s.getWorkspace(), ref["lam"])
+            np.testing.assert_array_equal(found.astype(np.int32), ref["sens"][:, 0])
+            np.testing.assert_array_equal(ctr, ref["sens"][:, 1])
+            np.testing.assert_array_equal(obj, ref["sens"][:, 2])
+            np.testing.assert_array_equal(maxabs, ref["maxabs"])
+            np.testing.assert_array_equal(s.getCtrType(), ref["ctr_type_out"])

@@ -253,3 +253,88 @@ def test_removal_path_closed_form(oracle):
     # column of objective 1: [multipliers of level 0; residual of level 1]; sign convention of the reference: lambda = -(stationarity multiplier)
     np.testing.assert_allclose(np.abs(L[:4, 1]), np.abs(lam), atol=1e-13)
     assert (np.sign(L[:4, 1]) == np.sign(L[0, 1]) * np.sign(lam) * np.sign(lam[0])).all()
+
+
+# --- the reference's manual lexlse suite (interfaces/matlab-octave/tests/lexlse/test_lexlse_main.m) ----------------------------------
+SUITE_N, SUITE_M, SUITE_R, SUITE_TOL = 30, (9, 8, 10, 6), (7, 6, 8, 5), 1e-10  # test_lexlse_main.m:16-20
+
+
+def suite_solve(run, n, blocks, fixed, reg_type, factors, least_norm):
+    """x of one `lexlse(obj, options)` call of the MEX front end (interfaces/matlab-octave/lexlse.cpp:144-199) through `run`"""
+    dims = [b.shape[0] for b in blocks]
+    kw = dict(reg_type=reg_type, reg_factors=np.asarray(factors, float), solve_option=least_norm)
+    if fixed is not None:
+        nf = len(fixed[0])
+        idx, val = np.zeros((1, n), np.uint32), np.zeros((1, n))
+        idx[0, :nf], val[0, :nf] = fixed
+        kw.update(nfixed=np.array([nf], np.uint32), fixed_idx=idx, fixed_val=val)
+    return run(P.stack_levels(blocks)[None], dims, n, **kw)["x"][0]
+
+
+def suite_case(run, seed, least_norm, fixed_variables, reg_type, factors):
+    """test_lexlse.m:13-20 + compare_results.m: the fixed-variable formulation against the general one (+ terminal objective); returns
+    (|x1 - x2|, largest per-level residual difference)"""
+    n = SUITE_N
+    blocks, fixed = P.lexlse_suite_problem(seed, n, SUITE_M, SUITE_R, bool(fixed_variables))
+    x1 = suite_solve(run, n, blocks, fixed, reg_type, factors[1:] if fixed_variables else factors, least_norm)
+    gblocks, gfac = P.lexlse_suite_general_form(n, blocks, fixed, factors, least_norm)
+    x2 = suite_solve(run, n, gblocks, None, reg_type, gfac, 0)
+    err_r = max(np.linalg.norm((g[:, :n] @ x1 - g[:, n]) - (g[:, :n] @ x2 - g[:, n])) for g in gblocks)
+    return np.linalg.norm(x1 - x2), err_r
+
+
+@pytest.mark.parametrize("least_norm,fixed_variables,reg_type,factors", P.lexlse_suite_options(),
+                         ids=["ln%d-fix%d-type%d-f%d" % (o[0], o[1], o[2], o[3][0]) for o in P.lexlse_suite_options()])
+def test_reference_lexlse_suite(oracle, least_norm, fixed_variables, reg_type, factors):
+    """The 42 option sets of test_lexlse_define.m on the suite's problem (n = 30, m = [9,8,10,6], r = [7,6,8,5], tol 1e-10): solving with
+    fixed variables / a least-norm routine equals solving the general formulation with a terminal objective — for every regularization type
+    of the suite, the experimental TIKHONOV_1 (7) included.  This is the reference's own acceptance test of the regularization family."""
+    for seed in (1, 2, 3):
+        err_x, err_r = suite_case(oracle.lse_run, seed, least_norm, fixed_variables, reg_type, factors)
+        assert err_x <= SUITE_TOL and err_r <= SUITE_TOL, (seed, err_x, err_r)
+
+
+def test_tikhonov_against_the_sequence_of_stacked_problems(oracle):
+    """test_lexlse_main.m:22-49 with seq_lexls.m: Tikhonov regularization of every level == a sequence of two-level problems
+    [upper levels kept at their values ; A_k stacked over mu_k I]; the per-level residuals agree to 1e-10 (x may differ, :41-43)."""
+    n, mu = SUITE_N, (1.0, 2.0, 3.0, 4.0)
+    for seed in (1, 2):
+        blocks, _ = P.lexlse_suite_problem(seed, n, SUITE_M, SUITE_R, False)
+        x1 = suite_solve(oracle.lse_run, n, blocks, None, 1, mu, 0)
+        x, eye = None, np.hstack([np.eye(n), np.zeros((n, 1))])
+        for k, blk in enumerate(blocks):
+            reg = np.vstack([blk, eye * 1.0])
+            reg[blk.shape[0]:, :n] *= mu[k]
+            if k == 0:
+                levels = [reg]
+            else:
+                C = np.vstack([b[:, :n] for b in blocks[:k]])
+                levels = [np.hstack([C, (C @ x)[:, None]]), reg]
+            x = oracle.lse_run(P.stack_levels(levels)[None], [l.shape[0] for l in levels], n)["x"][0]
+        err = [np.linalg.norm((b[:, :n] @ x1 - b[:, n]) - (b[:, :n] @ x - b[:, n])) for b in blocks]
+        assert np.linalg.norm(err) <= SUITE_TOL, err
+
+
+def test_tikhonov_1_byproducts_satisfy_the_regularized_optimality_conditions(oracle):
+    """REGULARIZATION_TIKHONOV_1 (the reference's experimental type 7, lexlse.h:1774-1886) has no fixture; what pins the restatement of
+    its by-products: for a level k with a non-zero factor, residual_mu is the residual of level k at X_mu(:,k); the multipliers its
+    ObjectiveSensitivity returns (:647-651, :688-690, initialize_rhs :1921-1959) make the Lagrangian of the regularized problem
+    stationary, sum_{j<=k} A_j' lambda_j + mu_k^2 X_mu(:,k) = 0; with no free column left X_mu of the last level is x."""
+    for (n, dims, ranks, fac) in [(12, [4, 5, 3], None, [0.0, 0.7, 0.4]), (12, [4, 5, 6], None, [0.5, 0.7, 0.4]), (10, [3, 3, 3], [2, 3, 2], [0.3, 0.0, 0.6])]:
+        lod = (P.rank_deficient_problem(3, n, dims, ranks) if ranks else P.lse_problem(3, n, dims))[None]
+        lv = P.levels_of(lod[0], dims)
+        for k in range(len(dims)):
+            r = oracle.lse_run(lod, dims, n, reg_type=7, reg_factors=fac, sens_obj=k)
+            X, rm, lam = r["x_mu"][0], r["residual_mu"][0], r["lam"][0]
+            if fac[k] == 0.0:  # a level the routine does not enter keeps X_mu = 0 and residual_mu = +rhs (the reference's \todo, :1768-1770)
+                assert not X[k].any()
+                continue
+            off = sum(dims[:k])
+            np.testing.assert_allclose(lv[k][0] @ X[k] - lv[k][1], rm[off:off + dims[k]], atol=1e-12)
+            g, o = fac[k] ** 2 * X[k], 0
+            for j in range(k + 1):
+                g = g + lv[j][0].T @ lam[o:o + dims[j]]
+                o += dims[j]
+            np.testing.assert_allclose(g, 0, atol=1e-11)
+        if sum(r["rank"][0]) == n:
+            np.testing.assert_allclose(r["x"][0], r["x_mu"][0][-1], atol=1e-12)
