@@ -338,3 +338,32 @@ def test_tikhonov_1_byproducts_satisfy_the_regularized_optimality_conditions(ora
             np.testing.assert_allclose(g, 0, atol=1e-11)
         if sum(r["rank"][0]) == n:
             np.testing.assert_allclose(r["x"][0], r["x_mu"][0][-1], atol=1e-12)
+
+
+@pytest.mark.parametrize("n,dims,ranks,nfix", [(15, [5, 5, 5, 5], [3, 3, 3, 3], 0), (15, [5, 5, 5, 5], [3, 3, 3, 3], 3), (6, [4, 4, 4], None, 0), (8, [5, 6], None, 2)])
+def test_multipliers_are_the_dual_of_the_lexicographic_problem(oracle, n, dims, ranks, nfix):
+    """What tests/implementation/test1.m checks of `d.lambda` (nObj = 4, nVar = 15, m = 5, r = m - 2, against lexqr_lambda.m), as the
+    property that defines those multipliers: column k of Lambda holds the optimal residual of level k in its own block, and together with
+    the multipliers of the levels above (and of the fixed variables) it makes the Lagrangian of level k's least-squares problem stationary,
+    sum_{j<=k} A_j' lambda_j + E' lambda_fixed = 0."""
+    for seed in range(5):
+        lod = (P.rank_deficient_problem(seed, n, dims, ranks) if ranks else P.lse_problem(seed, n, dims))[None]
+        lv = P.levels_of(lod[0], dims)
+        kw, E = {}, np.zeros((0, n))
+        if nfix:
+            idx, val = np.zeros((1, n), np.uint32), np.zeros((1, n))
+            idx[0, :nfix] = np.argsort(P.uniform(seed, n, 7))[:nfix]
+            val[0, :nfix] = P.normal(seed, nfix, 8)
+            kw = dict(nfixed=np.array([nfix], np.uint32), fixed_idx=idx, fixed_val=val)
+            E = np.zeros((nfix, n))
+            E[np.arange(nfix), idx[0, :nfix]] = 1.0
+        for k in range(len(dims)):
+            r = oracle.lse_run(lod, dims, n, sens_obj=k, **kw)
+            x, lam = r["x"][0], r["lam"][0]
+            g, o = E.T @ lam[:nfix], nfix
+            for j in range(k + 1):
+                g = g + lv[j][0].T @ lam[o:o + dims[j]]
+                o += dims[j]
+            np.testing.assert_allclose(g, 0, atol=1e-12)
+            np.testing.assert_allclose(lam[o - dims[k]:o], lv[k][0] @ x - lv[k][1], atol=1e-12)
+            assert not lam[o:].any()
