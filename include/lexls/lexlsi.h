@@ -267,6 +267,10 @@ namespace LexLS
 
             const dMatrixType &get_lexqr() { return lexlse.get_lexqr(); }
             const dMatrixType &get_data() { return lexlse.get_data(); }
+            /// lexlsi.h:617-630: by-products of REGULARIZATION_TIKHONOV_1 in the last equality problem
+            const dMatrixType &get_X_mu() { return lexlse.get_X_mu(); }
+            const dMatrixType &get_X_mu_rhs() { return lexlse.get_X_mu_rhs(); }
+            const dVectorType &get_residual_mu() { return lexlse.get_residual_mu(); }
 
             Index getCyclingCounter() const { return cycling_handler.get_counter(); }
             Index getFactorizationsCount() const { return nFactorizations; }

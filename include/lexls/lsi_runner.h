@@ -110,6 +110,102 @@ namespace LexLS
             }
         }
 
+        /// Where the fifth output of the MEX front end goes (interfaces/matlab-octave/lexlsi.cpp:739-770, formDebugStructure :77-260).
+        /// Every pointer may be NULL.  total = sum(dims); rows = row capacity of the equality solver (total, minus dims[0] when
+        /// objective 0 holds simple bounds); nObjL = its number of levels.
+        struct LsiDebug
+        {
+            double *lambda;       // total x nObj, column-major: getLambda() with the objectives stacked in the user's constraint order
+            double *lexqr, *data; // rows x (nVar+1), column-major, ld = rows: get_lexqr(), get_data() of the last equality problem
+            double *x_star;       // nVar: get_xStar()
+            int32_t *active_ctr;  // total x 3: (obj_index, ctr_index, ctr_type) in working-set order (getActiveCtr_order)
+            int32_t *log;         // max_log x 5: (obj_index, ctr_index, ctr_type, cycling_detected, rank) per working-set change
+            double *log_alpha;    // max_log: alpha_or_lambda
+            uint32_t max_log;
+            double *x_mu, *x_mu_rhs, *residual_mu; // REGULARIZATION_TIKHONOV_1 only: nObjL x nVar (column k contiguous) twice, rows
+            uint32_t *counts;     // 4: rows, nObjL, number of active constraints, number of log entries (may exceed max_log: truncated)
+        };
+
+        /// the getter sequence of lexlsi.cpp:752-762, in its order (getLambda and get_xStar re-factorize the last equality problem)
+        template <class LSI>
+        void collect_debug(LSI &lsi, const LsiProblem &p, const ParametersLexLSI &par, const LsiDebug &d)
+        {
+            Index total = 0;
+            for (Index k = 0; k < p.nObj; k++) total += p.dims[k];
+            const std::vector<WorkingSetLogEntry> wlog = lsi.getWorkingSetLog();
+            if (d.lambda)
+            {
+                std::vector<dMatrixType> L;
+                lsi.getLambda(L);
+                Index r0 = 0;
+                for (Index k = 0; k < p.nObj; k++)
+                {
+                    for (Index i = 0; i < p.dims[k]; i++)
+                        for (Index j = 0; j < p.nObj; j++) d.lambda[(r0 + i) + static_cast<size_t>(j) * total] = L[k](i, j);
+                    r0 += p.dims[k];
+                }
+            }
+            if (d.x_star)
+            {
+                const dVectorType &xs = lsi.get_xStar();
+                for (Index i = 0; i < p.nVar; i++) d.x_star[i] = xs(i);
+            }
+            const dMatrixType &F = lsi.get_lexqr();
+            const Index rows     = F.rows();
+            if (d.lexqr)
+                for (Index j = 0; j <= p.nVar; j++)
+                    for (Index i = 0; i < rows; i++) d.lexqr[i + static_cast<size_t>(j) * rows] = F(i, j);
+            Index nObjL = p.nObj - ((p.nObj > 0 && p.types[0] == 1) ? 1 : 0);
+            if (par.regularization_type == REGULARIZATION_TIKHONOV_1)
+            {
+                const dMatrixType &X = lsi.get_X_mu(), &Xr = lsi.get_X_mu_rhs();
+                const dVectorType &rm = lsi.get_residual_mu();
+                nObjL = X.cols();
+                for (Index k = 0; k < nObjL; k++)
+                    for (Index i = 0; i < p.nVar; i++)
+                    {
+                        if (d.x_mu) d.x_mu[static_cast<size_t>(k) * p.nVar + i] = X(i, k);
+                        if (d.x_mu_rhs) d.x_mu_rhs[static_cast<size_t>(k) * p.nVar + i] = Xr(i, k);
+                    }
+                if (d.residual_mu)
+                    for (Index i = 0; i < rows; i++) d.residual_mu[i] = rm(i);
+            }
+            std::vector<ConstraintIdentifier> act;
+            lsi.getActiveCtr_order(act);
+            if (d.active_ctr)
+                for (size_t i = 0; i < act.size() && i < static_cast<size_t>(total); i++)
+                {
+                    d.active_ctr[3 * i + 0] = static_cast<int32_t>(act[i].obj_index);
+                    d.active_ctr[3 * i + 1] = static_cast<int32_t>(act[i].ctr_index);
+                    d.active_ctr[3 * i + 2] = static_cast<int32_t>(act[i].ctr_type);
+                }
+            if (d.data)
+            {
+                const dMatrixType &D = lsi.get_data();
+                for (Index j = 0; j <= p.nVar; j++)
+                    for (Index i = 0; i < rows; i++) d.data[i + static_cast<size_t>(j) * rows] = D(i, j);
+            }
+            for (size_t i = 0; i < wlog.size() && i < d.max_log; i++)
+            {
+                if (d.log)
+                {
+                    d.log[5 * i + 0] = static_cast<int32_t>(wlog[i].obj_index);
+                    d.log[5 * i + 1] = static_cast<int32_t>(wlog[i].ctr_index);
+                    d.log[5 * i + 2] = static_cast<int32_t>(wlog[i].ctr_type);
+                    d.log[5 * i + 3] = wlog[i].cycling_detected ? 1 : 0;
+                    d.log[5 * i + 4] = static_cast<int32_t>(wlog[i].rank);
+                }
+                if (d.log_alpha) d.log_alpha[i] = wlog[i].alpha_or_lambda;
+            }
+            if (d.counts)
+            {
+                d.counts[0] = static_cast<uint32_t>(rows);
+                d.counts[1] = static_cast<uint32_t>(nObjL);
+                d.counts[2] = static_cast<uint32_t>(act.size());
+                d.counts[3] = static_cast<uint32_t>(wlog.size());
+            }
+        }
+
         template <class LSI>
         void solve(const LsiProblem &p, const ParametersLexLSI &par, double *x_out, LsiInfo *info, uint8_t *active_out, double *v_out)
         {

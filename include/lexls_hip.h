@@ -246,6 +246,26 @@ int lexls_lsi_solve_ex(int device, uint32_t nVar, uint32_t nObj, const uint32_t 
                        const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_v0,
                        const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
                        double *h_v);
+/* The fifth output of the MEX front end, `[x, info, v, as, d] = lexlsi(...)` (interfaces/matlab-octave/lexlsi.cpp:739-770,
+ * formDebugStructure :77-260): lexls_lsi_solve_ex with the working-set log on (ParametersLexLSI::log_working_set_enabled), followed by the
+ * getter sequence of :752-762.  Every pointer of `debug` may be NULL.  total = sum(dims); rows = row capacity of the equality solver
+ * (total, minus dims[0] when objective 0 holds simple bounds); nObjL = its number of levels. */
+typedef struct lexls_lsi_debug
+{
+    double *lambda;       /* total x nObj, column-major: getLambda() lexlsi.h:552-605, objectives stacked, user's constraint order   */
+    double *lexqr, *data; /* rows x (nVar+1), column-major, ld = rows: get_lexqr() :632, get_data() :637 of the last equality problem */
+    double *x_star;       /* nVar: get_xStar() :519                                                                                */
+    int32_t *active_ctr;  /* total x 3: (obj_index, ctr_index, ctr_type) in working-set order, getActiveCtr_order() :703            */
+    int32_t *log;         /* max_log x 5: (obj_index, ctr_index, ctr_type, cycling_detected, rank) per change, getWorkingSetLog()  */
+    double *log_alpha;    /* max_log: alpha_or_lambda of the entry                                                                 */
+    uint32_t max_log;
+    double *x_mu, *x_mu_rhs, *residual_mu; /* REGULARIZATION_TIKHONOV_1 only (:617-630): nObjL x nVar (column k contiguous) twice, rows */
+    uint32_t *counts;     /* 4: rows, nObjL, number of active constraints, number of log entries (entries beyond max_log are dropped) */
+} lexls_lsi_debug;
+int lexls_lsi_solve_debug(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types, const double *h_data,
+                          const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_v0,
+                          const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
+                          double *h_v, const lexls_lsi_debug *debug);
 /* the same on a hierarchy file in the reference's .dat format (tools.h:261-453); h_solution receives the file's
  * `#Solution` block when present (may be NULL).  one_based: simple-bound indices in the file are 1-based. */
 int lexls_lsi_solve_dat(int device, const char *path, int one_based, int use_active_guess, int use_x_guess, double *h_x, int32_t *h_info6,

@@ -17,7 +17,7 @@ SYMBOLS = [
     "lexls_lse_create", "lexls_lse_destroy", "lexls_lse_set_stream", "lexls_lse_synchronize",
     "lexls_lse_set_tolerance", "lexls_lse_set_obj_dim", "lexls_lse_set_fixed", "lexls_lse_set_ctr_type",
     "lexls_lse_set_problem_host", "lexls_lse_set_problem_device", "lexls_lse_set_skip",
-    "lexls_lse_set_constraint_data", "lexls_lse_gather_problem", "lexls_lse_solve_least_norm_2", "lexls_lse_set_fixed_type", "lexls_lse_get_fixed_type", "lexls_lse_set_deferred_sync", "lexls_lse_set_regularization", "lexls_lse_set_cg_iterations", "lexls_lsi_solve_ex", "lexls_lsi_batch_solve_ex", "lexls_lse_solve_least_norm_3",
+    "lexls_lse_set_constraint_data", "lexls_lse_gather_problem", "lexls_lse_solve_least_norm_2", "lexls_lse_set_fixed_type", "lexls_lse_get_fixed_type", "lexls_lse_set_deferred_sync", "lexls_lse_set_regularization", "lexls_lse_set_cg_iterations", "lexls_lsi_solve_ex", "lexls_lsi_solve_debug", "lexls_lsi_batch_solve_ex", "lexls_lse_solve_least_norm_3",
     "lexls_lsi_batch_create", "lexls_lsi_batch_run", "lexls_lsi_batch_destroy", "lexls_lsi_batch_stats",
     "lexls_lse_round_layout", "lexls_lse_upload_round", "lexls_lse_download_round", "lexls_lse_sensitivity_resident", "lexls_lse_set_sensitivity_scan",
     "lexls_lse_factorize", "lexls_lse_solve", "lexls_lse_factorize_solve", "lexls_lse_solve_least_norm",

@@ -1714,6 +1714,39 @@ extern "C"
         }
     }
 
+    int lexls_lsi_solve_debug(int device, uint32_t nVar, uint32_t nObj, const uint32_t *h_dims, const int32_t *h_types, const double *h_data,
+                              const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_v0,
+                              const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
+                              double *h_v, const lexls_lsi_debug *debug)
+    {
+        try
+        {
+            if (h_params && nparams != 9 && nparams != 12) throw Exception("lexls_lsi_solve_debug: 9 or 12 parameters expected");
+            if (!debug) throw Exception("lexls_lsi_solve_debug: debug is NULL (use lexls_lsi_solve_ex)");
+            runner::LsiProblem p = {nVar, nObj, h_dims, h_types, h_data, h_var_index, h_active_guess, h_x0, h_v0, h_reg_factors};
+            ParametersLexLSI par        = unpack(h_params, nparams);
+            par.log_working_set_enabled = true;
+            internal::LexLSI lsi;
+            lsi.getLexLSE().setDevice(device);
+            lsi.getLexLSE().setSensitivityScan(true);
+            lsi.setSensitivityScansAllLevels(true);
+            runner::setup(lsi, p, par);
+            lsi.solve();
+            runner::LsiInfo info;
+            runner::collect(lsi, p, h_x, &info, h_active, h_v);
+            if (h_info6) std::memcpy(h_info6, &info, sizeof(info));
+            const runner::LsiDebug d = {debug->lambda, debug->lexqr, debug->data, debug->x_star, debug->active_ctr, debug->log, debug->log_alpha, debug->max_log,
+                                        debug->x_mu, debug->x_mu_rhs, debug->residual_mu, debug->counts};
+            runner::collect_debug(lsi, p, par, d);
+            return LEXLS_OK;
+        }
+        catch (const std::exception &e)
+        {
+            lexls_internal_set_error(e.what());
+            return LEXLS_ERR_INVALID;
+        }
+    }
+
     int lexls_lsi_solve_dat(int device, const char *path, int one_based, int use_active_guess, int use_x_guess, double *h_x, int32_t *h_info6,
                             double *h_solution)
     {

@@ -58,9 +58,10 @@ def lexlse(obj, options=None, device: int = 0):
     return x, {"status": STATUS_OK}, v
 
 
-def lexlsi(obj, options=None, active_set=None, x0=None, v0=None, device: int = 0):
+def lexlsi(obj, options=None, active_set=None, x0=None, v0=None, device: int = 0, debug: bool = False):
     """-> x, info {status, number_of_iterations, number_of_activations, number_of_deactivations, number_of_factorizations}
-    (lexlsi.cpp:640-700), v (list), active_set (list of per-objective activation flags 0..3)"""
+    (lexlsi.cpp:640-700), v (list), active_set (list of per-objective activation flags 0..3) and — with debug=True, the MEX call with five
+    outputs — d {working_set_log, active_ctr, lambda, lexqr, data, xStar [, X_mu, X_mu_rhs, residual_mu]} (lexlsi.cpp:739-770)"""
     opt = dict(options or {})
     n = None
     for o in obj:
@@ -70,8 +71,11 @@ def lexlsi(obj, options=None, active_set=None, x0=None, v0=None, device: int = 0
     if n is None:
         raise ValueError("lexlsi: at least one general objective is needed")
     factors = opt.pop("regularization_factors", None)
-    r = _lsi.lsi_solve(n, obj, active_guess=active_set, x0=x0, device=device, v0=v0, regularization_factors=factors, **opt)
+    solve = _lsi.lsi_solve_debug if debug else _lsi.lsi_solve
+    r = solve(n, obj, active_guess=active_set, x0=x0, device=device, v0=v0, regularization_factors=factors, **opt)
     i = r["info"]
     info = {"status": i["status"], "number_of_iterations": i["iterations"], "number_of_activations": i["activations"],
             "number_of_deactivations": i["deactivations"], "number_of_factorizations": i["factorizations"]}
+    if debug:
+        return r["x"], info, r["v"], r["active"], r["debug"]
     return r["x"], info, r["v"], r["active"]

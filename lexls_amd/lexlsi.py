@@ -142,6 +142,65 @@ def lsi_solve(nvar: int, objectives, active_guess=None, x0=None, device: int = 0
     return dict(x=x, info=dict(zip(INFO_KEYS, info.tolist())), active=np.split(active, cuts), v=np.split(v, cuts))
 
 
+class _DebugStruct(C.Structure):
+    """lexls_lsi_debug of include/lexls_hip.h"""
+    _fields_ = [("lambda_", C.c_void_p), ("lexqr", C.c_void_p), ("data", C.c_void_p), ("x_star", C.c_void_p), ("active_ctr", C.c_void_p),
+                ("log", C.c_void_p), ("log_alpha", C.c_void_p), ("max_log", C.c_uint32), ("x_mu", C.c_void_p), ("x_mu_rhs", C.c_void_p),
+                ("residual_mu", C.c_void_p), ("counts", C.c_void_p)]
+
+
+def debug_buffers(nvar: int, dims, max_log: int = 4096):
+    """numpy arrays for the debug outputs of one LexLSI solve (lexls_lsi_debug); shaped into the MEX structure by debug_structure()"""
+    total, nobj = int(np.sum(dims)), len(dims)
+    return dict(lam=np.zeros((nobj, total)), lexqr=np.zeros((nvar + 1, total)), data=np.zeros((nvar + 1, total)), x_star=np.zeros(nvar),
+                active_ctr=np.zeros((total, 3), np.int32), log=np.zeros((max_log, 5), np.int32), log_alpha=np.zeros(max_log),
+                x_mu=np.zeros((nobj, nvar)), x_mu_rhs=np.zeros((nobj, nvar)), residual_mu=np.zeros(total), counts=np.zeros(4, np.uint32))
+
+
+def debug_structure(nvar: int, dims, buf, with_mu: bool):
+    """the fields of formDebugStructure (interfaces/matlab-octave/lexlsi.cpp:77-260) from filled debug_buffers()"""
+    rows, nobjl, nact, nlog = (int(c) for c in buf["counts"])
+    cuts = np.cumsum(dims)[:-1]
+    nlog = min(nlog, buf["log"].shape[0])
+    d = {
+        "working_set_log": [dict(obj_index=int(e[0]), ctr_index=int(e[1]), ctr_type=int(e[2]), alpha_or_lambda=float(a), cycling_detected=int(e[3]), rank=int(e[4]))
+                            for e, a in zip(buf["log"][:nlog], buf["log_alpha"][:nlog])],
+        "active_ctr": [dict(obj_index=int(e[0]), ctr_index=int(e[1]), ctr_type=int(e[2])) for e in buf["active_ctr"][:nact]],
+        "lambda": np.split(np.ascontiguousarray(buf["lam"].T), cuts),  # one (dim_k x nObj) matrix per objective
+        "lexqr": np.ascontiguousarray(buf["lexqr"].reshape(-1)[:rows * (nvar + 1)].reshape(nvar + 1, rows).T),
+        "data": np.ascontiguousarray(buf["data"].reshape(-1)[:rows * (nvar + 1)].reshape(nvar + 1, rows).T),
+        "xStar": buf["x_star"],
+    }
+    if with_mu:
+        d.update(X_mu=np.ascontiguousarray(buf["x_mu"][:nobjl].T), X_mu_rhs=np.ascontiguousarray(buf["x_mu_rhs"][:nobjl].T), residual_mu=buf["residual_mu"][:rows])
+    return d
+
+
+def lsi_solve_debug(nvar: int, objectives, active_guess=None, x0=None, device: int = 0, v0=None, regularization_factors=None, max_log: int = 4096, **params):
+    """lsi_solve plus the MEX front end's debug structure `d` (lexls_lsi_solve_debug): returns the lsi_solve dict with key "debug"."""
+    dims, types, data, var_index = flatten(nvar, objectives)
+    total = int(dims.sum())
+    x, info = np.zeros(nvar), np.zeros(6, np.int32)
+    active, v = np.zeros(total, np.uint8), np.zeros(total)
+    guess = None if active_guess is None else np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint8) for g in active_guess]))
+    x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
+    v0a = None if v0 is None else np.ascontiguousarray(np.concatenate([np.asarray(a, np.float64) for a in v0]))
+    rfa = None if regularization_factors is None else np.ascontiguousarray(regularization_factors, np.float64)
+    par = pack_params_ex(**params)
+    buf = debug_buffers(nvar, dims, max_log)
+    ds = _DebugStruct(buf["lam"].ctypes.data, buf["lexqr"].ctypes.data, buf["data"].ctypes.data, buf["x_star"].ctypes.data, buf["active_ctr"].ctypes.data,
+                      buf["log"].ctypes.data, buf["log_alpha"].ctypes.data, max_log, buf["x_mu"].ctypes.data, buf["x_mu_rhs"].ctypes.data,
+                      buf["residual_mu"].ctypes.data, buf["counts"].ctypes.data)
+    capi.check(capi.lib().lexls_lsi_solve_debug(
+        C.c_int(device), C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, C.c_uint32), _p(types, C.c_int32), _p(data, C.c_double),
+        _p(var_index if var_index.size else None, C.c_uint32), _p(guess, C.c_uint8), _p(x0a, C.c_double), _p(v0a, C.c_double),
+        _p(rfa, C.c_double), _p(par, C.c_double), C.c_uint32(len(par)), _p(x, C.c_double), _p(info, C.c_int32), _p(active, C.c_uint8),
+        _p(v, C.c_double), C.byref(ds)))
+    cuts = np.cumsum(dims)[:-1]
+    return dict(x=x, info=dict(zip(INFO_KEYS, info.tolist())), active=np.split(active, cuts), v=np.split(v, cuts),
+                debug=debug_structure(nvar, dims, buf, int(params.get("regularization_type", 0)) == 7))
+
+
 def lsi_solve_dat(path: str, nvar: int, one_based=True, use_active_guess=False, use_x_guess=False, device: int = 0):
     x, sol, info = np.zeros(nvar), np.zeros(nvar), np.zeros(6, np.int32)
     capi.check(capi.lib().lexls_lsi_solve_dat(C.c_int(device), path.encode(), C.c_int(one_based), C.c_int(use_active_guess), C.c_int(use_x_guess),

@@ -334,6 +334,51 @@ extern "C"
         }
     }
 
+    /// oracle_lsi_run_ex + the debug outputs of the MEX front end (runner::collect_debug); `dbg` = 12 pointers / values in the order of
+    /// runner::LsiDebug: lambda, lexqr, data, x_star, active_ctr, log, log_alpha, max_log (as uintptr), x_mu, x_mu_rhs, residual_mu, counts
+    int oracle_lsi_run_debug(uint32_t nVar, uint32_t nObj, const uint32_t *dims, const int32_t *types, const double *data, const uint32_t *var_index,
+                             const uint8_t *active_guess, const double *x0, const double *v0, const double *reg_factors, const double *params12,
+                             double *x_out, int32_t *info6, uint8_t *active_out, double *v_out, double *lambda, double *lexqr, double *pdata, double *x_star,
+                             int32_t *active_ctr, int32_t *log, double *log_alpha, uint32_t max_log, double *x_mu, double *x_mu_rhs, double *residual_mu,
+                             uint32_t *counts)
+    {
+        try
+        {
+            runner::LsiProblem p = {nVar, nObj, dims, types, data, var_index, active_guess, x0, v0, reg_factors};
+            ParametersLexLSI par;
+            if (params12)
+            {
+                par.max_number_of_factorizations   = static_cast<Index>(params12[0]);
+                par.tol_linear_dependence          = params12[1];
+                par.tol_wrong_sign_lambda          = params12[2];
+                par.tol_correct_sign_lambda        = params12[3];
+                par.tol_feasibility                = params12[4];
+                par.cycling_handling_enabled       = params12[5] != 0;
+                par.cycling_max_counter            = static_cast<Index>(params12[6]);
+                par.cycling_relax_step             = params12[7];
+                par.deactivate_first_wrong_sign    = params12[8] != 0;
+                par.regularization_type            = static_cast<RegularizationType>(static_cast<int>(params12[9]));
+                par.variable_regularization_factor = params12[10];
+                par.max_number_of_CG_iterations    = static_cast<Index>(params12[11]);
+            }
+            par.log_working_set_enabled = true;
+            OLSI lsi;
+            runner::setup(lsi, p, par);
+            lsi.solve();
+            runner::LsiInfo info;
+            runner::collect(lsi, p, x_out, &info, active_out, v_out);
+            if (info6) std::memcpy(info6, &info, sizeof(info));
+            const runner::LsiDebug d = {lambda, lexqr, pdata, x_star, active_ctr, log, log_alpha, max_log, x_mu, x_mu_rhs, residual_mu, counts};
+            runner::collect_debug(lsi, p, par, d);
+            return 0;
+        }
+        catch (const std::exception &e)
+        {
+            g_err = e.what();
+            return 1;
+        }
+    }
+
     /// multipliers of a solved-from-scratch LexLSI problem: lambda_out is sum(dims) x nObj, column-major (lexlsi.h:552-605)
     int oracle_lsi_lambda(uint32_t nVar, uint32_t nObj, const uint32_t *dims, const int32_t *types, const double *data, const uint32_t *var_index,
                           double *x_out, double *lambda_out)

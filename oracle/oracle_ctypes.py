@@ -138,6 +138,32 @@ def lsi_run(nvar, objectives, active_guess=None, x0=None, v0=None, regularizatio
     return dict(x=x, info=dict(zip(keys, info.tolist())), active=np.split(active, np.cumsum(dims)[:-1]), v=np.split(v, np.cumsum(dims)[:-1]))
 
 
+def lsi_run_debug(nvar, objectives, active_guess=None, x0=None, v0=None, regularization_factors=None, max_log=4096, **params):
+    """lsi_run plus the debug structure of the MEX front end (oracle_lsi_run_debug): the oracle-backed twin of lexls_lsi_solve_debug"""
+    from lexls_amd.lexlsi import debug_buffers, debug_structure
+    dims, types, data, var_index = flatten_lsi(nvar, objectives)
+    total = int(dims.sum())
+    x, info, active, v = np.zeros(nvar), np.zeros(6, np.int32), np.zeros(total, np.uint8), np.zeros(total)
+    guess = None if active_guess is None else np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint8) for g in active_guess]))
+    x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
+    v0a = None if v0 is None else np.ascontiguousarray(np.concatenate([np.asarray(a, np.float64) for a in v0]))
+    rfa = None if regularization_factors is None else np.ascontiguousarray(regularization_factors, np.float64)
+    par = pack_params_ex(**params)
+    b = debug_buffers(nvar, dims, max_log)
+    i32p = C.POINTER(C.c_int32)
+    rc = lib().oracle_lsi_run_debug(C.c_uint32(nvar), C.c_uint32(len(dims)), _p(dims, _u32p), _p(types, _i32p), _p(data, _dp),
+                                    _p(var_index if var_index.size else None, _u32p), _p(guess, _u8p), _p(x0a, _dp), _p(v0a, _dp), _p(rfa, _dp),
+                                    _p(par, _dp), _p(x, _dp), _p(info, _i32p), _p(active, _u8p), _p(v, _dp), _p(b["lam"], _dp), _p(b["lexqr"], _dp),
+                                    _p(b["data"], _dp), _p(b["x_star"], _dp), _p(b["active_ctr"], i32p), _p(b["log"], i32p), _p(b["log_alpha"], _dp),
+                                    C.c_uint32(max_log), _p(b["x_mu"], _dp), _p(b["x_mu_rhs"], _dp), _p(b["residual_mu"], _dp), _p(b["counts"], _u32p))
+    if rc:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    keys = ["status", "iterations", "activations", "deactivations", "factorizations", "total_rank"]
+    cuts = np.cumsum(dims)[:-1]
+    return dict(x=x, info=dict(zip(keys, info.tolist())), active=np.split(active, cuts), v=np.split(v, cuts),
+                debug=debug_structure(nvar, dims, b, int(params.get("regularization_type", 0)) == 7))
+
+
 def lsi_lambda(nvar, objectives):
     dims, types, data, var_index = flatten_lsi(nvar, objectives)
     total = int(dims.sum())

@@ -510,3 +510,44 @@ def test_config5_full_size_lock_step_batch(hip, oracle, monkeypatch, resident):
         np.testing.assert_array_equal(warm["x"][b], o["x"], err_msg=str(b))
         np.testing.assert_array_equal(warm["active"][b], np.concatenate(o["active"]), err_msg=str(b))
         np.testing.assert_array_equal(warm["v"][b], np.concatenate(o["v"]), err_msg=str(b))
+
+
+def test_front_end_debug_output(hip, oracle):
+    """The fifth output of the MEX front end through lexls_lsi_solve_debug (`frontend.lexlsi(..., debug=True)`): working-set log with its
+    step lengths / multipliers, final working set in order, the multiplier matrices of getLambda, factor, data and xStar of the last
+    equality problem — identical to the oracle-backed driver's; cold start, a warm start that has to remove constraints, simple bounds,
+    and the by-products of the experimental regularization type 7."""
+    from lexls_amd import frontend
+    n, dims = 20, [6, 5, 5, 6]
+
+    def check(objs, **kw):
+        okw = dict(kw)
+        opt = okw.pop("options", {})
+        x, info, v, act, d = frontend.lexlsi(objs, opt, okw.get("active_set"), okw.get("x0"), debug=True)
+        o = oracle.lsi_run_debug(n, objs, active_guess=okw.get("active_set"), x0=okw.get("x0"), regularization_factors=opt.get("regularization_factors"),
+                                 **{k: val for k, val in opt.items() if k != "regularization_factors"})
+        od = o["debug"]
+        assert info["number_of_factorizations"] == o["info"]["factorizations"] and info["status"] == o["info"]["status"]
+        np.testing.assert_array_equal(x, o["x"])
+        assert d["working_set_log"] == od["working_set_log"] and d["active_ctr"] == od["active_ctr"]
+        # rows of the equality problem = active constraints of the general objectives (the rows beyond them are stale in the reference too)
+        m = sum(1 for e in d["active_ctr"] if "A" in objs[e["obj_index"]])
+        for key in ("lexqr", "data", "xStar") + (("X_mu", "X_mu_rhs", "residual_mu") if "X_mu" in od else ()):
+            rows = slice(0, m) if key in ("lexqr", "data", "residual_mu") else slice(None)
+            np.testing.assert_array_equal(d[key][rows], od[key][rows], err_msg=key)
+        for a, b in zip(d["lambda"], od["lambda"]):
+            np.testing.assert_array_equal(a, b)
+        return info, d
+
+    for seed in (700, 701, 702):
+        objs = P.lsi_problem(seed, n, dims)
+        info, d = check(objs)
+        assert len(d["working_set_log"]) == info["number_of_activations"] + info["number_of_deactivations"]
+        # warm start from a wrong guess: everything active at the upper bound -> removals in the log
+        guess = [np.full(m, 2, np.uint8) for m in dims]
+        info, d = check(objs, active_set=guess)
+        assert info["number_of_deactivations"] > 0 and any(e["ctr_type"] == 0 for e in d["working_set_log"])
+    objs = [o for o in P.lsi_problem(703, n, dims) if "A" in o]  # general objectives only
+    check(objs)
+    info, d = check(P.lsi_problem(704, n, dims), options=dict(regularization_type=7, regularization_factors=[0, 0.3, 0.2, 0.4], max_number_of_factorizations=40))
+    assert d["X_mu"].shape == (n, 3) and d["residual_mu"].shape == (16,)

@@ -367,3 +367,38 @@ def test_multipliers_are_the_dual_of_the_lexicographic_problem(oracle, n, dims, 
             np.testing.assert_allclose(g, 0, atol=1e-12)
             np.testing.assert_allclose(lam[o - dims[k]:o], lv[k][0] @ x - lv[k][1], atol=1e-12)
             assert not lam[o:].any()
+
+
+def test_front_end_debug_structure(oracle):
+    """`[x, info, v, as, d] = lexlsi(obj)` as tests/implementation/test1.m uses it (nObj = 4, nVar = 15, m = 5, r = m - 2, equalities through
+    lb = ub): d.lexqr is the factor of the equality solver on the same problem, d.xStar = x, and the columns of d.lambda are the dual of the
+    lexicographic problem (what test1.m compares with lexqr_lambda.m); on an inequality problem the working-set log has one entry per
+    activation / deactivation and d.active_ctr lists the final working set in insertion order."""
+    n, dims, ranks = 15, [5, 5, 5, 5], [3, 3, 3, 3]
+    for seed in range(4):
+        lod = P.rank_deficient_problem(seed, n, dims, ranks)
+        lv = P.levels_of(lod, dims)
+        r = oracle.lsi_run_debug(n, [dict(A=A, lb=b, ub=b) for A, b in lv])
+        d, e = r["debug"], oracle.lse_run(lod[None], dims, n)
+        assert r["info"]["factorizations"] == 1 and not d["working_set_log"] and len(d["active_ctr"]) == sum(dims)
+        np.testing.assert_array_equal(r["x"], e["x"][0])
+        np.testing.assert_array_equal(d["xStar"], e["x"][0])
+        np.testing.assert_array_equal(d["lexqr"], e["factor"][0].T)
+        np.testing.assert_array_equal(d["data"], lod.T)
+        L = np.vstack(d["lambda"])
+        for k in range(len(dims)):
+            g, o = np.zeros(n), 0
+            for j in range(len(dims)):
+                g += lv[j][0].T @ L[o:o + dims[j], k]
+                o += dims[j]
+            np.testing.assert_allclose(g, 0, atol=1e-12)
+            lo = sum(dims[:k])
+            np.testing.assert_allclose(L[lo:lo + dims[k], k], lv[k][0] @ r["x"] - lv[k][1], atol=1e-12)
+            assert not L[lo + dims[k]:, k].any()
+    objs = P.lsi_problem(700, 20, [6, 5, 5, 6])
+    r = oracle.lsi_run_debug(20, objs)
+    d = r["debug"]
+    assert len(d["working_set_log"]) == r["info"]["activations"] + r["info"]["deactivations"] > 0
+    final = {(e["obj_index"], e["ctr_index"]): e["ctr_type"] for e in d["active_ctr"]}
+    assert final == {(k, j): int(t) for k, a in enumerate(r["active"]) for j, t in enumerate(a) if t}
+    assert d["lexqr"].shape == (16, 21)  # the simple bounds of objective 0 are fixed variables, not rows
