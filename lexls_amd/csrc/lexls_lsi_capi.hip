@@ -1299,8 +1299,35 @@ struct lexls_lsi_batch_s
     void run(const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0, const double *h_v0,
              const double *h_reg_factors, const ParametersLexLSI &par, double *h_x, int32_t *h_info6, uint8_t *h_active, double *h_v, int32_t *h_rounds2)
     {
-        if (par.deactivate_first_wrong_sign) throw Exception("lexls_lsi_batch_solve: deactivate_first_wrong_sign has no device path");
         if (!h_data || !h_x) throw Exception("lexls_lsi_batch_run: null data / x");
+        if (par.deactivate_first_wrong_sign)
+        {
+            // The lock-step stages ask the device for ONE removal candidate per instance; this option (lexlsi.h:1089-1103) wants every
+            // wrong-sign multiplier of the first level that has one, read back per iteration.  Such a batch runs its instances one after
+            // the other through the single-problem driver — same results as lexls_lsi_solve_ex on each, every equality problem on the GPU.
+            int32_t fs = 0;
+            for (uint32_t b = 0; b < batch; b++)
+            {
+                runner::LsiProblem p = {nVar, nObj, dims.data(), types.data(), h_data + (size_t)b * per_data, h_var_index ? h_var_index + (size_t)b * dims[0] : NULL,
+                                        h_active_guess ? h_active_guess + (size_t)b * total : NULL, h_x0 ? h_x0 + (size_t)b * nVar : NULL,
+                                        h_v0 ? h_v0 + (size_t)b * total : NULL, h_reg_factors};
+                internal::LexLSI lsi;
+                lsi.getLexLSE().setDevice(device);
+                lsi.getLexLSE().setSensitivityScan(true);
+                lsi.setSensitivityScansAllLevels(true);
+                runner::setup(lsi, p, par);
+                lsi.solve();
+                runner::LsiInfo info;
+                runner::collect(lsi, p, h_x + (size_t)b * nVar, &info, h_active ? h_active + (size_t)b * total : NULL, h_v ? h_v + (size_t)b * total : NULL);
+                if (h_info6) std::memcpy(h_info6 + (size_t)b * 6, &info, sizeof(info));
+                fs += info.factorizations;
+            }
+            last_stats[0] = fs;
+            last_stats[1] = last_stats[2] = 0;
+            last_stats[3] = 1;
+            if (h_rounds2) h_rounds2[0] = fs, h_rounds2[1] = 0;
+            return;
+        }
         const uint32_t *h_dims = dims.data();
         const int32_t *h_types = types.data();
         WorkerPool &pool       = *this->pool;

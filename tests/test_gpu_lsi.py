@@ -551,3 +551,18 @@ def test_front_end_debug_output(hip, oracle):
     check(objs)
     info, d = check(P.lsi_problem(704, n, dims), options=dict(regularization_type=7, regularization_factors=[0, 0.3, 0.2, 0.4], max_number_of_factorizations=40))
     assert d["X_mu"].shape == (n, 3) and d["residual_mu"].shape == (16,)
+
+
+def test_batch_with_deactivate_first_wrong_sign(hip, oracle):
+    """lexls_lsi_batch_solve with ParametersLexLSI::deactivate_first_wrong_sign (lexlsi.h:1089-1103): no lock-step form — the instances run
+    one after the other through the single-problem driver; every instance ends where its oracle-backed solve ends."""
+    n, dims, batch = 20, [6, 5, 5, 6], 6
+    problems = [P.lsi_problem(800 + b, n, dims) for b in range(batch)]
+    guess = [[np.full(m, 2, np.uint8) for m in dims] for _ in range(batch)]  # everything active at the upper bound: removals needed
+    r = lexlsi.lsi_batch_solve(n, problems, active_guess=guess, deactivate_first_wrong_sign=1)
+    for b in range(batch):
+        o = oracle.lsi_run(n, problems[b], active_guess=guess[b], deactivate_first_wrong_sign=1)
+        assert r["info"][b] == o["info"], b
+        np.testing.assert_array_equal(r["x"][b], o["x"])
+        np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
+    assert any(i["deactivations"] > 0 for i in r["info"])
