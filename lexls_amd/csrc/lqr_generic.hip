@@ -25,31 +25,209 @@ namespace lexls
 {
     namespace
     {
-        /// block-wide "first index of the maximum": every thread passes its best candidate
+// Diagnostic build only (-DLEXLS_GENERIC_STAMPS): thread 0 of lqr_generic_kernel accumulates shader-clock totals per phase and leaves them in
+// the (otherwise unused) multiplier buffer; the product build contains no stamp.  Phases: 0 stage + init + fixed variables, 1 level norms,
+// 2 pivot search, 3 fresh norm + reflector scalars, 4 column swap + essential part, 5 reflector application + down-date,
+// 6 regularization + Gauss step, 7 results + factor store, 8 solve
+#ifdef LEXLS_GENERIC_STAMPS
+#define GSTAMP_DECL                 \
+    unsigned long long gs_acc[9];   \
+    for (int i_ = 0; i_ < 9; i_++) gs_acc[i_] = 0; \
+    unsigned long long gs_t0 = clock64();
+#define GSTAMP(i)                                  \
+    {                                              \
+        const unsigned long long t_ = clock64();   \
+        gs_acc[i] += t_ - gs_t0;                   \
+        gs_t0 = t_;                                \
+    }
+#define GSTAMP_WRITE \
+    if (tid == 0)    \
+        for (int i_ = 0; i_ < 9; i_++) a.lambda[(size_t)b * (n + cap) + i_] = (double)gs_acc[i_];
+#else
+#define GSTAMP_DECL
+#define GSTAMP(i)
+#define GSTAMP_WRITE
+#endif
+
+        /// block-wide "first index of the maximum" (every thread passes its best candidate) with ONE barrier: the wavefront's maximum by DPP (wave_max), the first position that attains it by a minimum over the
+        /// lanes that hold it, then the NT/64 wavefront results through LDS; the slots alternate with `parity` (a pivot's slots are not
+        /// rewritten before the pivot after the next one, several barriers later).  rv / ri hold at least 32 entries (NT >= 64).
         template <int NT>
-        __device__ __forceinline__ uint32_t block_argmax(double v, uint32_t idx, double *rv, uint32_t *ri, uint32_t tid)
+        __device__ __forceinline__ uint32_t block_argmax_fast(double v, uint32_t idx, double *rv, uint32_t *ri, uint32_t tid, uint32_t parity)
         {
-            rv[tid] = v;
-            ri[tid] = idx;
-            __syncthreads();
-#pragma unroll
-            for (int s = NT / 2; s > 0; s >>= 1)
+            const double m = wave_max(v);
+            unsigned c     = row_min16(v == m ? idx : 0xffffffffu);
             {
-                if (tid < (uint32_t)s)
-                {
-                    const double v2   = rv[tid + s];
-                    const uint32_t i2 = ri[tid + s];
-                    if (v2 > rv[tid] || (v2 == rv[tid] && i2 < ri[tid]))
-                    {
-                        rv[tid] = v2;
-                        ri[tid] = i2;
-                    }
-                }
-                __syncthreads();
+                const unsigned c0 = (unsigned)__builtin_amdgcn_readlane((int)c, 0), c1 = (unsigned)__builtin_amdgcn_readlane((int)c, 16);
+                const unsigned c2 = (unsigned)__builtin_amdgcn_readlane((int)c, 32), c3 = (unsigned)__builtin_amdgcn_readlane((int)c, 48);
+                const unsigned a01 = c0 < c1 ? c0 : c1, a23 = c2 < c3 ? c2 : c3;
+                c = a01 < a23 ? a01 : a23;
             }
-            const uint32_t out = ri[0];
+            if (NT == 64) return c;
+            const uint32_t base = parity * 16u;
+            if ((tid & 63u) == 0)
+            {
+                rv[base + (tid >> 6)] = m;
+                ri[base + (tid >> 6)] = c;
+            }
             __syncthreads();
-            return out;
+            double fm   = rv[base];
+            uint32_t fi = ri[base];
+#pragma unroll
+            for (uint32_t w = 1; w < (uint32_t)(NT / 64); w++)
+            {
+                const double v2   = rv[base + w];
+                const uint32_t i2 = ri[base + w];
+                if (v2 > fm || (v2 == fm && i2 < fi))
+                {
+                    fm = v2;
+                    fi = i2;
+                }
+            }
+            return fi;
+        }
+
+        /// s = fma(p_i, p_i, s) for i ascending.  The reads of a chunk of U are issued together and the next chunk is fetched (into the
+        /// other of two register sets) before the current one is consumed, so the chain runs at the latency of the fused multiply-add
+        /// instead of a memory round trip per term (same order, same result)
+        template <int U>
+        __device__ __forceinline__ double chain_square(const double *p, uint32_t len, double s)
+        {
+            uint32_t i = 0;
+            if (len >= (uint32_t)U)
+            {
+                double v0[U], v1[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) v0[u] = p[u];
+                i = U;
+                while (true)
+                {
+                    const bool more1 = i + U <= len;
+                    if (more1)
+                    {
+#pragma unroll
+                        for (int u = 0; u < U; u++) v1[u] = p[i + u];
+                        i += U;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) s = dfma(v0[u], v0[u], s);
+                    if (!more1) break;
+                    const bool more0 = i + U <= len;
+                    if (more0)
+                    {
+#pragma unroll
+                        for (int u = 0; u < U; u++) v0[u] = p[i + u];
+                        i += U;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) s = dfma(v1[u], v1[u], s);
+                    if (!more0) break;
+                }
+            }
+            for (; i < len; i++) s = dfma(p[i], p[i], s);
+            return s;
+        }
+        /// the two chains of a pivot column in one pass: fresh = sum_{i<R} c_i^2 and tail = sum_{1<=i<R} c_i^2, each ascending from 0
+        template <int U>
+        __device__ __forceinline__ void chain_square_pair(const double *c, uint32_t R, double &fresh, double &tail)
+        {
+            double f = dfma(c[0], c[0], 0.0), t = 0.0;
+            uint32_t i = 1;
+            if (R >= 1u + (uint32_t)U)
+            {
+                double v0[U], v1[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) v0[u] = c[1 + u];
+                i = 1 + U;
+                while (true)
+                {
+                    const bool more1 = i + U <= R;
+                    if (more1)
+                    {
+#pragma unroll
+                        for (int u = 0; u < U; u++) v1[u] = c[i + u];
+                        i += U;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+                    {
+                        f = dfma(v0[u], v0[u], f);
+                        t = dfma(v0[u], v0[u], t);
+                    }
+                    if (!more1) break;
+                    const bool more0 = i + U <= R;
+                    if (more0)
+                    {
+#pragma unroll
+                        for (int u = 0; u < U; u++) v0[u] = c[i + u];
+                        i += U;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+                    {
+                        f = dfma(v1[u], v1[u], f);
+                        t = dfma(v1[u], v1[u], t);
+                    }
+                    if (!more0) break;
+                }
+            }
+            for (; i < R; i++)
+            {
+                f = dfma(c[i], c[i], f);
+                t = dfma(c[i], c[i], t);
+            }
+            fresh = f;
+            tail  = t;
+        }
+        /// s = fma(a_i, b_i, s) for i ascending, reads batched and prefetched as in chain_square
+        template <int U>
+        __device__ __forceinline__ double chain_dot(const double *a, const double *b, uint32_t len, double s)
+        {
+            uint32_t i = 0;
+            if (len >= (uint32_t)U)
+            {
+                double x0[U], y0[U], x1[U], y1[U];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                {
+                    x0[u] = a[u];
+                    y0[u] = b[u];
+                }
+                i = U;
+                while (true)
+                {
+                    const bool more1 = i + U <= len;
+                    if (more1)
+                    {
+#pragma unroll
+                        for (int u = 0; u < U; u++)
+                        {
+                            x1[u] = a[i + u];
+                            y1[u] = b[i + u];
+                        }
+                        i += U;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) s = dfma(x0[u], y0[u], s);
+                    if (!more1) break;
+                    const bool more0 = i + U <= len;
+                    if (more0)
+                    {
+#pragma unroll
+                        for (int u = 0; u < U; u++)
+                        {
+                            x0[u] = a[i + u];
+                            y0[u] = b[i + u];
+                        }
+                        i += U;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) s = dfma(x1[u], y1[u], s);
+                    if (!more0) break;
+                }
+            }
+            for (; i < len; i++) s = dfma(a[i], b[i], s);
+            return s;
         }
 
         struct Shared
@@ -79,8 +257,7 @@ namespace lexls
                 {
                     if (tid == 0)
                     {
-                        double t = 0.0;
-                        for (uint32_t i = 1; i < rows; i++) t = dfma(ess[i - 1], v[j + i], t);
+                        double t = chain_dot<8>(ess, v + j + 1, rows - 1, 0.0);
                         t += v[j];
                         *bcast = t;
                     }
@@ -147,6 +324,10 @@ namespace lexls
             const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
             const size_t pstride = (size_t)cap * (n + 1);
             if (a.skip && a.skip[b]) return; // uniform per workgroup
+            // terms per read batch of the ordered chains: the one-wavefront form serves large batches of small problems, where registers
+            // are occupancy (16 -> 157 VGPRs, 3 wavefronts per SIMD: measured slower there); the wide forms run one workgroup per CU
+            constexpr int CH = NT >= 256 ? 16 : 4;
+            GSTAMP_DECL
 
             // ---- LDS carve-up (doubles first) ----
             double *W;
@@ -186,15 +367,74 @@ namespace lexls
                 M += dims[k];
             }
 
+            // ---- fixed variables (lexlse.h:132-143): the column transpositions, and — when the matrix is staged into LDS — the column
+            // order they leave behind, so that the staging pass below places the columns directly (one pass instead of one per variable)
+            const uint32_t nf = a.nfixed ? a.nfixed[b] : 0;
+            for (uint32_t i = tid; i < n; i += NT) perm_s[i] = i;
+            const uint32_t *src = nullptr;
+            if (nf > 0)
+            {
+                __syncthreads();
+                if (tid == 0)
+                {
+                    uint32_t *order = reinterpret_cast<uint32_t *>(norms); // norms is free until the level loop: n + n entries
+                    uint32_t *fidx  = order + n;                             // scratch copy of fixed_var_index
+                    for (uint32_t k = 0; k < nf; k++) fidx[k] = a.fixed_idx[(size_t)b * n + k];
+                    for (uint32_t k = 0; k < nf; k++)
+                    {
+                        const uint32_t coeff = fidx[k];
+                        perm_s[k]            = coeff;
+                        for (uint32_t i = k + 1; i < nf; i++)
+                        {
+                            if (fidx[i] == k)
+                            {
+                                fidx[i] = coeff;
+                                break;
+                            }
+                        }
+                    }
+                    if (LDSMAT)
+                    {
+                        for (uint32_t j = 0; j < n; j++) order[j] = j;
+                        for (uint32_t k = 0; k < nf; k++) // swapping columns k and perm[k] = swapping where they come from
+                        {
+                            const uint32_t c = perm_s[k], t = order[k];
+                            order[k]         = order[c];
+                            order[c]         = t;
+                        }
+                    }
+                }
+                if (LDSMAT) src = reinterpret_cast<const uint32_t *>(norms);
+                __syncthreads();
+            }
+
             // ---- stage the problem (coalesced down the columns) ----
             const double *in = a.in + b * pstride;
             if (LDSMAT || in != W)
-                for (uint32_t j = 0; j <= n; j++)
-                    for (uint32_t i = tid; i < M; i += NT) W[i + j * ld] = in[i + (size_t)j * cap];
+            {
+                // every thread busy and four independent loads in flight per thread (a column at a time leaves NT - M threads idle and
+                // one global round trip per column on the critical path)
+                const uint32_t total = M * (n + 1);
+                for (uint32_t e0 = tid; e0 < total; e0 += 4 * NT)
+                {
+                    double v[4];
+                    uint32_t dst[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                    {
+                        const uint32_t e = e0 + (uint32_t)u * NT;
+                        const uint32_t j = e < total ? e / M : 0, i = e < total ? e - j * M : 0;
+                        const size_t sj  = (src && j < n) ? src[j] : j;
+                        v[u]             = e < total ? in[i + sj * cap] : 0.0;
+                        dst[u]           = e < total ? (uint32_t)(i + j * ld) : 0xffffffffu;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (dst[u] != 0xffffffffu) W[dst[u]] = v[u];
+                }
+            }
             double *hh = a.hh + (size_t)b * cap;
             for (uint32_t i = tid; i < cap; i += NT) hh[i] = 0.0; // initialize(), lexlse.h:1683
-            for (uint32_t i = tid; i < n; i += NT) perm_s[i] = i;
-            const uint32_t nf = a.nfixed ? a.nfixed[b] : 0;
             for (uint32_t i = tid; i < n; i += NT) xs[i] = (i < nf) ? a.fixed_val[(size_t)b * n + i] : 0.0;
             if (a.reg_type) // initialize(): null_space.setZero() (lexlse.h:1686)
             {
@@ -210,41 +450,23 @@ namespace lexls
             }
             __syncthreads();
 
-            // ---- fixed variables: their columns go first, their contribution goes to the RHS (lexlse.h:132-156) ----
+            // ---- fixed variables: their columns go first (done by the staging pass when the matrix lives in LDS), their contribution
+            // goes to the RHS (lexlse.h:132-156) ----
             if (nf > 0)
             {
-                if (tid == 0)
-                {
-                    uint32_t *fi = red_i; // scratch copy of fixed_var_index (nf <= n; red_i has NT entries, so spill to norms when larger)
-                    uint32_t *fidx = (nf <= (uint32_t)NT) ? fi : reinterpret_cast<uint32_t *>(norms);
-                    for (uint32_t k = 0; k < nf; k++) fidx[k] = a.fixed_idx[(size_t)b * n + k];
+                if (!LDSMAT)
                     for (uint32_t k = 0; k < nf; k++)
                     {
-                        const uint32_t coeff = fidx[k];
-                        perm_s[k]            = coeff;
-                        for (uint32_t i = k + 1; i < nf; i++)
-                        {
-                            if (fidx[i] == k)
+                        const uint32_t coeff = perm_s[k];
+                        if (coeff != k)
+                            for (uint32_t i = tid; i < M; i += NT)
                             {
-                                fidx[i] = coeff;
-                                break;
+                                const double t    = W[i + k * ld];
+                                W[i + k * ld]     = W[i + coeff * ld];
+                                W[i + coeff * ld] = t;
                             }
-                        }
+                        __syncthreads();
                     }
-                }
-                __syncthreads();
-                for (uint32_t k = 0; k < nf; k++)
-                {
-                    const uint32_t coeff = perm_s[k];
-                    if (coeff != k)
-                        for (uint32_t i = tid; i < M; i += NT)
-                        {
-                            const double t    = W[i + k * ld];
-                            W[i + k * ld]     = W[i + coeff * ld];
-                            W[i + coeff * ld] = t;
-                        }
-                    __syncthreads();
-                }
                 for (uint32_t i = tid; i < M; i += NT)
                 {
                     double s = 0.0;
@@ -256,6 +478,7 @@ namespace lexls
 
             uint32_t ColIndex  = nf;
             uint32_t TotalRank = nf;
+            GSTAMP(0)
 
             if (ColIndex < n)
             {
@@ -270,11 +493,10 @@ namespace lexls
                     // initial squared column norms of the level (lexlse.h:193-196): one ordered chain per column
                     for (uint32_t k = ColIndex + tid; k < n; k += NT)
                     {
-                        double s = 0.0;
-                        for (uint32_t i = 0; i < dim; i++) s = dfma(W[F + i + k * ld], W[F + i + k * ld], s);
-                        norms[k] = s;
+                        norms[k] = chain_square<CH>(W + F + k * ld, dim, 0.0);
                     }
                     __syncthreads();
+                    GSTAMP(1)
 
                     for (uint32_t counter = 0; counter < dim; counter++)
                     {
@@ -289,14 +511,15 @@ namespace lexls
                                 bv = norms[k];
                                 bi = k;
                             }
-                        const uint32_t piv = block_argmax<NT>(bv, bi, red_v, red_i, tid);
+                        const uint32_t piv = block_argmax_fast<NT>(bv, bi, red_v, red_i, tid, counter & 1u);
+                        GSTAMP(2)
 
                         // fresh norm, rank test, Householder scalars (lexlse.h:210-217, :241)
                         if (tid == 0)
                         {
                             const double *col = W + row + piv * ld;
-                            double fresh      = 0.0;
-                            for (uint32_t i = 0; i < R; i++) fresh = dfma(col[i], col[i], fresh);
+                            double fresh, tailSq;
+                            chain_square_pair<CH>(col, R, fresh, tailSq);
                             norms[piv]     = fresh;
                             sh->stop       = fresh < a.tol;
                             sh->degenerate = 0;
@@ -309,8 +532,6 @@ namespace lexls
                                 norms[piv]             = t;
                                 if (R > 1)
                                 {
-                                    double tailSq = 0.0;
-                                    for (uint32_t i = 1; i < R; i++) tailSq = dfma(col[i], col[i], tailSq);
                                     const double c0 = col[0];
                                     if (tailSq <= DBL_MIN)
                                     {
@@ -329,6 +550,7 @@ namespace lexls
                             }
                         }
                         __syncthreads();
+                        GSTAMP(3)
                         if (sh->stop) break; // uniform
 
                         // column swap over ALL nCtr rows (lexlse.h:222-232) fused with writing beta / the essential part
@@ -362,28 +584,51 @@ namespace lexls
                             }
                         }
                         __syncthreads();
+                        GSTAMP(4)
 
                         // apply H to the trailing columns incl. the RHS (lexlse.h:243-246), then down-date (:262-266)
                         {
                             const double tau  = sh->tau;
                             const double *ess = W + row + 1 + ColIndex * ld;
-                            for (uint32_t j = ColIndex + 1 + tid; j <= n; j += NT)
+                            // Two phases per batch of NT columns.  A: one thread per column walks the ordered dot product (the only serial
+                            // part), updates the column's pivot-row entry and down-dates its norm.  B: ALL threads apply the rank-one
+                            // update to the rows below (lanes along the rows, 32 at a time; the column-per-thread form left 3/4 of the
+                            // workgroup idle through half of the step).  Same operations on every entry, same results.
+                            const bool reflect = R > 1 && tau != 0.0; // uniform
+                            for (uint32_t base = ColIndex + 1; base <= n; base += NT)
                             {
-                                double *col = W + row + j * ld;
-                                if (R > 1 && tau != 0.0)
+                                const uint32_t j = base + tid;
+                                if (j <= n)
                                 {
-                                    double tmp = 0.0;
-                                    for (uint32_t i = 1; i < R; i++) tmp = dfma(ess[i - 1], col[i], tmp);
-                                    tmp += col[0];
-                                    col[0] = dfma(-tau, tmp, col[0]);
-                                    for (uint32_t i = 1; i < R; i++) col[i] = dfma(-(tau * ess[i - 1]), tmp, col[i]);
+                                    double *col = W + row + j * ld;
+                                    if (reflect)
+                                    {
+                                        double tmp = chain_dot<CH>(ess, col + 1, R - 1, 0.0);
+                                        tmp += col[0];
+                                        col[0]     = dfma(-tau, tmp, col[0]);
+                                        red_v[tid] = tmp;
+                                    }
+                                    if (j < n) norms[j] = dfma(-col[0], col[0], norms[j]);
                                 }
-                                if (j < n) norms[j] = dfma(-col[0], col[0], norms[j]);
+                                if (reflect)
+                                {
+                                    __syncthreads();
+                                    const uint32_t nb = (n + 1 - base < (uint32_t)NT) ? n + 1 - base : (uint32_t)NT;
+                                    const uint32_t tx = tid & 31u, ty = tid >> 5;
+                                    for (uint32_t c = ty; c < nb; c += NT / 32)
+                                    {
+                                        double *col      = W + row + (base + c) * ld;
+                                        const double tmp = red_v[c];
+                                        for (uint32_t i = 1 + tx; i < R; i += 32) col[i] = dfma(-(tau * ess[i - 1]), tmp, col[i]);
+                                    }
+                                    if (base + NT <= n) __syncthreads(); // red_v is rewritten by the next batch
+                                }
                             }
                             if (tid == 0 && R > 1) hh[row] = tau;
                         }
                         ColIndex++;
                         __syncthreads();
+                        GSTAMP(5)
                         if (ColIndex == n) break;
                     }
 
@@ -424,6 +669,7 @@ namespace lexls
                         __syncthreads();
                     }
 
+                    GSTAMP(6)
                     if (ColIndex == n) // lexlse.h:475-490
                     {
                         if (tid == 0)
@@ -463,6 +709,7 @@ namespace lexls
                     for (uint32_t i = tid; i < M; i += NT) out[i + (size_t)j * cap] = W[i + j * ld];
             }
 
+            GSTAMP(7)
             // ---- solve(): block back-substitution (lexlse.h:1015-1045) ----
             if (do_solve)
             {
@@ -501,6 +748,8 @@ namespace lexls
                 __syncthreads();
                 for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
             }
+            GSTAMP(8)
+            GSTAMP_WRITE
         }
 
         // -----------------------------------------------------------------------------------------
@@ -902,9 +1151,7 @@ namespace lexls
             {
                 for (uint32_t c = tid; c < Fc; c += NT) // rhs.head(ColDim) -= L^T lambda (lexlse.h:706-707)
                 {
-                    double s = 0.0;
-                    for (uint32_t i = 0; i < dim; i++) s = dfma(W[F + i + c * ld], Lambda[F + i], s);
-                    rhs[c] -= s;
+                    rhs[c] -= chain_dot<8>(W + F + c * ld, Lambda + F, dim, 0.0);
                 }
                 __syncthreads();
                 for (uint32_t k = ObjIndex; k--;)
@@ -921,9 +1168,7 @@ namespace lexls
                         apply_q_block<NT>(W, ld, hh, F, Fc, dim, rank, Lambda + F, bcast, tid);
                     for (uint32_t c = tid; c < Fc; c += NT)
                     {
-                        double s = 0.0;
-                        for (uint32_t i = 0; i < dim; i++) s = dfma(W[F + i + c * ld], Lambda[F + i], s);
-                        rhs[c] -= s;
+                        rhs[c] -= chain_dot<8>(W + F + c * ld, Lambda + F, dim, 0.0);
                     }
                     if (tid == 0) find_descent(ctr_type + F, Lambda + F, dim, tolW, tolC, (int)k, st);
                     __syncthreads();
