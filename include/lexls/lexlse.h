@@ -37,6 +37,8 @@
 #include <lexls/typedefs.h>
 #include <lexls_hip.h>
 
+#include <cstring>
+
 namespace LexLS
 {
     namespace internal
@@ -75,6 +77,10 @@ namespace LexLS
                 nVar = nVar_;
                 nObj = nObj_;
                 check(lexls_lse_create(&h, device, 1, nVar, nObj, maxObjDim));
+                check(lexls_lse_round_layout(h, &lay)); // the small per-factorization arrays travel as ONE block each way
+                round_in.assign(lay.in_bytes, 0);
+                round_out.assign(lay.out_bytes, 0);
+                reg_sent = false;
                 cap = 0;
                 for (Index k = 0; k < nObj; k++) cap += maxObjDim[k];
                 dims.assign(nObj, 0);
@@ -106,9 +112,9 @@ namespace LexLS
                     nCtr += ObjDim_[k];
                     rank[k] = first_col[k] = 0;
                 }
-                check(lexls_lse_set_obj_dim(h, dims.data(), 0));
-                nVarFixedInit = 0;
+                nVarFixedInit = 0; // (the dimensions reach the device with the next factorize(): upload())
                 TotalRank     = 0;
+                ranks_fetched = total_rank_fetched = true;
                 for (Index i = nVarFixed; i < nVar; i++) x(i) = 0.0;
             }
 
@@ -191,32 +197,33 @@ namespace LexLS
                 PROBLEM_DATA = LOD; // :119
                 upload();
                 check(lexls_lse_factorize(h));
-                check(lexls_lse_get_ranks(h, rank.data(), first_col.data(), &TotalRank));
                 factor_on_host = false;
+                ranks_fetched = total_rank_fetched = false; // fetched when asked for (getRank / getTotalRank) or with the solution
+                lambda_pending = false;
             }
             /// lexlse.h:1015-1045
             void solve()
             {
                 check(lexls_lse_solve(h));
-                check(lexls_lse_get_x(h, x.data()));
+                fetch_solution();
             }
             /// lexlse.h:1052-1131
             void solveLeastNorm_1()
             {
                 check(lexls_lse_solve_least_norm(h));
-                check(lexls_lse_get_x(h, x.data()));
+                fetch_solution();
             }
             /// lexlse.h:1138-1213
             void solveLeastNorm_2()
             {
                 check(lexls_lse_solve_least_norm_2(h));
-                check(lexls_lse_get_x(h, x.data()));
+                fetch_solution();
             }
             /// lexlse.h:1222-1277 (needs regularization_type TIKHONOV / TIKHONOV_2 / R, normally with all factors 0)
             void solveLeastNorm_3()
             {
                 check(lexls_lse_solve_least_norm_3(h));
-                check(lexls_lse_get_x(h, x.data()));
+                fetch_solution();
             }
 
             /// lexlse.h:611-762; on return getWorkspace().head(nVarFixed + nLambda) = [lambda_fixed; lambda]
@@ -225,11 +232,11 @@ namespace LexLS
             {
                 if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");
                 check(lexls_lse_sensitivity(h, NULL, static_cast<int32_t>(ObjIndex), tol_wrong_sign_lambda, tol_correct_sign_lambda));
+                check(lexls_lse_download_round(h, round_out.data(), NULL)); // verdict and largest violation in one copy
                 int32_t s3[3];
-                check(lexls_lse_get_sensitivity(h, s3, &maxAbsValue));
-                std::vector<double> lam(nVar + cap);
-                check(lexls_lse_get_lambda(h, lam.data()));
-                for (Index i = 0; i < nVar + cap && i < dWorkspace.size(); i++) dWorkspace(i) = lam[i];
+                std::memcpy(s3, round_out.data() + lay.found, sizeof(s3));
+                std::memcpy(&maxAbsValue, round_out.data() + lay.max_abs, sizeof(double));
+                lambda_pending = true; // the multipliers themselves are fetched when getWorkspace() is read (getLambda, lexlsi.h:552-605)
                 if (s3[0])
                 {
                     CtrIndex2Remove = static_cast<Index>(s3[1]);
@@ -250,6 +257,7 @@ namespace LexLS
                 std::vector<double> lam(nVar + cap);
                 check(lexls_lse_get_lambda(h, lam.data()));
                 for (Index i = 0; i < nVar + cap && i < dWorkspace.size(); i++) dWorkspace(i) = lam[i];
+                lambda_pending       = false;
                 const double *Lambda = lam.data() + nVarFixed;
                 auto scan = [&](int obj, bool fixed, Index first, Index count) {
                     for (Index k = 0; k < count; k++)
@@ -280,16 +288,25 @@ namespace LexLS
                 check(lexls_lse_residual(h));
                 std::vector<double> v(cap);
                 check(lexls_lse_get_v(h, v.data()));
+                lambda_pending = false; // the residuals take the workspace, as in the reference
                 for (Index i = 0; i < nCtr; i++) dWorkspace(i) = v[i];
                 return dWorkspace;
             }
 
             const dVectorType &get_x() const { return x; }
             Index getDim(Index k) const { return dims[k]; }
-            Index getRank(Index k) const { return rank[k]; }
+            Index getRank(Index k) const
+            {
+                fetch_ranks();
+                return rank[k];
+            }
             Index get_nObj() const { return nObj; }
             Index get_nVar() const { return nVar; }
-            Index getTotalRank() const { return TotalRank; }
+            Index getTotalRank() const
+            {
+                if (!total_rank_fetched) fetch_ranks();
+                return TotalRank;
+            }
             Index getFixedVariablesCount() const { return nVarFixed; }
             /// lexlse.h:1495.  The indices as given to fixVariable(); the reference hands out its working copy, which factorize()
             /// rewrites by the chained-index rule (:146-153) — nothing in the reference reads it afterwards.
@@ -317,7 +334,17 @@ namespace LexLS
             }
             /// lexlse.h:770-861: the debug overload that prints every multiplier; use getWorkspace() after the overloads above
             void ObjectiveSensitivity(Index) { throw Exception("lexls_hip: the printing overload of ObjectiveSensitivity is not provided"); }
-            const dVectorType &getWorkspace() const { return dWorkspace; }
+            const dVectorType &getWorkspace()
+            {
+                if (lambda_pending)
+                {
+                    std::vector<double> lam(nVar + cap);
+                    check(lexls_lse_get_lambda(h, lam.data()));
+                    for (Index i = 0; i < nVar + cap && i < dWorkspace.size(); i++) dWorkspace(i) = lam[i];
+                    lambda_pending = false;
+                }
+                return dWorkspace;
+            }
             const dMatrixType &get_data() const { return PROBLEM_DATA; }
             const dMatrixType &get_lexqr()
             {
@@ -343,16 +370,54 @@ namespace LexLS
             {
                 if (rc != LEXLS_OK) throw Exception(std::string("liblexls_hip: ") + lexls_last_error());
             }
+            /// what setObjDim / fixVariable / setCtrType collected goes to the device as one block (lexls_lse_upload_round), the matrix as a
+            /// second copy; the regularization setup only when it changed
             void upload()
             {
+                unsigned char *in = round_in.data();
                 const uint32_t nf = nVarFixed;
-                check(lexls_lse_set_fixed(h, nf ? &nf : NULL, fixed_idx.data(), fixed_val.data(), fixed_type.data()));
-                check(lexls_lse_set_ctr_type(h, ctr_type.data()));
+                std::memcpy(in + lay.dims, dims.data(), sizeof(uint32_t) * nObj);
+                std::memcpy(in + lay.nfixed, &nf, sizeof(uint32_t));
+                std::memcpy(in + lay.fixed_idx, fixed_idx.data(), sizeof(uint32_t) * nVar);
+                std::memcpy(in + lay.fixed_val, fixed_val.data(), sizeof(double) * nVar);
+                in[lay.skip] = 0;
+                const int32_t none = -1;
+                std::memcpy(in + lay.obj_index, &none, sizeof(int32_t));
+                std::memcpy(in + lay.fixed_type, fixed_type.data(), nVar);
+                std::memcpy(in + lay.ctr_type, ctr_type.data(), cap);
+                check(lexls_lse_upload_round(h, in, 0));
                 check(lexls_lse_set_problem_host(h, LOD.data()));
                 if (reg_factor.size() < nObj) reg_factor.assign(nObj, 0.0);
-                check(lexls_lse_set_cg_iterations(h, parameters.max_number_of_CG_iterations));
-                check(lexls_lse_set_regularization(h, static_cast<int>(parameters.regularization_type), reg_factor.data(), 0,
-                                                   parameters.variable_regularization_factor));
+                const int type = static_cast<int>(parameters.regularization_type);
+                if (!reg_sent || type != sent_type || parameters.variable_regularization_factor != sent_variable ||
+                    parameters.max_number_of_CG_iterations != sent_cg || (type != 0 && reg_factor != sent_factor))
+                {
+                    check(lexls_lse_set_cg_iterations(h, parameters.max_number_of_CG_iterations));
+                    check(lexls_lse_set_regularization(h, type, reg_factor.data(), 0, parameters.variable_regularization_factor));
+                    reg_sent      = true;
+                    sent_type     = type;
+                    sent_variable = parameters.variable_regularization_factor;
+                    sent_cg       = parameters.max_number_of_CG_iterations;
+                    sent_factor   = reg_factor;
+                }
+            }
+            /// x and the total rank in one copy (the out slab of the round block)
+            void fetch_solution()
+            {
+                check(lexls_lse_download_round(h, round_out.data(), NULL));
+                std::memcpy(x.data(), round_out.data() + lay.x, sizeof(double) * nVar);
+                uint32_t tr;
+                std::memcpy(&tr, round_out.data() + lay.total_rank, sizeof(uint32_t));
+                TotalRank          = tr;
+                total_rank_fetched = true;
+            }
+            void fetch_ranks() const
+            {
+                if (ranks_fetched) return;
+                Index tr = 0;
+                check(lexls_lse_get_ranks(h, rank.data(), first_col.data(), &tr));
+                TotalRank     = tr;
+                ranks_fetched = total_rank_fetched = true;
             }
 
             void fetch_mu()
@@ -366,12 +431,22 @@ namespace LexLS
             }
 
             lexls_lse_t h;
-            Index nVar, nObj, nCtr, cap, nVarFixed, nVarFixedInit, TotalRank;
+            Index nVar, nObj, nCtr, cap, nVarFixed, nVarFixedInit;
+            mutable Index TotalRank;
             int device;
             bool factor_on_host = false;
             bool sens_scan      = false;
+            lexls_round_layout lay;
+            std::vector<unsigned char> round_in, round_out;
+            mutable bool ranks_fetched = true, total_rank_fetched = true;
+            bool lambda_pending = false, reg_sent = false;
+            int sent_type = 0;
+            double sent_variable = 0.0;
+            Index sent_cg = 0;
+            std::vector<double> sent_factor;
             ParametersLexLSE parameters;
-            std::vector<Index> dims, first_row, rank, first_col, fixed_idx;
+            std::vector<Index> dims, first_row, fixed_idx;
+            mutable std::vector<Index> rank, first_col;
             std::vector<double> fixed_val, reg_factor;
             std::vector<uint8_t> fixed_type, ctr_type;
             dMatrixType LOD, PROBLEM_DATA, FACTOR, X_mu, X_mu_rhs;
