@@ -28,11 +28,11 @@ namespace lexls
 // Diagnostic build only (-DLEXLS_GENERIC_STAMPS): thread 0 of lqr_generic_kernel accumulates shader-clock totals per phase and leaves them in
 // the (otherwise unused) multiplier buffer; the product build contains no stamp.  Phases: 0 stage + init + fixed variables, 1 level norms,
 // 2 pivot search, 3 fresh norm + reflector scalars, 4 column swap + essential part, 5 reflector application + down-date,
-// 6 regularization + Gauss step, 7 results + factor store, 8 solve
+// 6 regularization + Gauss step, 7 results + factor store, 8 solve, 9 the dot-product phase of 5 (up to its barrier)
 #ifdef LEXLS_GENERIC_STAMPS
 #define GSTAMP_DECL                 \
-    unsigned long long gs_acc[9];   \
-    for (int i_ = 0; i_ < 9; i_++) gs_acc[i_] = 0; \
+    unsigned long long gs_acc[10];   \
+    for (int i_ = 0; i_ < 10; i_++) gs_acc[i_] = 0; \
     unsigned long long gs_t0 = clock64();
 #define GSTAMP(i)                                  \
     {                                              \
@@ -42,7 +42,7 @@ namespace lexls
     }
 #define GSTAMP_WRITE \
     if (tid == 0)    \
-        for (int i_ = 0; i_ < 9; i_++) a.lambda[(size_t)b * (n + cap) + i_] = (double)gs_acc[i_];
+        for (int i_ = 0; i_ < 10; i_++) a.lambda[(size_t)b * (n + cap) + i_] = (double)gs_acc[i_];
 #else
 #define GSTAMP_DECL
 #define GSTAMP(i)
@@ -374,16 +374,37 @@ namespace lexls
             const uint32_t *src = nullptr;
             if (nf > 0)
             {
+                uint32_t *order = reinterpret_cast<uint32_t *>(norms); // norms is free until the level loop: n + n entries
+                uint32_t *fidx  = order + n;                             // scratch copy of fixed_var_index
+                uint32_t *where = reinterpret_cast<uint32_t *>(xs);    // xs is initialised after the staging pass: slot that holds a value
+                for (uint32_t k = tid; k < nf; k += NT) fidx[k] = a.fixed_idx[(size_t)b * n + k];
+                for (uint32_t v = tid; v < n; v += NT) where[v] = 0xffffffffu;
                 __syncthreads();
                 if (tid == 0)
                 {
-                    uint32_t *order = reinterpret_cast<uint32_t *>(norms); // norms is free until the level loop: n + n entries
-                    uint32_t *fidx  = order + n;                             // scratch copy of fixed_var_index
-                    for (uint32_t k = 0; k < nf; k++) fidx[k] = a.fixed_idx[(size_t)b * n + k];
+                    // lexlse.h:146-153: slot k takes its variable; the later slot that named variable k is redirected to the column that
+                    // variable k was swapped into.  With distinct indices (the normal case) "the later slot" is a table look-up
+                    bool distinct = true;
+                    for (uint32_t i = 0; i < nf; i++)
+                    {
+                        const uint32_t v = fidx[i];
+                        if (where[v] != 0xffffffffu) distinct = false;
+                        else where[v] = i;
+                    }
                     for (uint32_t k = 0; k < nf; k++)
                     {
                         const uint32_t coeff = fidx[k];
                         perm_s[k]            = coeff;
+                        if (distinct)
+                        {
+                            const uint32_t i = where[k];
+                            if (i != 0xffffffffu && i > k)
+                            {
+                                fidx[i]      = coeff;
+                                where[coeff] = i;
+                            }
+                            continue;
+                        }
                         for (uint32_t i = k + 1; i < nf; i++)
                         {
                             if (fidx[i] == k)
@@ -412,15 +433,16 @@ namespace lexls
             const double *in = a.in + b * pstride;
             if (LDSMAT || in != W)
             {
-                // every thread busy and four independent loads in flight per thread (a column at a time leaves NT - M threads idle and
+                // every thread busy and eight independent loads in flight per thread (a column at a time leaves NT - M threads idle and
                 // one global round trip per column on the critical path)
                 const uint32_t total = M * (n + 1);
-                for (uint32_t e0 = tid; e0 < total; e0 += 4 * NT)
+                constexpr int SU = 8;
+                for (uint32_t e0 = tid; e0 < total; e0 += SU * NT)
                 {
-                    double v[4];
-                    uint32_t dst[4];
+                    double v[SU];
+                    uint32_t dst[SU];
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < SU; u++)
                     {
                         const uint32_t e = e0 + (uint32_t)u * NT;
                         const uint32_t j = e < total ? e / M : 0, i = e < total ? e - j * M : 0;
@@ -429,7 +451,7 @@ namespace lexls
                         dst[u]           = e < total ? (uint32_t)(i + j * ld) : 0xffffffffu;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < SU; u++)
                         if (dst[u] != 0xffffffffu) W[dst[u]] = v[u];
                 }
             }
@@ -613,13 +635,29 @@ namespace lexls
                                 if (reflect)
                                 {
                                     __syncthreads();
+                                    GSTAMP(9)
                                     const uint32_t nb = (n + 1 - base < (uint32_t)NT) ? n + 1 - base : (uint32_t)NT;
                                     const uint32_t tx = tid & 31u, ty = tid >> 5;
-                                    for (uint32_t c = ty; c < nb; c += NT / 32)
+                                    constexpr uint32_t CG = NT / 32; // column groups
+                                    for (uint32_t i = 1 + tx; i < R; i += 32)
                                     {
-                                        double *col      = W + row + (base + c) * ld;
-                                        const double tmp = red_v[c];
-                                        for (uint32_t i = 1 + tx; i < R; i += 32) col[i] = dfma(-(tau * ess[i - 1]), tmp, col[i]);
+                                        const double te = -(tau * ess[i - 1]);
+                                        uint32_t c      = ty;
+                                        for (; c + 3 * CG < nb; c += 4 * CG) // four columns per trip: their reads are issued together
+                                        {
+                                            double *p0 = W + row + i + (base + c) * ld, *p1 = p0 + CG * ld, *p2 = p1 + CG * ld, *p3 = p2 + CG * ld;
+                                            const double c0 = *p0, c1 = *p1, c2 = *p2, c3 = *p3;
+                                            const double t0 = red_v[c], t1 = red_v[c + CG], t2 = red_v[c + 2 * CG], t3 = red_v[c + 3 * CG];
+                                            *p0 = dfma(te, t0, c0);
+                                            *p1 = dfma(te, t1, c1);
+                                            *p2 = dfma(te, t2, c2);
+                                            *p3 = dfma(te, t3, c3);
+                                        }
+                                        for (; c < nb; c += CG)
+                                        {
+                                            double *p0 = W + row + i + (base + c) * ld;
+                                            *p0        = dfma(te, red_v[c], *p0);
+                                        }
                                     }
                                     if (base + NT <= n) __syncthreads(); // red_v is rewritten by the next batch
                                 }

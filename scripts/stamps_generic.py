@@ -21,8 +21,8 @@ for _ in range(20):
     s.factorize_solve(True)
 s.synchronize()
 print(f"{s.last_kernel()}: {(time.perf_counter() - t0) / 20 * 1e6:.1f} us per factorize_solve (batch {batch})")
-lam = s.getWorkspace()[:, :9]
-names = ["stage + init + fixed", "level norms", "pivot search", "fresh norm + scalars", "column swap", "apply + down-date", "regularize + Gauss", "results + factor store", "solve"]
+lam = s.getWorkspace()[:, :10]
+names = ["stage + init + fixed", "level norms", "pivot search", "fresh norm + scalars", "column swap", "apply + down-date", "regularize + Gauss", "results + factor store", "solve", "(of apply) dot products"]
 med = np.median(lam, axis=0); tot = med.sum()
 if tot > 0:
     for nm, v in zip(names, med): print(f"{nm:24s} {v:10.0f} cycles  {100*v/tot:5.1f}%")

@@ -838,3 +838,31 @@ def test_tikhonov_1_sensitivity_and_byproducts(hip, oracle):
             np.testing.assert_array_equal(obj, ref["sens"][:, 2])
             np.testing.assert_array_equal(maxabs, ref["maxabs"])
             np.testing.assert_array_equal(s.getCtrType(), ref["ctr_type_out"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", [0, 1], ids=["default-kernel", "generic-kernel"])
+def test_fixed_variable_index_chains_and_repeats(hip, oracle, policy):
+    """fixVariable index bookkeeping of lexlse.h:132-153 (a later entry that names an already used slot is redirected to the column that
+    slot's variable went to): long chains, a permutation of the leading slots, and the degenerate case of a variable named twice — the
+    generic kernel resolves distinct indices through a look-up table and falls back to the reference's scan otherwise; everything
+    bit-identical to the oracle."""
+    n, dims = 70, [20, 30, 25]
+    cases = [[5, 0, 1, 2, 3, 4], [3, 2, 1, 0], [1, 2, 3, 4, 5, 6, 7, 0], [9, 9, 4], [0, 5, 5, 0], list(range(20, 0, -1)), [2, 0, 2, 1]]
+    batch = len(cases)
+    lod = P.lse_batch(61, batch, n, dims)
+    nfixed = np.array([len(c) for c in cases], np.uint32)
+    idx, val = np.zeros((batch, n), np.uint32), np.zeros((batch, n))
+    for b, c in enumerate(cases):
+        idx[b, :len(c)] = c
+        val[b, :len(c)] = P.normal(62 + b, len(c))
+    ref = oracle.lse_run(lod, dims, n, nfixed=nfixed, fixed_idx=idx, fixed_val=val)
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.set_kernel_policy(policy)
+    s.fixVariables(nfixed, idx, val)
+    s.setProblem(lod)
+    s.factorize_solve()
+    assert s.last_kernel().startswith("lqr_generic")
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    assert_factor_equal(s, ref, dims, n)
