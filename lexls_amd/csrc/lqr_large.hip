@@ -1452,7 +1452,7 @@ namespace lexls
             // rows below the level: a ragged batch may hold a problem with small early levels and many rows below — the grid spans the
             // largest row count of the batch, workgroups beyond a problem's own rows return at once (r0 >= M)
             const uint32_t below = h_rows_max;
-            if (level + 1 < a.nObj && below > 0)
+            if (level + 1 < a.nObj && below > 0 && h_level_max[level] > 0) // (a level that is empty in every problem has rank 0: no Gauss step)
             {
                 if (h_level_max[level] <= 1024)
                     hipLaunchKernelGGL(large_trsm_cols, dim3((below + TRB - 1) / TRB, B), dim3(((h_level_max[level] + 63) / 64) * 64), 0, s, a, st, level);
@@ -1545,7 +1545,7 @@ namespace lexls
         {
             hipLaunchKernelGGL(fast_level_begin, dim3((n + 4) / 4, B), dim3(256), 0, s, a, fb, cur, pp, level);
             bool run_steps = false;
-            if (!all_exhausted && persist)
+            if (!all_exhausted && persist && h_level_max[level] > 0) // (an empty level has no pivot: nothing to launch, no state parity to flip)
             {
                 // the tags restart with every level (and every call): records and column granules of earlier pivots must not match them
                 e = hipMemsetAsync(ctl, 0, sizeof(PersistCtl) + 2 * (size_t)G * PRS * sizeof(PersistCand) + 16 * 2 * (size_t)G * ((maxdim + 1u) & ~1u), s);
@@ -1578,7 +1578,7 @@ namespace lexls
             hipLaunchKernelGGL(fast_level_end, dim3((h_rows_max + 1023) / 1024, n + 1, B), dim3(256), 0, s, a, fb, cur, pp, level);
             cur ^= 1u;
             hipLaunchKernelGGL(fast_level_commit, dim3((B + 63) / 64), dim3(64), 0, s, a, fb, pp);
-            if (level + 1 < a.nObj && h_rows_max > 0)
+            if (level + 1 < a.nObj && h_rows_max > 0 && h_level_max[level] > 0) // (a level that is empty in every problem has rank 0: no Gauss step)
             {
                 LseArgs ac = a;
                 ac.fac     = fb.W[cur];

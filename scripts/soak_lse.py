@@ -15,9 +15,21 @@ from test_gpu_parity import assert_factor_equal
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(20261005)
 t0, cases, kernels, sens_checks = time.time(), 0, {}, 0
+def _draw_wide(rng):
+    """shapes beyond the one-wavefront kernels (SOAK_WIDE=1): the workgroup forms of the generic kernel, LDS-resident and in HBM"""
+    n = int(rng.integers(40, 200))
+    nobj = int(rng.integers(1, 6))
+    md = int(rng.choice([20, 40, 100, 160]))
+    cap_dims = rng.integers(1, md + 1, nobj)
+    batch = int(rng.integers(1, 4))
+    dims = np.stack([np.minimum(cap_dims, rng.integers(0, md + 1, nobj)) if rng.random() < 0.5 else cap_dims for _ in range(batch)]).astype(np.uint32)
+    return n, cap_dims.astype(np.uint32), dims, batch
+
+
+wide = bool(os.environ.get("SOAK_WIDE"))
 while time.time() - t0 < budget:
-    n, cap_dims, dims, batch = _draw(rng)
-    batch = batch if rng.random() < 0.7 else int(rng.integers(5, 40))
+    n, cap_dims, dims, batch = _draw_wide(rng) if wide else _draw(rng)
+    batch = batch if rng.random() < 0.7 or wide else int(rng.integers(5, 40))
     if dims.shape[0] != batch:
         dims = np.repeat(dims[:1], batch, axis=0)
     cap = int(cap_dims.sum())
@@ -33,7 +45,7 @@ while time.time() - t0 < budget:
             lod[b, i, :] = lod[b, j, :]
     fixed = {}
     if rng.random() < 0.4:
-        nf = rng.integers(0, min(n, 6) + 1, batch).astype(np.uint32)
+        nf = rng.integers(0, min(n, 40 if wide else 6) + 1, batch).astype(np.uint32)
         idx = np.zeros((batch, n), np.uint32)
         val = np.zeros((batch, n))
         for b in range(batch):
@@ -65,7 +77,22 @@ while time.time() - t0 < budget:
     k = s.last_kernel()
     kernels[k] = kernels.get(k, 0) + 1
     ctx = f"case {cases}: n={n} cap={cap_dims.tolist()} dims={dims.tolist()} policy={policy} keep={keep} fixed={bool(fixed)} reg={reg} kernel={k}"
-    np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
+    if k.startswith("lqr_large<step-per-pivot"):  # the large fast path: pivots exact, values to 1e-10 (north_star)
+        err = np.abs(s.get_x() - ref["x"]).max()
+        if err > 1e-10 * max(1.0, np.abs(ref["x"]).max()):
+            print("FAIL", ctx, "\n max |dx| =", err, "max |x| =", np.abs(ref["x"]).max(), "perm equal:", np.array_equal(s.get_column_permutations(), ref["perm"]),
+                  "ranks", s.getRanks()[0].tolist(), ref["rank"].tolist())
+            g = hip.BatchedLexLSE(batch, n, cap_dims)
+            g.set_kernel_policy(5)
+            g.setObjDim(dims)
+            g.setProblem(lod)
+            g.factorize_solve(keep_factor=True)
+            print(" bit-exact large path", g.last_kernel(), "max |dx| =", np.abs(g.get_x() - ref["x"]).max())
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            np.savez(os.path.join(ROOT, "gpurun_out", "soak_fail.npz"), lod=lod, dims=dims, cap_dims=cap_dims, n=n)
+            sys.exit(1)
+    else:
+        np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
     np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"], err_msg=ctx)
     np.testing.assert_array_equal(s.getRanks()[0], ref["rank"], err_msg=ctx)
     if keep:

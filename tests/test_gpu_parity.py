@@ -866,3 +866,31 @@ def test_fixed_variable_index_chains_and_repeats(hip, oracle, policy):
     np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
     np.testing.assert_array_equal(s.get_x(), ref["x"])
     assert_factor_equal(s, ref, dims, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", [0, 5], ids=["step-per-pivot", "bit-exact-multi-launch"])
+@pytest.mark.parametrize("empty", [3, 1, 0], ids=["last-level-empty", "middle-level-empty", "first-level-empty"])
+def test_large_path_with_an_empty_level(hip, oracle, empty, policy):
+    """A single problem on the large fast path whose level `empty` has no rows (capacity > 0, dimension 0): found by scripts/soak_lse.py
+    (SOAK_WIDE=1) — the one-launch-per-level kernel was launched for the empty level and flipped the parity of the state buffers, which
+    left x wrong while factor, pivots and ranks were right; an empty first or middle level made both large paths launch their Gauss-step
+    kernel with zero threads (invalid configuration).  Pivots exact, values to 1e-10 on the fast path, bitwise on the other."""
+    n, cap_dims = 188, np.array([149, 44, 131, 64], np.uint32)
+    dims = np.array([[130, 40, 60, 30]], np.uint32)  # (more rows than the generic kernel's LDS image holds, whichever level is emptied)
+    dims[0, empty] = 0
+    m = int(dims.sum())
+    lod = np.zeros((1, n + 1, int(cap_dims.sum())))
+    lod[0, :, :m] = P.normal(4242 + empty, (n + 1) * m).reshape(n + 1, m)
+    ref = oracle.lse_run(lod, dims, n, maxdim=cap_dims)
+    s = hip.BatchedLexLSE(1, n, cap_dims)
+    s.set_kernel_policy(policy)
+    s.setObjDim(dims)
+    s.setProblem(lod)
+    s.factorize_solve()
+    assert s.last_kernel().startswith("lqr_large<step-per-pivot" if policy == 0 else "lqr_large<multi-launch")
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
+    if policy == 5:
+        np.testing.assert_array_equal(s.get_x(), ref["x"])
+    assert np.abs(s.get_x() - ref["x"]).max() <= 1e-10
