@@ -2178,8 +2178,15 @@ namespace lexls
                 hipLaunchKernelGGL(sensitivity_sweep_kernel<SWEEP_MD>, dim3(a.batch), dim3(64), lds_sweep, s, a, d_obj_index, obj_all, tolW, tolC, scan_up ? 1 : 0);
             return hipGetLastError();
         }
-        if (lds_staged <= 40 * 1024 && a.batch <= 4u * (uint32_t)cus)
+        // (up to a problem per CU the whole LDS is there for the taking: a single mid-size problem — configs[0] — walks its chains at LDS
+        // latency instead of through L2)
+        if ((lds_staged <= 40 * 1024 && a.batch <= 4u * (uint32_t)cus) || (lds_staged <= kMaxLdsBytes && a.batch <= (uint32_t)cus))
         {
+            if (lds_staged > 64 * 1024)
+            {
+                hipError_t e = set_lds(sensitivity_kernel<64, true>, lds_staged);
+                if (e != hipSuccess) return e;
+            }
             hipLaunchKernelGGL((sensitivity_kernel<64, true>), dim3(a.batch), dim3(64), lds_staged, s, a, d_obj_index, obj_all, tolW, tolC, scan_up ? 1 : 0);
             return hipGetLastError();
         }
