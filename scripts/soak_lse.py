@@ -14,7 +14,7 @@ from test_gpu_parity import assert_factor_equal
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(20261005)
-t0, cases, kernels, sens_checks = time.time(), 0, {}, 0
+t0, cases, kernels, sens_checks, extra_checks = time.time(), 0, {}, 0, 0
 def _draw_wide(rng):
     """shapes beyond the one-wavefront kernels (SOAK_WIDE=1): the workgroup forms of the generic kernel, LDS-resident and in HBM"""
     n = int(rng.integers(40, 200))
@@ -100,6 +100,13 @@ while time.time() - t0 < budget:
             pass
         else:
             assert_factor_equal(s, ref, dims, n)
+    if keep and not k.startswith("lqr_large") and rng.random() < 0.2:  # residuals and a least-norm solve from the factor just made
+        np.testing.assert_array_equal(s.get_v(), ref["v"], err_msg=ctx + " get_v")
+        opt = int(rng.choice([1, 2]))
+        refn = oracle.lse_run(lod, dims, n, maxdim=cap_dims, solve_option=opt, **fixed, **kw)
+        (s.solveLeastNorm_1 if opt == 1 else s.solveLeastNorm_2)()
+        np.testing.assert_array_equal(s.get_x(), refn["x"], err_msg=ctx + f" least-norm {opt}")
+        extra_checks += 1
     if reg == 7:  # by-products of the experimental TIKHONOV_1 (generic kernel)
         xm, _, rm = s.get_mu()
         np.testing.assert_array_equal(xm, ref["x_mu"], err_msg=ctx)
@@ -116,4 +123,4 @@ while time.time() - t0 < budget:
         sens_checks += 1
     s.close()
     cases += 1
-print(f"soak ok: {cases} random cases ({sens_checks} with a removal search) in {time.time() - t0:.0f} s; kernels: " + ", ".join(f"{k} x{v}" for k, v in sorted(kernels.items())))
+print(f"soak ok: {cases} random cases ({sens_checks} with a removal search, {extra_checks} with residuals + a least-norm solve) in {time.time() - t0:.0f} s; kernels: " + ", ".join(f"{k} x{v}" for k, v in sorted(kernels.items())))
