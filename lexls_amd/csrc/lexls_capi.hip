@@ -624,7 +624,8 @@ extern "C"
         h->max_level_dim = max_level;
         h->dims_set      = true;
         h->has_fixed     = any_fixed;
-        h->has_skip      = true;
+        h->has_skip      = false; // kernels look at the mask only when some problem is masked (the one-launch-per-level large kernel needs "none")
+        for (uint32_t b = 0; b < h->batch && !h->has_skip; b++) h->has_skip = skip[b] != 0;
         h->factor_valid  = false;
         if (gather)
         {
