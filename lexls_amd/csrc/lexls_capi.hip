@@ -679,6 +679,12 @@ extern "C"
             const int ll = h->fused_gather ? -1 : (h->force_generic == 2 ? -1 : (h->force_generic == 3 ? 1 : (h->force_generic == 4 ? 2 : 0)));
             HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, ll, h->stream, &variant)); // always solves as well
         }
+        else if (shape_kernels && h->force_generic != 2 && h->max_rows > 64 && h->max_level_dim <= 16 && a.nObj <= 16 &&
+                 deep_kernel_supports(a, h->max_level_dim, write_factor, h->has_fixed))
+        {
+            // deep hierarchies (more than 64 rows in all): the left-looking kernels, whose LDS holds pivot rows only
+            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, 2, h->stream, &variant));
+        }
         else if (shape_kernels && h->reg_type == 0 && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
         {
             if (h->force_generic == 5) // the bit-exact multi-launch path (ordered chains: parity tests, reference for the fast path)

@@ -24,6 +24,7 @@ namespace lexls
 
     // lqr_small.hip — one wavefront per problem, problem in VGPRs (n+1 <= 64, rows <= 64, level dims <= 16)
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed);
+    bool deep_kernel_supports(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed);
     bool wave_dispatch_is_register_resident(const LseArgs &a, uint32_t max_level_dim, bool has_fixed, int left_looking);
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
                                const char **variant);

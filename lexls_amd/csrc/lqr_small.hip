@@ -87,6 +87,16 @@ namespace lexls
         return !(lwave_pays && !has_fixed && max_level_dim <= 12 && nc <= 41 && a.nObj <= 8);
     }
 
+    /// Deep hierarchies — more than 64 rows in all, which the register-resident kernel's LDS image of the rows below a level cannot hold —
+    /// are served by the left-looking kernels (a level's rows come from HBM when the level starts; LDS holds only the finished pivot rows,
+    /// at most nVar of them): true when launch_lqr_wave with left_looking = 2 ends in lqr_quad or lqr_lwave for these arguments
+    bool deep_kernel_supports(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed)
+    {
+        if (a.reg_type != 0 || a.nVar + 1 > 64) return false;
+        if (quad_choice(a, max_level_dim, write_factor, 2, has_fixed) != 0) return true;
+        return !has_fixed && max_level_dim <= 12 && a.nVar + 1 <= 41 && a.nObj <= 8;
+    }
+
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
                                const char **variant)
     {

@@ -566,3 +566,17 @@ def test_batch_with_deactivate_first_wrong_sign(hip, oracle):
         np.testing.assert_array_equal(r["x"][b], o["x"])
         np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
     assert any(i["deactivations"] > 0 for i in r["info"])
+
+
+def test_lock_step_batch_with_a_deep_hierarchy(hip, oracle):
+    """seven levels of an IK-sized problem (more than 64 constraint rows in all): the equality problems of the batch run on the left-looking
+    kernels; every instance ends where its oracle-backed solve ends"""
+    n, dims, batch = 30, [8, 12, 12, 12, 12, 12, 10], 10
+    problems = [P.lsi_problem(1200 + b, n, dims) for b in range(batch)]
+    r = lexlsi.lsi_batch_solve(n, problems)
+    for b in range(batch):
+        o = oracle.lsi_run(n, problems[b])
+        assert r["info"][b] == o["info"], b
+        np.testing.assert_array_equal(r["x"][b], o["x"])
+        np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
+        np.testing.assert_array_equal(r["v"][b], np.concatenate(o["v"]))

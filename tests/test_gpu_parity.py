@@ -894,3 +894,47 @@ def test_large_path_with_an_empty_level(hip, oracle, empty, policy):
     if policy == 5:
         np.testing.assert_array_equal(s.get_x(), ref["x"])
     assert np.abs(s.get_x() - ref["x"]).max() <= 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keep", [False, True], ids=["x-only", "factor-kept"])
+def test_deep_hierarchies_on_the_left_looking_kernels(hip, oracle, keep):
+    """More than 64 rows in all (six to eight levels of an IK-sized problem) do not fit the register-resident kernel's LDS image of the rows
+    below a level; the left-looking kernels read a level's rows when the level starts and serve them: four-per-wavefront kernel where its
+    slots hold the columns, left-looking wave kernel otherwise — full rank, rank-deficient and ragged levels, fixed variables; bit-identical
+    to the oracle and to the generic kernel."""
+    cases = [(40, [12] * 8, None, 0, "lqr_quad<3,12,shift 7"), (40, [12] * 7, [12, 9, 6, 3, 3, 3, 2], 0, "lqr_quad<3,12,shift 7"), (30, [10, 12, 12, 11, 12, 9, 8], None, 3, "lqr_quad<3,12"),
+             (47, [12] * 6, None, 0, "lqr_quad<3,12"), (55, [16, 14, 16, 12, 16], None, 0, "lqr_quad<4,16" if not keep else "lqr_generic"), (36, [12] * 8, None, 2, "lqr_quad<3,12")]
+    for (n, dims, ranks, nfix, kernel) in cases:
+        batch = 9
+        lod = np.stack([(P.rank_deficient_problem(5000 + b, n, dims, ranks) if ranks else P.lse_problem(5000 + b, n, dims)) for b in range(batch)])
+        rdims = np.tile(np.array(dims, np.uint32), (batch, 1))
+        rdims[1, 2] = 5  # a ragged problem inside the wavefront
+        rdims[6, 0] = 0
+        packed = np.zeros_like(lod)
+        for b in range(batch):
+            r = c = 0
+            for k, d in enumerate(dims):
+                packed[b, :, r:r + int(rdims[b, k])] = lod[b, :, c:c + int(rdims[b, k])]
+                r += int(rdims[b, k])
+                c += d
+        kw = {}
+        if nfix:
+            idx, val = np.zeros((batch, n), np.uint32), np.zeros((batch, n))
+            idx[:, :nfix] = [7, 2, 11][:nfix]
+            val[:, :nfix] = P.normal(5100, nfix)
+            kw = dict(nfixed=np.array([nfix] * (batch - 1) + [1], np.uint32), fixed_idx=idx, fixed_val=val)
+        ref = oracle.lse_run(packed, rdims, n, maxdim=np.array(dims, np.uint32), **kw)
+        s = hip.BatchedLexLSE(batch, n, dims)
+        s.setObjDim(rdims)
+        if nfix:
+            s.fixVariables(kw["nfixed"], idx, val)
+        s.setProblem(packed)
+        s.factorize_solve(keep_factor=keep)
+        assert s.last_kernel().startswith(kernel), (s.last_kernel(), kernel, n, dims)
+        np.testing.assert_array_equal(s.get_x(), ref["x"])
+        np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+        np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
+        if keep:
+            assert_factor_equal(s, ref, rdims, n)
+            np.testing.assert_array_equal(s.get_v(), ref["v"])
