@@ -26,10 +26,22 @@ def _draw_wide(rng):
     return n, cap_dims.astype(np.uint32), dims, batch
 
 
+def _draw_deep(rng):
+    """IK-sized problems with five to eight levels (SOAK_DEEP=1): mostly more than 64 rows in all — the left-looking kernels' share of the dispatch"""
+    n = int(rng.integers(6, 64))
+    nobj = int(rng.integers(5, 9))
+    md = int(rng.choice([8, 10, 12, 16]))
+    cap_dims = rng.integers(max(1, md - 4), md + 1, nobj)
+    batch = int(rng.integers(1, 12))
+    dims = np.stack([np.minimum(cap_dims, rng.integers(0, md + 1, nobj)) if rng.random() < 0.5 else cap_dims for _ in range(batch)]).astype(np.uint32)
+    return n, cap_dims.astype(np.uint32), dims, batch
+
+
 wide = bool(os.environ.get("SOAK_WIDE"))
+deep = bool(os.environ.get("SOAK_DEEP"))
 while time.time() - t0 < budget:
-    n, cap_dims, dims, batch = _draw_wide(rng) if wide else _draw(rng)
-    batch = batch if rng.random() < 0.7 or wide else int(rng.integers(5, 40))
+    n, cap_dims, dims, batch = _draw_wide(rng) if wide else (_draw_deep(rng) if deep else _draw(rng))
+    batch = batch if rng.random() < 0.7 or wide or deep else int(rng.integers(5, 40))
     if dims.shape[0] != batch:
         dims = np.repeat(dims[:1], batch, axis=0)
     cap = int(cap_dims.sum())
