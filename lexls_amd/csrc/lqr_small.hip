@@ -21,6 +21,8 @@ namespace lexls
 
     hipError_t launch_quad_3x12_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_4x16_x(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_4x16_f(const LseArgs &a, hipStream_t s);
+    hipError_t launch_quad_4x16_fF(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12s7_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12_f(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12s7_f(const LseArgs &a, hipStream_t s);
@@ -71,7 +73,9 @@ namespace lexls
             if (!has_fixed && a.nVar + 1 <= 32) return 4; // two slots
             return a.nVar == 40 ? 2 : 1; // 2: the IK shape, columns right-aligned in the slots (see SIG in lqr_quad_impl.h)
         }
-        lds = (max_level_dim <= 16 && !write_factor) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0; // n + 1 <= 64, level dims <= 16 (x-only)
+        // n + 1 <= 64, level dims <= 16: x only by default; with the factor kept when forced (deep hierarchies, kernel policy 4) — for batches
+        // the register-resident kernel serves in one round that kernel stays ahead when the factor is wanted
+        lds = (max_level_dim <= 16 && (!write_factor || left_looking == 2)) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0;
         if (lds && lds <= kMaxLdsBytes) return 3;
         return 0;
     }
@@ -136,6 +140,11 @@ namespace lexls
             if (has_fixed) return write_factor ? launch_quad_3x12_fF(a, s) : launch_quad_3x12_xF(a, s);
             return write_factor ? launch_quad_3x12_f(a, s) : launch_quad_3x12_x(a, s);
         case 3:
+            if (write_factor)
+            {
+                *variant = has_fixed ? "lqr_quad<4,16,factor,fixed>" : "lqr_quad<4,16,factor>";
+                return has_fixed ? launch_quad_4x16_fF(a, s) : launch_quad_4x16_f(a, s);
+            }
             *variant = has_fixed ? "lqr_quad<4,16,fixed>" : "lqr_quad<4,16>";
             return has_fixed ? launch_quad_4x16_xF(a, s) : launch_quad_4x16_x(a, s);
         default: break;

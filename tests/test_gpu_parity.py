@@ -904,7 +904,7 @@ def test_deep_hierarchies_on_the_left_looking_kernels(hip, oracle, keep):
     slots hold the columns, left-looking wave kernel otherwise — full rank, rank-deficient and ragged levels, fixed variables; bit-identical
     to the oracle and to the generic kernel."""
     cases = [(40, [12] * 8, None, 0, "lqr_quad<3,12,shift 7"), (40, [12] * 7, [12, 9, 6, 3, 3, 3, 2], 0, "lqr_quad<3,12,shift 7"), (30, [10, 12, 12, 11, 12, 9, 8], None, 3, "lqr_quad<3,12"),
-             (47, [12] * 6, None, 0, "lqr_quad<3,12"), (55, [16, 14, 16, 12, 16], None, 0, "lqr_quad<4,16" if not keep else "lqr_generic"), (36, [12] * 8, None, 2, "lqr_quad<3,12")]
+             (47, [12] * 6, None, 0, "lqr_quad<3,12"), (55, [16, 14, 16, 12, 16], None, 0, "lqr_quad<4,16"), (63, [13, 16, 15, 16, 14], None, 2, "lqr_quad<4,16"), (36, [12] * 8, None, 2, "lqr_quad<3,12")]
     for (n, dims, ranks, nfix, kernel) in cases:
         batch = 9
         lod = np.stack([(P.rank_deficient_problem(5000 + b, n, dims, ranks) if ranks else P.lse_problem(5000 + b, n, dims)) for b in range(batch)])
