@@ -73,9 +73,10 @@ namespace lexls
             if (!has_fixed && a.nVar + 1 <= 32) return 4; // two slots
             return a.nVar == 40 ? 2 : 1; // 2: the IK shape, columns right-aligned in the slots (see SIG in lqr_quad_impl.h)
         }
-        // n + 1 <= 64, level dims <= 16: x only by default; with the factor kept when forced (deep hierarchies, kernel policy 4) — for batches
-        // the register-resident kernel serves in one round that kernel stays ahead when the factor is wanted
-        lds = (max_level_dim <= 16 && (!write_factor || left_looking == 2)) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0;
+        // n + 1 <= 64, level dims <= 16: x only at every batch size; with the factor kept when forced (deep hierarchies, kernel policy 4) or when
+        // the batch needs more than one round of the register-resident kernel (n = 55, [16,14,16,12], factor kept, us per batch, register-
+        // resident / four-per-wavefront: 1024: 168 / 183, 2048: 332 / 206, 4096: 640 / 404, 8192: 1155 / 799)
+        lds = (max_level_dim <= 16 && (!write_factor || left_looking == 2 || lwave_pays)) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0;
         if (lds && lds <= kMaxLdsBytes) return 3;
         return 0;
     }

@@ -938,3 +938,21 @@ def test_deep_hierarchies_on_the_left_looking_kernels(hip, oracle, keep):
         if keep:
             assert_factor_equal(s, ref, rdims, n)
             np.testing.assert_array_equal(s.get_v(), ref["v"])
+
+
+@pytest.mark.gpu
+def test_wide_ik_shapes_keep_their_factor_on_the_quad_kernel_beyond_one_round(hip, oracle):
+    """n + 1 in 49..64 or level dimensions 13..16 with the factor kept: up to one round of the register-resident kernel (2048 problems) that
+    kernel, beyond it `lqr_quad<4,16,factor>` (1.4-1.6x faster there, scripts in DESIGN section 5) — same results, bit-identical to the oracle"""
+    n, dims = 50, [14, 16, 13]
+    for batch, kernel in ((2100, "lqr_quad<4,16,factor>"), (300, "lqr_wave<64,16>")):
+        lod = P.lse_batch(6100, batch, n, dims)
+        lod[7, :, 20] = lod[7, :, 3]  # a rank-deficient problem in the batch
+        ref = oracle.lse_run(lod, dims, n, nthreads=8)
+        s = hip.BatchedLexLSE(batch, n, dims)
+        s.setProblem(lod)
+        s.factorize_solve(keep_factor=True)
+        assert s.last_kernel() == kernel
+        np.testing.assert_array_equal(s.get_x(), ref["x"])
+        np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+        assert_factor_equal(s, ref, dims, n)
