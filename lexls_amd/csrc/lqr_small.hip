@@ -65,18 +65,27 @@ namespace lexls
         // 1024: 62 / 54, 2048: 78 / 58, 4096: 146 / 63: the four-per-wavefront kernel at every batch size; factor kept — 1024: 71 / 98,
         // 2048: 89 / 103, 3072: 144 / 109, 4096: 166 / 115: the register-resident kernel while the batch fits one round of it.
         const bool lwave_pays = left_looking > 0 || (left_looking == 0 && a.batch > resident_wave_capacity());
-        if (!(left_looking == 2 || (left_looking == 0 && (lwave_pays || !write_factor)))) return 0;
+        if (left_looking < 0 || left_looking == 1) return 0; // register-resident / left-looking wave kernel asked for
+        // Factor kept, automatic dispatch (scripts/dispatch_scan.py, register-resident / four-per-wavefront, us per batch): one slot (n = 12,
+        // 3 x 4) 33 / 28 at 256, 42 / 29 at 2048: four-per-wavefront at every batch size; two slots (n = 20, 30) within 10 % up to 1024,
+        // 62 / 56 and 66 / 56 at 2048: from 2048 on; 42..48 columns, where the register-resident alternative is the 64-column
+        // instantiation (n = 47, 4 x 12): 120 / 96 at 256, 299 / 109 at 2048: at every batch size
+        const uint32_t nc = a.nVar + 1;
+        const bool full   = a.batch >= resident_wave_capacity(); // the register-resident kernel is at two wavefronts per SIMD
+        const bool forced = left_looking == 2;
         size_t lds = (max_level_dim <= 12) ? quad_lds_bytes(3, 12, a.nVar, a.nObj) : 0;
         if (lds && lds <= kMaxLdsBytes)
         {
-            if (!has_fixed && a.nVar + 1 <= 16) return 5; // one slot
-            if (!has_fixed && a.nVar + 1 <= 32) return 4; // two slots
+            const bool take = forced || !write_factor || lwave_pays || (!has_fixed && nc <= 16) || (!has_fixed && nc <= 32 && full) || nc > 41;
+            if (!take) return 0;
+            if (!has_fixed && nc <= 16) return 5; // one slot
+            if (!has_fixed && nc <= 32) return 4; // two slots
             return a.nVar == 40 ? 2 : 1; // 2: the IK shape, columns right-aligned in the slots (see SIG in lqr_quad_impl.h)
         }
         // n + 1 <= 64, level dims <= 16: x only at every batch size; with the factor kept when forced (deep hierarchies, kernel policy 4) or when
         // the batch needs more than one round of the register-resident kernel (n = 55, [16,14,16,12], factor kept, us per batch, register-
-        // resident / four-per-wavefront: 1024: 168 / 183, 2048: 332 / 206, 4096: 640 / 404, 8192: 1155 / 799)
-        lds = (max_level_dim <= 16 && (!write_factor || left_looking == 2 || lwave_pays)) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0;
+        // resident / four-per-wavefront: 1024: 168 / 183, 2048: 332 / 206, 4096: 640 / 404, 8192: 1155 / 799: from 2048 on)
+        lds = (max_level_dim <= 16 && (!write_factor || forced || lwave_pays || full)) ? quad_lds_bytes(4, 16, a.nVar, a.nObj) : 0;
         if (lds && lds <= kMaxLdsBytes) return 3;
         return 0;
     }
