@@ -559,7 +559,10 @@ extern "C"
         // (a forced left-looking / four-per-wavefront policy is honoured; otherwise the register-resident kernel at every batch size: on the
         // ragged problems of a lock-step LSI stage, with the gather fused, it beats the four-per-wavefront kernel + gather launch also beyond
         // one round — 4096 instances, warm-started ~30 iterations: 37.1 ms vs 39.1 ms)
-        const int ll = h->force_generic == 3 ? 1 : (h->force_generic == 4 ? 2 : -1);
+        // 42..48 columns are the exception: their register-resident form is the 64-column instantiation, and the four-per-wavefront kernel
+        // behind a gather launch is ahead of it at every batch size (1024 instances, n = 47, 5 x 12, cold: 21.3 -> 17.1 ms)
+        const bool wide_slot = h->nVar + 1 > 41 && h->nVar + 1 <= 48 && h->max_level_dim <= 12;
+        const int ll = h->force_generic == 3 ? 1 : (h->force_generic == 4 ? 2 : (wide_slot && h->force_generic == 0 ? 0 : -1));
         if (h->force_generic != 1 && h->reg_type == 0 && wave_kernel_supports(h->args(), h->max_rows, h->max_level_dim, h->has_fixed) &&
             wave_dispatch_is_register_resident(h->args(), h->max_level_dim, h->has_fixed, ll))
             h->fused_gather = true;

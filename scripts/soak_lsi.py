@@ -11,7 +11,7 @@ rng = np.random.default_rng(20261004)
 t0, cases, insts = time.time(), 0, 0
 wide = bool(os.environ.get("SOAK_WIDE"))  # shapes beyond the one-wavefront kernels: generic kernel, host-side active-set logic
 while time.time() - t0 < budget:
-    n = int(rng.integers(50, 121)) if wide else int(rng.integers(4, 41))
+    n = int(rng.integers(50, 121)) if wide else int(rng.integers(4, 48))
     nobj = int(rng.integers(2, 6 if wide else 9))  # up to eight levels: deep hierarchies (more than 64 rows) take the left-looking kernels
     dims = [int(rng.integers(1, 41 if wide else 13)) for _ in range(nobj)]
     sb = bool(rng.integers(0, 2))

@@ -580,3 +580,18 @@ def test_lock_step_batch_with_a_deep_hierarchy(hip, oracle):
         np.testing.assert_array_equal(r["x"][b], o["x"])
         np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
         np.testing.assert_array_equal(r["v"][b], np.concatenate(o["v"]))
+
+
+def test_lock_step_batch_with_42_to_48_columns(hip, oracle):
+    """43..48 columns (n = 42..47): the rounds of a lock-step batch use the four-per-wavefront kernel behind a gather launch instead of the
+    64-column register-resident instantiation; trajectories and results identical to the oracle-backed driver"""
+    for n, dims in ((47, [10, 12, 12, 11]), (43, [12, 9, 12])):
+        batch = 9
+        problems = [P.lsi_problem(1300 + b, n, dims) for b in range(batch)]
+        r = lexlsi.lsi_batch_solve(n, problems)
+        for b in range(batch):
+            o = oracle.lsi_run(n, problems[b])
+            assert r["info"][b] == o["info"], b
+            np.testing.assert_array_equal(r["x"][b], o["x"])
+            np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
+            np.testing.assert_array_equal(r["v"][b], np.concatenate(o["v"]))
