@@ -8,6 +8,8 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n, dims = 88, [33, 3, 2, 97]
 if len(sys.argv) > 2 and sys.argv[2] == "n47":  # 48 columns: beyond the 41-column register-resident instantiation
     n, dims = 47, [12, 12, 12, 12, 12]
+if len(sys.argv) > 2 and sys.argv[2] == "n55":  # the 64-column shapes
+    n, dims = 55, [12, 16, 14, 16]
 if len(sys.argv) > 2 and sys.argv[2] == "n12":  # one slot of the four-per-wavefront kernel
     n, dims = 12, [6, 4, 4, 4]
 if len(sys.argv) > 2 and sys.argv[2] == "deep":  # IK-sized problem with eight levels: 12 simple bounds + 7 x 12 rows (deep hierarchy: left-looking kernels)
