@@ -1,6 +1,6 @@
 """Is the automatic dispatch the fastest kernel?  Times every kernel policy (0 automatic, 2 register-resident, 3 left-looking wave, 4 four per wavefront)
 on a grid of IK-like shapes x batch sizes x {x only, factor kept} and prints the cases where the automatic choice is more than 10 % behind the best.
-usage: python scripts/dispatch_scan.py"""
+usage: python scripts/dispatch_scan.py [--fixed] [-v]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,6 +16,10 @@ for n, dims in shapes:
             for pol in (0, 2, 3, 4):
                 s = lexls_amd.BatchedLexLSE(batch, n, dims)
                 s.set_kernel_policy(pol)
+                if "--fixed" in sys.argv:  # three fixed variables per problem (an active simple-bounds level of a LexLSI iteration)
+                    idx = np.zeros((batch, n), np.uint32)
+                    idx[:, :3] = [min(5, n - 1), 1, min(9, n - 2)]
+                    s.fixVariables(np.full(batch, 3, np.uint32), idx, np.zeros((batch, n)))
                 s.setProblem(lod)
                 for _ in range(3):
                     s.factorize_solve(keep)
