@@ -40,7 +40,7 @@ struct lexls_lse_s
 {
     int device;
     hipStream_t stream;
-    uint32_t batch, nVar, nObj, cap, max_rows, max_level_dim;
+    uint32_t batch, nVar, nObj, cap, max_rows, max_level_dim, min_level_dim;
     int force_generic;
     std::vector<uint32_t> maxdim, level_max;
     void *d_large_state;
@@ -93,6 +93,7 @@ struct lexls_lse_s
         a.fcol  = d_fcol;
         a.totalrank  = d_totalrank;
         a.dims       = d_dims;
+        a.uniform_dim = (dims_set && min_level_dim == max_level_dim) ? max_level_dim : 0u;
         a.nfixed     = has_fixed ? d_nfixed : nullptr;
         a.fixed_idx  = d_fixed_idx;
         a.fixed_val  = d_fixed_val;
@@ -160,6 +161,7 @@ extern "C"
         }
         h->max_rows    = h->cap;
         h->max_level_dim = 0;
+        h->min_level_dim = 0;
         h->force_generic = 0;
         if (const char *e = std::getenv("LEXLS_KERNEL_POLICY")) h->force_generic = std::atoi(e); // diagnostic default of lexls_lse_set_kernel_policy
         h->tol         = 1e-12; // typedefs.h:120
@@ -361,7 +363,7 @@ extern "C"
             d_tmp.resize(nd);
             d = d_tmp.data();
         }
-        uint32_t max_rows = 0, max_level = 0;
+        uint32_t max_rows = 0, max_level = 0, min_level = 0xffffffffu;
         h->level_max.assign(h->nObj, 0);
         for (uint32_t b = 0; b < h->batch; b++)
         {
@@ -373,6 +375,7 @@ extern "C"
                 d[(size_t)b * h->nObj + k] = v;
                 m += v;
                 if (v > max_level) max_level = v;
+                if (v < min_level) min_level = v;
                 if (v > h->level_max[k]) h->level_max[k] = v;
             }
             if (m > max_rows) max_rows = m;
@@ -389,6 +392,7 @@ extern "C"
             HIP_TRY(hipStreamSynchronize(h->stream)); // d is a temporary
         h->max_rows      = max_rows ? max_rows : 1;
         h->max_level_dim = max_level;
+        h->min_level_dim = min_level;
         h->dims_set     = true;
         h->factor_valid = false;
         return LEXLS_OK;
@@ -549,6 +553,7 @@ extern "C"
         for (uint32_t v : h->maxdim) max_level = v > max_level ? v : max_level;
         h->max_rows      = h->cap ? h->cap : 1;
         h->max_level_dim = max_level;
+        h->min_level_dim = 0; // this round's dimensions are known to the device only
         h->dims_set      = true;
         h->has_fixed     = has_fixed != 0;
         h->has_skip      = true;
@@ -591,7 +596,7 @@ extern "C"
         const uint32_t *row_ld   = reinterpret_cast<const uint32_t *>(in + L.row_ld);
         // the host-side checks and bookkeeping of set_obj_dim / set_fixed / gather_problem (skipped problems included: a later
         // sensitivity call may still serve them, and the kernels' LDS budget follows the largest problem of the batch)
-        uint32_t max_rows = 0, max_level = 0;
+        uint32_t max_rows = 0, max_level = 0, min_level = 0xffffffffu;
         bool any_fixed = false;
         h->level_max.assign(h->nObj, 0);
         if (gather && !h->d_cdata) return fail(LEXLS_ERR_INVALID, "upload_round: call lexls_lse_set_constraint_data first");
@@ -604,6 +609,7 @@ extern "C"
                 if (v > h->maxdim[k]) return fail(LEXLS_ERR_INVALID, "upload_round: dimension exceeds the capacity given at creation");
                 m += v;
                 if (v > max_level) max_level = v;
+                if (v < min_level) min_level = v;
                 if (v > h->level_max[k]) h->level_max[k] = v;
             }
             if (m > max_rows) max_rows = m;
@@ -625,6 +631,7 @@ extern "C"
         h->fused_gather  = false;
         h->max_rows      = max_rows ? max_rows : 1;
         h->max_level_dim = max_level;
+        h->min_level_dim = min_level;
         h->dims_set      = true;
         h->has_fixed     = any_fixed;
         h->has_skip      = false; // kernels look at the mask only when some problem is masked (the one-launch-per-level large kernel needs "none")
@@ -680,7 +687,10 @@ extern "C"
         if (shape_kernels && wave_kernel_supports(a, h->max_rows, h->max_level_dim, h->has_fixed))
         {
             const int ll = h->fused_gather ? -1 : (h->force_generic == 2 ? -1 : (h->force_generic == 3 ? 1 : (h->force_generic == 4 ? 2 : 0)));
-            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, ll, h->stream, &variant)); // always solves as well
+            // the tolerance-contract kernel (lqr_qtol_impl.h): automatic dispatch and policy 6; LEXLS_QTOL=0 keeps every solve bit-exact
+            static const bool qtol_env = !(std::getenv("LEXLS_QTOL") && std::atoi(std::getenv("LEXLS_QTOL")) == 0);
+            const bool tol_ok = !h->fused_gather && (h->force_generic == 6 || (h->force_generic == 0 && qtol_env));
+            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, ll, h->stream, &variant, tol_ok)); // always solves as well
         }
         else if (shape_kernels && h->force_generic != 2 && h->max_rows > 64 && h->max_level_dim <= 16 && a.nObj <= 16 &&
                  deep_kernel_supports(a, h->max_level_dim, write_factor, h->has_fixed))

@@ -30,6 +30,7 @@ namespace lexls
         uint32_t *fcol;                  // batch x nObj
         uint32_t *totalrank;             // batch
         const uint32_t *dims;            // batch x nObj
+        uint32_t uniform_dim;            // != 0: EVERY level of EVERY problem has exactly this many rows (host-side knowledge; 0 = ragged / unknown)
         const uint32_t *nfixed;          // batch (NULL: no fixed variables anywhere)
         const uint32_t *fixed_idx;       // batch x nVar
         const double *fixed_val;         // batch x nVar

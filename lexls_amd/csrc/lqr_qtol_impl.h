@@ -1,0 +1,589 @@
+// FOUR PROBLEMS PER WAVEFRONT, x-only, TOLERANCE-CONTRACT lexicographic-QR kernel for IK-sized batches — the bench kernel since round 3
+// (lexlse.h:117-506 factorize() + :1015-1045 solve()).
+//
+// Contract (BASELINE north_star): column permutation, ranks and first columns EXACTLY those of the reference algorithm (first-maximum
+// column pivoting on down-dated norms, rank test on the fresh squared norm against tol_linear_dependence), x within 1e-10.  Unlike
+// lqr_quad_impl.h (same wavefront mapping, bit-identical to oracle/lexlse_oracle.h, still behind lexls_lse_set_kernel_policy(h, 4)) the
+// VALUES are not held to the oracle's summation order, which buys:
+//   * the reflector in RAW form.  With w = [c0 - beta; column tail] (= (c0 - beta) [1; essential part], lexlse.h:239-248) and
+//     q = 1 / ((c0 - beta) beta):   H a = a + q (w.a) w.   The dot products w.a run on the raw pivot column BESIDE the sqrt / reciprocal
+//     chain instead of behind it, and no essential part / tau is ever formed or broadcast (22 row broadcasts per pivot gone);
+//   * NORMALISED images: a finished pivot row is kept as [R T | rhs] / R_jj.  The Gauss elimination of a later level's rows
+//     (lexlse.h:431-471) then needs no multiplier product (a[r][P] -= a[r][c'] U'[c'][P]) and the back-substitution (lexlse.h:1015-1045) no
+//     division.  The sign of beta cancels in U', so identity reflectors (tail == 0, last row of a level) need no special case;
+//   * the search for pivot j+1 (butterflies on the down-dated norms, lexlse.h:205-206, :262-266) is issued right after row j of the block is
+//     final, in front of the rank-one update of the rows below — latency chain and fma stream overlap;
+//   * coalesced level loads: a level's rows arrive as 48-byte pieces of columns in consecutive lanes (a third of the line look-ups of the
+//     column-per-lane load), are requested ONE LEVEL AHEAD (spread over the pivot steps of the level in front) and turned into the
+//     position layout through a 2-KB LDS staging block per problem, half the rows at a time;
+//   * triangular images (the part of [R_q T_q] below the diagonal is never read): 6,880 instead of 8,512 bytes per IK problem — what
+//     makes room for the staging block at one wavefront per SIMD (4 x 10 KB per wavefront, 160 KB per CU).
+// Mapping, position layout, index words: as in lqr_quad_impl.h (one problem per 16-lane DPP row, slot s of lane l = position 16 s + l - SIG
+// when the level started, finished pivots in static lanes, row broadcasts with v_mov_b64_dpp row_newbcast).
+//
+// Shapes: every level of every problem has exactly MD rows (checked by the host: LseArgs::uniform_dim), no fixed variables, no
+// regularization, n + 1 + SIG <= 16 NS, cap even, 16-byte aligned input.  Anything else takes the bit-exact kernels.
+#pragma once
+#include "lqr_quad_impl.h"
+
+namespace lexls
+{
+    namespace
+    {
+        /// 1 / x to full double precision for normal x (v_rcp_f64 + two Newton steps); no scaling: |x| in [1e-290, 1e290]
+        __device__ __forceinline__ double qt_rcp(double x)
+        {
+            double y = __builtin_amdgcn_rcp(x);
+            double e = dfma(-x, y, 1.0);
+            y        = dfma(y, e, y);
+            e        = dfma(-x, y, 1.0);
+            return dfma(y, e, y);
+        }
+
+        /// sqrt(x) for normal x (v_rsq_f64, one coupled iteration, two correction steps — the unscaled core of the library routine)
+        __device__ __forceinline__ double qt_sqrt(double x)
+        {
+            const double y = __builtin_amdgcn_rsq(x);
+            double g       = x * y;
+            double h       = 0.5 * y;
+            const double r = dfma(-h, g, 0.5);
+            g              = dfma(g, r, g);
+            h              = dfma(h, r, h);
+            double d       = dfma(-g, g, x);
+            g              = dfma(d, h, g);
+            d              = dfma(-g, g, x);
+            return dfma(d, h, g);
+        }
+
+        /// a double whose high word is `hi` and whose low word is that of v (sentinel norms: any low word gives a huge negative number)
+        __device__ __forceinline__ double qt_with_hi(double v, int hi) { return __hiloint2double(hi, __double2loint(v)); }
+
+        typedef double qt_d2 __attribute__((ext_vector_type(2))); // 16 bytes as a native vector (the level pieces stay in registers)
+
+        constexpr int kQtSentinelHi = (int)0xFFE00000; // -2^1023 * 1.x: below every down-dated norm, finite whatever the low word
+
+        template <int NS, int MD, int SIG>
+        __global__ __launch_bounds__(64) void lqr_qtol_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes)
+        {
+            static_assert(NS >= 1 && NS <= 4 && MD <= 16 && (MD % 4) == 0, "shape limits of the row layout / two row parts of even size");
+            constexpr int NH  = 2;        // row parts of the staging transposition
+            constexpr int RP  = MD / NH;  // rows per part
+            constexpr int HP  = RP / 2;   // 16-byte pieces per column and part
+            constexpr int NIH = NS * HP;  // load instructions per part (16 NS columns x HP pieces / 16 lanes)
+            extern __shared__ double smem[];
+            char *const L  = reinterpret_cast<char *>(smem);
+            const int lane = threadIdx.x & 63;
+            const int g    = lane >> 4; // row = problem inside the wave
+            const int gl   = lane & 15;
+            const int n    = (int)a.nVar;
+            const int cap  = (int)a.cap;
+            const int nObj = (int)a.nObj;
+            const uint32_t b  = blockIdx.x * 4u + (uint32_t)g;
+            const uint32_t bb = b < a.batch ? b : a.batch - 1u; // rows beyond the batch idle on a valid address
+            const bool live   = b < a.batch && !(a.skip && a.skip[bb]);
+            const uint32_t pstride = (uint32_t)cap * (uint32_t)(n + 1);
+            const double *inw      = a.in + (size_t)blockIdx.x * 4u * pstride; // wave-uniform base; lane offsets stay 32-bit
+            const uint32_t poff    = (bb - blockIdx.x * 4u) * pstride;
+
+            // ---- LDS carve-up of this row's slice (byte offsets; launch_qtol_t computes group_bytes) ----
+            const int o_img   = g * (int)group_bytes;
+            const int o_xs    = o_img + 8 * (int)img_doubles; // 16*NS : x by position (zero until the back-substitution: also the "U" of a position that is no pivot yet)
+            const int o_ex    = o_xs + 8 * 16 * NS;           // MD    : pivot column hand-off of a pivot step
+            const int o_phys  = o_ex + 8 * MD;                // 64 B  : physical column at each position
+            const int o_perm  = o_phys + 64;                  // 64 B  : column_permutations
+            const int o_meta  = o_perm + 64;                  // kQuadMaxObj x {first column, rank, image offset, image width}
+            const int o_emap  = o_meta + 16 * kQuadMaxObj;    // 16 NS x 8 B: byte k of entry j = column index of PHYSICAL column j in the image of level k
+            const int o_stage = o_emap + 8 * 16 * NS;         // (n + 1) x RP doubles: staging block of the level loads
+            auto D   = [&](int off) -> double & { return *reinterpret_cast<double *>(L + off); };
+            auto D2  = [&](int off) -> double2 & { return *reinterpret_cast<double2 *>(L + off); };
+            auto B8  = [&](int off) -> uint8_t & { return *reinterpret_cast<uint8_t *>(L + off); };
+            auto U32 = [&](int off) -> uint32_t & { return *reinterpret_cast<uint32_t *>(L + off); };
+
+#pragma unroll
+            for (int s = 0; s < 4; s++) B8(o_phys + 16 * s + gl) = (uint8_t)(16 * s + gl);
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+            {
+                D(o_emap + 8 * (16 * s + gl)) = 0.0;
+                D(o_xs + 8 * (16 * s + gl))   = 0.0;
+            }
+            quad_lds_fence();
+
+            // ---- level loads: pieces of 16 bytes, HP consecutive pieces = RP rows of one column, columns in consecutive lanes ----
+            const int CH = (n + 1) * HP; // pieces per problem, level and row part
+            qt_d2 chunk[NH][NIH];
+            auto issue_load = [&](auto hh, auto ii, int Frow) __attribute__((always_inline)) {
+                constexpr int h = decltype(hh)::value, i = decltype(ii)::value;
+                if (16 * i < CH) // wave-uniform
+                {
+                    int ch        = 16 * i + gl;
+                    ch            = ch < CH ? ch : CH - 1; // lanes past the end repeat the last piece (same bytes to the same LDS address)
+                    const int col = ch / HP, m = ch - col * HP;
+                    chunk[h][i]   = *reinterpret_cast<const qt_d2 *>(inw + (poff + (uint32_t)(col * cap + Frow + h * RP + 2 * m)));
+                }
+            };
+            auto issue_all_loads = [&](int Frow) __attribute__((always_inline)) {
+                for_each_index<0, NH>([&](auto hh) __attribute__((always_inline)) {
+                    for_each_index<0, NIH>([&](auto ii) __attribute__((always_inline)) { issue_load(hh, ii, Frow); });
+                });
+            };
+
+            double blk[NS][MD]; // the level block, position layout
+            int rp[NS];         // slot s, lane l: LDS byte address of the (triangular) image row of pivot position c = 16 s + l - SIG
+            int rq[NS];         // slot s, lane l: v_perm selector that picks the byte of pivot position c's LEVEL out of a column's index word
+            unsigned long long em[NS]; // the index word of the column held in slot s
+            int pos[NS];        // current position of the column held in slot s
+            int pc[NS];         // its physical column
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+            {
+                rp[s]  = o_xs; // (a position that is not a pivot yet "reads" zeros of the x block: see the elimination)
+                rq[s]  = 0x0c0c0c00;
+                em[s]  = 0ull;
+                pos[s] = 0;
+                pc[s]  = 0;
+            }
+
+            int ColIndex   = 0; // per row (uniform inside a row), like everything below
+            int TotalRank  = 0;
+            int imgoff     = 0; // doubles
+            bool exh       = false;
+            bool have_next = false; // the pieces of the level about to start are already in flight / in registers (wave-uniform)
+            STAMP_DECL
+            STAMP(0)
+
+            for (int k = 0; k < nObj; k++)
+            {
+                const bool work = live && !exh; // x only: once the columns are exhausted nothing below matters
+                const int Fc    = ColIndex;
+                int rank        = 0;
+                if (__ballot(work) == 0ull)
+                {
+                    if (gl == 0)
+                    {
+                        U32(o_meta + 16 * k)      = (uint32_t)Fc;
+                        U32(o_meta + 16 * k + 4)  = 0u;
+                        U32(o_meta + 16 * k + 8)  = (uint32_t)imgoff;
+                        U32(o_meta + 16 * k + 12) = (uint32_t)(n + 1 - Fc);
+                    }
+                    continue;
+                }
+                const int F = k * MD;
+                if (!have_next) issue_all_loads(F);
+
+                // =====================================================================================
+                // position layout of the level; staged pieces -> block
+                // =====================================================================================
+#pragma unroll
+                for (int s = 0; s < NS; s++)
+                {
+                    const int P = 16 * s + gl - SIG;
+                    pc[s]       = (P >= 0 && P < n) ? (int)B8(o_phys + P) : (P == n ? n : 0);
+                    pos[s]      = (P >= 0 && P <= n) ? P : 0x3fffff;
+                    em[s]       = *reinterpret_cast<const unsigned long long *>(L + o_emap + 8 * pc[s]);
+                }
+                for_each_index<0, NH>([&](auto hh) __attribute__((always_inline)) {
+                    constexpr int h = decltype(hh)::value;
+                    for_each_index<0, NIH>([&](auto ii) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ii)::value;
+                        if (16 * i < CH)
+                        {
+                            int ch = 16 * i + gl;
+                            ch     = ch < CH ? ch : CH - 1;
+                            *reinterpret_cast<qt_d2 *>(L + o_stage + 16 * ch) = chunk[h][i];
+                        }
+                    });
+                    quad_lds_fence();
+#pragma unroll
+                    for (int s = 0; s < NS; s++)
+                    {
+#pragma unroll
+                        for (int m = 0; m < HP; m++)
+                        {
+                            const double2 v          = D2(o_stage + 16 * (pc[s] * HP + m));
+                            blk[s][h * RP + 2 * m]     = v.x;
+                            blk[s][h * RP + 2 * m + 1] = v.y;
+                        }
+                    }
+                    quad_lds_fence();
+                });
+                STAMP(1)
+                // the next level's rows: requested while this level is factorised, unless this level can exhaust the columns
+                const bool prefetch = (k + 1 < nObj) && (rows_min(work ? Fc : 0x3fffffff) + MD < n);
+                have_next           = prefetch;
+
+                // =====================================================================================
+                // Gauss elimination of these rows by every finished pivot c' (lexlse.h:431-471, left-looking, normalised pivot rows)
+                // =====================================================================================
+                const int Fcmax = rows_max(work ? Fc : 0);
+                {
+                    // U'[c'][P] of this lane's columns is fetched one pivot ahead of its use (the read depends on a row-broadcast address)
+                    auto fetch_u = [&](auto cc, double (&u)[NS]) __attribute__((always_inline)) {
+                        constexpr int C  = decltype(cc)::value;
+                        constexpr int sc = (C + SIG) / 16, lc = (C + SIG) % 16;
+                        const int rowp   = gbci<lc>(rp[sc]);
+                        const int selq   = gbci<lc>(rq[sc]);
+#pragma unroll
+                        for (int s = sc; s < NS; s++)
+                        {
+                            const unsigned e = __builtin_amdgcn_perm((unsigned)(em[s] >> 32), (unsigned)em[s], (unsigned)selq);
+                            u[s]             = D(rowp + 8 * (int)e);
+                        }
+                    };
+                    double ucur[NS], unext[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; s++) ucur[s] = unext[s] = 0.0;
+                    if (Fcmax > 0) fetch_u(std::integral_constant<int, 0>{}, ucur);
+                    for_each_index<0, 16 * NS - SIG>([&](auto cc) __attribute__((always_inline)) {
+                        constexpr int C  = decltype(cc)::value;
+                        constexpr int sc = (C + SIG) / 16, lc = (C + SIG) % 16;
+                        if (C < Fcmax) // wave-uniform
+                        {
+                            if constexpr (C + 1 < 16 * NS - SIG)
+                            {
+                                if (C + 1 < Fcmax) fetch_u(std::integral_constant<int, C + 1>{}, unext);
+                            }
+                            // a row of the wavefront whose own pivots end before Fcmax meets the zeros of the x block as "U'": every fma adds a zero product
+                            double lr[MD];
+                            for_each_index<0, MD>([&](auto rr) {
+                                constexpr int r = decltype(rr)::value;
+                                lr[r]           = gbc<lc>(blk[sc][r]);
+                            });
+#pragma unroll
+                            for (int s = sc; s < NS; s++)
+                            {
+#pragma unroll
+                                for (int r = 0; r < MD; r++) blk[s][r] = dfma(-lr[r], ucur[s], blk[s][r]);
+                            }
+#pragma unroll
+                            for (int s = 0; s < NS; s++) ucur[s] = unext[s];
+                        }
+                    });
+                }
+                STAMP(7)
+
+                // =====================================================================================
+                // Householder QR with column pivoting of the level (lexlse.h:182-268), slots S0 .. NS-1.
+                // Straight-line per pivot: a row that has stopped keeps executing on data nobody reads again, its bookkeeping frozen by selects.
+                // =====================================================================================
+                auto factor_level = [&](auto s0c) __attribute__((always_inline)) {
+                    constexpr int S0 = decltype(s0c)::value;
+                    double nrm[NS];
+#pragma unroll
+                    for (int s = S0; s < NS; s++)
+                    {
+                        double t = 0.0;
+#pragma unroll
+                        for (int r = 0; r < MD; r++) t = dfma(blk[s][r], blk[s][r], t); // lexlse.h:193-196
+                        nrm[s] = sel(pos[s] >= ColIndex && pos[s] < n, t, qt_with_hi(t, kQtSentinelHi));
+                    }
+                    bool go = work;
+                    // pivot search: first maximum (by position) of the down-dated norms (lexlse.h:205-206).  Local best of the lane's slots first
+                    // (ties to the smaller position), then one f64 max butterfly and one u32 min butterfly inside the row
+                    int lbs      = S0;
+                    bool ispl    = false;
+                    unsigned wkey = 0;
+                    auto search = [&]() __attribute__((always_inline)) {
+                        double bn   = nrm[S0];
+                        unsigned bk = ((unsigned)pos[S0] << 8) | (unsigned)(S0 << 4) | (unsigned)gl;
+                        lbs         = S0;
+#pragma unroll
+                        for (int s = S0 + 1; s < NS; s++)
+                        {
+                            const unsigned ks = ((unsigned)pos[s] << 8) | (unsigned)(s << 4) | (unsigned)gl;
+                            const bool better = nrm[s] > bn || (nrm[s] == bn && ks < bk);
+                            bn                = sel(better, nrm[s], bn);
+                            bk                = sel(better, ks, bk);
+                            lbs               = sel(better, s, lbs);
+                        }
+                        const double m   = row_max16(bn);
+                        const unsigned w = row_min16(bn == m ? bk : 0x7fffffffu);
+                        wkey             = w;
+                        ispl             = bk == w;
+                    };
+                    search();
+
+                    for_each_index<0, MD>([&](auto cnt) __attribute__((always_inline)) {
+                        constexpr int j  = decltype(cnt)::value;
+                        constexpr int ce = j & ~1;
+                        // the next level's pieces, a few per pivot step (executed whether or not this step still has work)
+                        if (prefetch)
+                        {
+                            constexpr int TOT = NH * NIH;
+                            constexpr int lo = j * TOT / MD, hi = (j + 1) * TOT / MD;
+                            for_each_index<lo, hi>([&](auto tt) __attribute__((always_inline)) {
+                                constexpr int t = decltype(tt)::value;
+                                issue_load(std::integral_constant<int, t / NIH>{}, std::integral_constant<int, t % NIH>{}, F + MD);
+                            });
+                        }
+                        const bool act = go;
+                        if (__ballot(act) == 0ull) return;
+
+                        // the pivot's lane hands its column to the row through LDS
+                        {
+                            double colv[MD];
+#pragma unroll
+                            for (int r = ce; r < MD; r++) colv[r] = blk[S0][r];
+#pragma unroll
+                            for (int s = S0 + 1; s < NS; s++)
+                            {
+                                const bool pick = lbs == s;
+#pragma unroll
+                                for (int r = ce; r < MD; r++) colv[r] = sel(pick, blk[s][r], colv[r]);
+                            }
+                            if (ispl)
+                            {
+#pragma unroll
+                                for (int r = ce; r < MD; r += 2) D2(o_ex + 8 * r) = make_double2(colv[r], colv[r + 1]);
+                            }
+                        }
+                        STAMP(2)
+                        quad_lds_fence();
+                        double col[MD];
+#pragma unroll
+                        for (int r = ce; r < MD; r += 2)
+                        {
+                            const double2 v = D2(o_ex + 8 * r);
+                            col[r]          = v.x;
+                            col[r + 1]      = v.y;
+                        }
+                        quad_lds_fence();
+                        const double c0 = col[j];
+                        // tail norm in three partial sums, fresh norm = c0^2 + tail (lexlse.h:210-211, :241)
+                        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                        for (int r = j + 1; r < MD; r++)
+                        {
+                            if ((r - j) % 3 == 1) t0 = dfma(col[r], col[r], t0);
+                            if ((r - j) % 3 == 2) t1 = dfma(col[r], col[r], t1);
+                            if ((r - j) % 3 == 0) t2 = dfma(col[r], col[r], t2);
+                        }
+                        const double tailSq = (t0 + t1) + t2;
+                        const double fresh  = dfma(c0, c0, tailSq);
+                        STAMP(3)
+                        const bool cont = act && !(fresh < a.tol); // rank test on the squared norm (lexlse.h:214)
+                        go              = cont;
+                        if (__ballot(cont) == 0ull) return;
+
+                        // column "swap": update the position map (lexlse.h:222-232)
+                        const int ppos = (int)(wkey >> 8);
+#pragma unroll
+                        for (int s = S0; s < NS; s++)
+                        {
+                            const bool front = cont && pos[s] == ColIndex;
+                            pos[s]           = sel(front, ppos, pos[s]);
+                            pos[s]           = sel(cont && ispl && lbs == s, ColIndex, pos[s]);
+                        }
+                        if (cont && ispl) B8(o_perm + ColIndex) = (uint8_t)ppos;
+
+                        // raw dot products w.a of every live column, beside the scalar chain
+                        double dw[NS];
+#pragma unroll
+                        for (int s = S0; s < NS; s++)
+                        {
+                            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+                            for (int r = j + 1; r < MD; r++)
+                            {
+                                if ((r - j) & 1)
+                                    d0 = dfma(col[r], blk[s][r], d0);
+                                else
+                                    d1 = dfma(col[r], blk[s][r], d1);
+                            }
+                            dw[s] = d0 + d1;
+                        }
+                        // beta = -sign(c0) sqrt(fresh), den = c0 - beta, q = 1 / (den beta), 1 / beta = den q
+                        const double rt   = qt_sqrt(fresh);
+                        const double beta = c0 >= 0.0 ? -rt : rt;
+                        const double den  = c0 - beta;
+                        const double q    = qt_rcp(den * beta);
+                        const double ibet = den * q;
+                        STAMP(4)
+                        // row j of the block (final after this reflector), norm down-date (lexlse.h:262-266), normalisation by 1 / R_jj
+                        double gs[NS];
+#pragma unroll
+                        for (int s = S0; s < NS; s++)
+                        {
+                            gs[s]          = q * dfma(den, blk[s][j], dw[s]);
+                            const double t = dfma(gs[s], den, blk[s][j]);
+                            nrm[s]         = dfma(-t, t, nrm[s]);
+                            nrm[s]         = sel(cont && ispl && lbs == s, qt_with_hi(nrm[s], kQtSentinelHi), nrm[s]);
+                            blk[s][j]      = t * ibet;
+                        }
+                        ColIndex += cont ? 1 : 0;
+                        rank += cont ? 1 : 0;
+                        const bool full = cont && ColIndex == n;
+                        exh             = exh || full;
+                        go              = go && !full;
+                        // the search for the next pivot starts here, in front of the rank-one update of the rows below
+                        if constexpr (j + 1 < MD) search();
+#pragma unroll
+                        for (int s = S0; s < NS; s++)
+                        {
+#pragma unroll
+                            for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs[s], col[r], blk[s][r]);
+                        }
+                        STAMP(5)
+                    });
+                };
+                {
+                    const int s0 = (rows_min(work ? Fc : 0x3fffffff) + SIG) >> 4;
+                    if (NS > 3 && s0 >= 3)
+                        factor_level(std::integral_constant<int, (NS > 3 ? 3 : 0)>{});
+                    else if (NS > 2 && s0 >= 2)
+                        factor_level(std::integral_constant<int, (NS > 2 ? 2 : 0)>{});
+                    else if (NS > 1 && s0 >= 1)
+                        factor_level(std::integral_constant<int, (NS > 1 ? 1 : 0)>{});
+                    else
+                        factor_level(std::integral_constant<int, 0>{});
+                }
+
+                // =====================================================================================
+                // level end: triangular image [R_k T_k | rhs_k] / diag in end-of-level position order, maps
+                // =====================================================================================
+                const int wk   = n + 1 - Fc;
+                const int dump = o_ex; // stores that do not apply go to a dump slot (the hand-off block is idle here): no divergent regions
+#pragma unroll
+                for (int s = 0; s < NS; s++)
+                {
+                    const int P0  = 16 * s + gl - SIG;
+                    const bool mv = work && P0 <= n && P0 >= Fc; // columns that were live in this level (the RHS included)
+                    if (mv)
+                    {
+                        const int e    = pos[s] - Fc; // index of this column in the level's image: end-of-level position order
+                        const int base = o_img + 8 * (imgoff + e);
+#pragma unroll
+                        for (int p = 0; p < MD; p++) D(sel(p < rank && p <= e, base + 8 * (p * wk - p * (p + 1) / 2), dump)) = blk[s][p];
+                        B8(o_emap + 8 * pc[s] + k) = (uint8_t)e;
+                        if (P0 < n) B8(o_phys + pos[s]) = (uint8_t)pc[s];
+                    }
+                    // pivot position P0 of this level: its image row and the selector of this level's index byte
+                    const bool piv = work && P0 >= Fc && P0 < Fc + rank;
+                    const int p    = P0 - Fc;
+                    rp[s]          = sel(piv, o_img + 8 * (imgoff + p * wk - p * (p + 1) / 2), rp[s]);
+                    rq[s]          = sel(piv, 0x0c0c0c00 | k, rq[s]);
+                }
+                STAMP(6)
+                if (gl == 0)
+                {
+                    U32(o_meta + 16 * k)      = (uint32_t)Fc;
+                    U32(o_meta + 16 * k + 4)  = (uint32_t)rank;
+                    U32(o_meta + 16 * k + 8)  = (uint32_t)imgoff;
+                    U32(o_meta + 16 * k + 12) = (uint32_t)wk;
+                }
+                quad_lds_fence();
+                imgoff += wk * rank - rank * (rank - 1) / 2;
+                TotalRank += rank;
+            }
+
+            // ---- solve(): block back-substitution on the normalised images (lexlse.h:1015-1045); lane p <-> row p of a level ----
+            for (int k = nObj; k--;)
+            {
+                const int rank = live ? (int)U32(o_meta + 16 * k + 4) : 0;
+                const int rmax = rows_max(rank);
+                if (rmax == 0) continue;
+                const int Fc = (int)U32(o_meta + 16 * k), ok = (int)U32(o_meta + 16 * k + 8), wk = (int)U32(o_meta + 16 * k + 12);
+                const int c0   = Fc + rank;
+                const int acc  = rank > 0 ? TotalRank - c0 : 0;
+                const int amax = rows_max(acc);
+                const int p    = gl < rank ? gl : 0;
+                const int row  = o_img + 8 * (ok + p * wk - p * (p + 1) / 2);
+                double col[MD];
+#pragma unroll
+                for (int j = 0; j < MD; j++) col[j] = (j < rank && gl < j) ? D(row + 8 * j) : 0.0;
+                double sv = rank > 0 ? D(row + 8 * (n - Fc)) : 0.0;
+                // rhs'_k - T'_k x_later (lexlse.h:1029-1033): the column at final position c sits at its level-k index inside the image;
+                // sixteen solved positions per trip — lane j looks up index and x of position c0 + base + j, the row-broadcast hands them out
+                for (int base = 0; base < amax; base += 16)
+                {
+                    const int c     = c0 + base + gl;
+                    const bool have = base + gl < acc;
+                    const int ph    = have ? (int)B8(o_phys + c) : 0;
+                    const int offv  = have ? (int)B8(o_emap + 8 * ph + k) : 0;
+                    const double xv = have ? D(o_xs + 8 * c) : 0.0;
+                    for_each_index<0, 16>([&](auto jj) {
+                        constexpr int j   = decltype(jj)::value;
+                        const double uj   = D(row + 8 * gbci<j>(offv));
+                        const double tnew = dfma(-uj, gbc<j>(xv), sv);
+                        sv                = sel(base + j < acc, tnew, sv);
+                    });
+                }
+                for_each_index<0, MD>([&](auto jj) {
+                    constexpr int j = MD - 1 - decltype(jj)::value;
+                    if (j < rmax)
+                    {
+                        const double xj = gbc<j>(sv); // unit diagonal
+                        if (j < rank && gl < j) sv = dfma(-col[j], xj, sv);
+                    }
+                });
+                if (gl < rank) D(o_xs + 8 * (Fc + gl)) = sv;
+                quad_lds_fence();
+            }
+            STAMP(9)
+            // ---- results ----
+            if (live)
+            {
+#pragma unroll
+                for (int s = 0; s < NS; s++)
+                {
+                    const int P = 16 * s + gl; // every position once, whatever the layout offset
+                    if (P < n)
+                    {
+                        a.x[(size_t)b * n + B8(o_phys + P)] = D(o_xs + 8 * P); // x = P x: the variable at position P (lexlse.h:1044)
+                        a.perm[(size_t)b * n + P]           = (P < TotalRank) ? (uint32_t)B8(o_perm + P) : (uint32_t)P;
+                    }
+                }
+                if (gl < nObj)
+                {
+                    a.fcol[(size_t)b * nObj + gl] = U32(o_meta + 16 * gl);
+                    a.rank[(size_t)b * nObj + gl] = U32(o_meta + 16 * gl + 4);
+                }
+                if (gl == 0) a.totalrank[b] = (uint32_t)TotalRank;
+            }
+            STAMP(10)
+            STAMP_WRITE
+        }
+
+        /// exact worst case of the triangular images: sum_k ((n+1-Fc_k) rank_k - rank_k (rank_k - 1) / 2) over rank distributions with rank_k <= md
+        inline uint32_t qtol_image_doubles(uint32_t n, uint32_t nObj, uint32_t md)
+        {
+            uint32_t fc = 0, total = 0;
+            for (uint32_t k = 0; k < nObj && fc < n; k++)
+            {
+                const uint32_t r = md < n - fc ? md : n - fc;
+                total += (n + 1 - fc) * r - r * (r - 1) / 2;
+                fc += r;
+            }
+            return (total + 1) & ~1u;
+        }
+
+        template <int NS, int MD>
+        inline size_t qtol_group_bytes(uint32_t n, uint32_t nObj)
+        {
+            return (8 * ((size_t)qtol_image_doubles(n, nObj, MD) + 16 * NS + MD) + 64 + 64 + 16 * kQuadMaxObj + 8 * 16 * NS + 8 * (size_t)(n + 1) * (MD / 2) + 15) &
+                   ~(size_t)15;
+        }
+
+        template <int NS, int MD, int SIG>
+        hipError_t launch_qtol_t(const LseArgs &a, hipStream_t s)
+        {
+            const uint32_t img  = qtol_image_doubles(a.nVar, a.nObj, MD);
+            const size_t gbytes = qtol_group_bytes<NS, MD>(a.nVar, a.nObj);
+            const size_t lds    = 4 * gbytes;
+            if (lds > kMaxLdsBytes || a.nObj > (uint32_t)kQuadMaxObj || a.nVar + 1 + SIG > 16u * NS || a.nVar > 63u) return hipErrorInvalidValue;
+            if (a.uniform_dim != (uint32_t)MD || (a.cap & 1u) || (reinterpret_cast<uintptr_t>(a.in) & 15u) || a.nfixed || a.reg_type != 0) return hipErrorInvalidValue;
+            if (lds > 64 * 1024)
+            {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_qtol_kernel<NS, MD, SIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            const uint32_t blocks = (a.batch + 3u) / 4u;
+            hipLaunchKernelGGL((lqr_qtol_kernel<NS, MD, SIG>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes);
+            return hipGetLastError();
+        }
+    } // namespace
+} // namespace lexls
+
+#define LEXLS_QTOL_INSTANCE(NAME, NS, MD, SIG) \
+    namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_qtol_t<NS, MD, SIG>(a, s); } \
+                      size_t NAME##_lds(uint32_t nVar, uint32_t nObj) { return 4 * qtol_group_bytes<NS, MD>(nVar, nObj); } }

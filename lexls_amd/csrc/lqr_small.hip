@@ -36,6 +36,16 @@ namespace lexls
     hipError_t launch_quad_3x12_fF(const LseArgs &a, hipStream_t s);
     hipError_t launch_quad_3x12s7_fF(const LseArgs &a, hipStream_t s);
     size_t quad_lds_bytes(uint32_t slots, uint32_t md, uint32_t nVar, uint32_t nObj);
+    hipError_t launch_qtol_3x12s7(const LseArgs &a, hipStream_t s);
+    size_t launch_qtol_3x12s7_lds(uint32_t nVar, uint32_t nObj);
+
+    /// the tolerance-contract four-per-wavefront kernel (lqr_qtol_impl.h) serves: x-only solves of batches in which every level of every
+    /// problem has exactly 12 rows, n = 40 (the IK shape of BASELINE configs[2]/[3]), no fixed variables, no regularization
+    static bool qtol_serves(const LseArgs &a, bool write_factor, bool has_fixed)
+    {
+        return !write_factor && !has_fixed && a.reg_type == 0 && a.uniform_dim == 12 && a.nVar == 40 && a.nObj <= 8 && (a.cap & 1u) == 0 &&
+               (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0 && !a.g_cdata && launch_qtol_3x12s7_lds(a.nVar, a.nObj) <= kMaxLdsBytes;
+    }
 
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed)
     {
@@ -112,9 +122,14 @@ namespace lexls
     }
 
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
-                               const char **variant)
+                               const char **variant, bool allow_tolerance)
     {
         const uint32_t nc = a.nVar + 1;
+        if (allow_tolerance && qtol_serves(a, write_factor, has_fixed))
+        {
+            *variant = "lqr_qtol<3,12,shift 7>";
+            return launch_qtol_3x12s7(a, s);
+        }
         if (a.reg_type != 0) // the regularization family: the register-resident kernel's REG instantiations (factor always kept)
         {
             if (max_level_dim <= 12 && nc <= 41)
