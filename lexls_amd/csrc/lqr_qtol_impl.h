@@ -26,6 +26,8 @@
 #pragma once
 #include "lqr_quad_impl.h"
 
+#include <cstdlib>
+
 namespace lexls
 {
     namespace
@@ -58,18 +60,66 @@ namespace lexls
         /// a double whose high word is `hi` and whose low word is that of v (sentinel norms: any low word gives a huge negative number)
         __device__ __forceinline__ double qt_with_hi(double v, int hi) { return __hiloint2double(hi, __double2loint(v)); }
 
+#ifdef LEXLS_WAVE_STAMPS_FINE // = the S0 whose pivot steps are stamped (0: level 0 of the IK shape, 2: its last level)
+#define FSTAMP(i) if constexpr (S0 == LEXLS_WAVE_STAMPS_FINE) STAMP(i)
+#else
+#define FSTAMP(i)
+#endif
+// per-level phase stamps of the diagnostic build: lambda[11 + 4 k + {0 load, 1 eliminate, 2 Householder, 3 level end}]
+#ifdef LEXLS_WAVE_STAMPS
+#define LSTAMP(ph)                                                                                   \
+    {                                                                                                \
+        const unsigned long long t_ = clock64();                                                     \
+        if (gl == 0 && live) a.lambda[(size_t)b * (n + cap) + 11 + 4 * k + (ph)] = (double)(t_ - lst_t0); \
+        lst_t0 = t_;                                                                                 \
+    }
+#else
+#define LSTAMP(ph)
+#endif
         typedef double qt_d2 __attribute__((ext_vector_type(2))); // 16 bytes as a native vector (the level pieces stay in registers)
+
+
+        // ---- the level-ahead pieces live in FIXED accumulation registers a[184:255], managed by inline assembly -----------------------
+        // A piece register that the compiler allocates must have ONE load site (two sites meet in register copies that wait for the loads in
+        // flight: s_waitcnt vmcnt(0) in the middle of the pivot loop), but the requests have to be spread over the whole level in front —
+        // Householder phase included, which exists in one instantiation per number of live slots — because the memory system takes what
+        // every wave of the chip asks for at once at HBM speed only (scripts/ubench/loadpat.hip: ~8-10 k cycles per level and wave when
+        // nothing else is done meanwhile).  So the compiler never sees these registers: piece t is a[184 + 4 t : 187 + 4 t], loaded and
+        // stored by the statements below; the build checks that no other instruction of the code object names a184 .. a255
+        // (scripts/check_qtol_regs.py, run by the Makefile).
+#define QT_PF_LIST(X) X(0, 184, 187) X(1, 188, 191) X(2, 192, 195) X(3, 196, 199) X(4, 200, 203) X(5, 204, 207) X(6, 208, 211) X(7, 212, 215) X(8, 216, 219) \
+    X(9, 220, 223) X(10, 224, 227) X(11, 228, 231) X(12, 232, 235) X(13, 236, 239) X(14, 240, 243) X(15, 244, 247) X(16, 248, 251) X(17, 252, 255)
+        template <int T>
+        __device__ __forceinline__ void qt_pf_load(const double *p)
+        {
+#define QT_PF_LOAD(t, lo, hi) \
+    if constexpr (T == t) asm volatile("global_load_dwordx4 a[" #lo ":" #hi "], %0, off" ::"v"(p) : "memory", "a" #lo, "a" #hi);
+            QT_PF_LIST(QT_PF_LOAD)
+#undef QT_PF_LOAD
+        }
+        template <int T>
+        __device__ __forceinline__ void qt_pf_store_lds(int lds_byte_address)
+        {
+#define QT_PF_STORE(t, lo, hi) \
+    if constexpr (T == t) asm volatile("ds_write_b128 %0, a[" #lo ":" #hi "]" ::"v"(lds_byte_address) : "memory");
+            QT_PF_LIST(QT_PF_STORE)
+#undef QT_PF_STORE
+        }
 
         constexpr int kQtSentinelHi = (int)0xFFE00000; // -2^1023 * 1.x: below every down-dated norm, finite whatever the low word
 
         template <int NS, int MD, int SIG>
-        __global__ __launch_bounds__(64) void lqr_qtol_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes)
+        __global__ __launch_bounds__(64) void lqr_qtol_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes, uint32_t stagger)
         {
             static_assert(NS >= 1 && NS <= 4 && MD <= 16 && (MD % 4) == 0, "shape limits of the row layout / two row parts of even size");
             constexpr int NH  = 2;        // row parts of the staging transposition
             constexpr int RP  = MD / NH;  // rows per part
             constexpr int HP  = RP / 2;   // 16-byte pieces per column and part
             constexpr int NIH = NS * HP;  // load instructions per part (16 NS columns x HP pieces / 16 lanes)
+#ifndef LEXLS_QTOL_PF_STEPS
+#define LEXLS_QTOL_PF_STEPS 9
+#endif
+            constexpr int PF_STEPS = LEXLS_QTOL_PF_STEPS < MD ? LEXLS_QTOL_PF_STEPS : MD; // pivot steps over which a level's requests are spread
             extern __shared__ double smem[];
             char *const L  = reinterpret_cast<char *>(smem);
             const int lane = threadIdx.x & 63;
@@ -88,12 +138,12 @@ namespace lexls
             // ---- LDS carve-up of this row's slice (byte offsets; launch_qtol_t computes group_bytes) ----
             const int o_img   = g * (int)group_bytes;
             const int o_xs    = o_img + 8 * (int)img_doubles; // 16*NS : x by position (zero until the back-substitution: also the "U" of a position that is no pivot yet)
-            const int o_ex    = o_xs + 8 * 16 * NS;           // MD    : pivot column hand-off of a pivot step
+            const int o_ex    = o_xs + 8 * 16 * NS;           // MD    : dump slot of stores that do not apply
             const int o_phys  = o_ex + 8 * MD;                // 64 B  : physical column at each position
             const int o_perm  = o_phys + 64;                  // 64 B  : column_permutations
             const int o_meta  = o_perm + 64;                  // kQuadMaxObj x {first column, rank, image offset, image width}
             const int o_emap  = o_meta + 16 * kQuadMaxObj;    // 16 NS x 8 B: byte k of entry j = column index of PHYSICAL column j in the image of level k
-            const int o_stage = o_emap + 8 * 16 * NS;         // (n + 1) x RP doubles: staging block of the level loads
+            const int o_stage = o_emap + 8 * 16 * NS;         // max((n + 1) RP, 16 MD) doubles: staging block of the level loads; 16 hand-off slots of the pivot steps
             auto D   = [&](int off) -> double & { return *reinterpret_cast<double *>(L + off); };
             auto D2  = [&](int off) -> double2 & { return *reinterpret_cast<double2 *>(L + off); };
             auto B8  = [&](int off) -> uint8_t & { return *reinterpret_cast<uint8_t *>(L + off); };
@@ -109,23 +159,27 @@ namespace lexls
             }
             quad_lds_fence();
 
+            // The four waves of a CU (one per SIMD) start a little apart: every wave of the chip is in the same phase of the same level otherwise,
+            // and each level's rows are asked for by all 1024 waves at once — a burst the HBM serves at its full rate while every SIMD waits
+            if (stagger)
+            {
+                const unsigned simd = __builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | ((2 - 1) << 11)); // HW_REG_HW_ID, bits [5:4] = SIMD
+                for (unsigned i = 0; i < simd * stagger; i++) __builtin_amdgcn_s_sleep(8);
+            }
+
             // ---- level loads: pieces of 16 bytes, HP consecutive pieces = RP rows of one column, columns in consecutive lanes ----
             const int CH = (n + 1) * HP; // pieces per problem, level and row part
-            qt_d2 chunk[NH][NIH];
-            auto issue_load = [&](auto hh, auto ii, int Frow) __attribute__((always_inline)) {
-                constexpr int h = decltype(hh)::value, i = decltype(ii)::value;
+            static_assert(NH * NIH <= 18, "eighteen piece registers");
+            // piece t = (row part t / NIH, instruction t % NIH) of the level whose first row is Frow -> its fixed registers
+            auto prefetch_piece = [&](auto tt, int Frow) __attribute__((always_inline)) {
+                constexpr int t = decltype(tt)::value, h = t / NIH, i = t % NIH;
                 if (16 * i < CH) // wave-uniform
                 {
                     int ch        = 16 * i + gl;
                     ch            = ch < CH ? ch : CH - 1; // lanes past the end repeat the last piece (same bytes to the same LDS address)
                     const int col = ch / HP, m = ch - col * HP;
-                    chunk[h][i]   = *reinterpret_cast<const qt_d2 *>(inw + (poff + (uint32_t)(col * cap + Frow + h * RP + 2 * m)));
+                    qt_pf_load<t>(inw + (poff + (uint32_t)(col * cap + Frow + h * RP + 2 * m)));
                 }
-            };
-            auto issue_all_loads = [&](int Frow) __attribute__((always_inline)) {
-                for_each_index<0, NH>([&](auto hh) __attribute__((always_inline)) {
-                    for_each_index<0, NIH>([&](auto ii) __attribute__((always_inline)) { issue_load(hh, ii, Frow); });
-                });
             };
 
             double blk[NS][MD]; // the level block, position layout
@@ -151,6 +205,9 @@ namespace lexls
             bool have_next = false; // the pieces of the level about to start are already in flight / in registers (wave-uniform)
             STAMP_DECL
             STAMP(0)
+#ifdef LEXLS_WAVE_STAMPS
+            unsigned long long lst_t0 = clock64();
+#endif
 
             for (int k = 0; k < nObj; k++)
             {
@@ -169,7 +226,8 @@ namespace lexls
                     continue;
                 }
                 const int F = k * MD;
-                if (!have_next) issue_all_loads(F);
+                if (!have_next) // the first level, or a level whose predecessor could have exhausted the columns: all pieces at once
+                    for_each_index<0, NH * NIH>([&](auto tt) __attribute__((always_inline)) { prefetch_piece(tt, F); });
 
                 // =====================================================================================
                 // position layout of the level; staged pieces -> block
@@ -184,13 +242,15 @@ namespace lexls
                 }
                 for_each_index<0, NH>([&](auto hh) __attribute__((always_inline)) {
                     constexpr int h = decltype(hh)::value;
+                    // the pieces come out of their fixed registers (requested during the level in front, or just now)
+                    if constexpr (h == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     for_each_index<0, NIH>([&](auto ii) __attribute__((always_inline)) {
                         constexpr int i = decltype(ii)::value;
                         if (16 * i < CH)
                         {
                             int ch = 16 * i + gl;
                             ch     = ch < CH ? ch : CH - 1;
-                            *reinterpret_cast<qt_d2 *>(L + o_stage + 16 * ch) = chunk[h][i];
+                            qt_pf_store_lds<h * NIH + i>(o_stage + 16 * ch);
                         }
                     });
                     quad_lds_fence();
@@ -208,7 +268,9 @@ namespace lexls
                     quad_lds_fence();
                 });
                 STAMP(1)
-                // the next level's rows: requested while this level is factorised, unless this level can exhaust the columns
+                LSTAMP(0)
+                // the next level's rows: requested while this level is factorised (two pieces per pivot step, below), unless this level can
+                // exhaust the columns
                 const bool prefetch = (k + 1 < nObj) && (rows_min(work ? Fc : 0x3fffffff) + MD < n);
                 have_next           = prefetch;
 
@@ -227,16 +289,18 @@ namespace lexls
                         for (int s = sc; s < NS; s++)
                         {
                             const unsigned e = __builtin_amdgcn_perm((unsigned)(em[s] >> 32), (unsigned)em[s], (unsigned)selq);
-                            u[s]             = D(rowp + 8 * (int)e);
+                            u[s]             = D(rowp + (int)(e << 3));
                         }
                     };
-                    double ucur[NS], unext[NS];
+                    double ua[NS], ub[NS]; // even / odd steps (no copies between the steps)
 #pragma unroll
-                    for (int s = 0; s < NS; s++) ucur[s] = unext[s] = 0.0;
-                    if (Fcmax > 0) fetch_u(std::integral_constant<int, 0>{}, ucur);
+                    for (int s = 0; s < NS; s++) ua[s] = ub[s] = 0.0;
+                    if (Fcmax > 0) fetch_u(std::integral_constant<int, 0>{}, ua);
                     for_each_index<0, 16 * NS - SIG>([&](auto cc) __attribute__((always_inline)) {
                         constexpr int C  = decltype(cc)::value;
                         constexpr int sc = (C + SIG) / 16, lc = (C + SIG) % 16;
+                        double(&ucur)[NS]  = (C & 1) ? ub : ua;
+                        double(&unext)[NS] = (C & 1) ? ua : ub;
                         if (C < Fcmax) // wave-uniform
                         {
                             if constexpr (C + 1 < 16 * NS - SIG)
@@ -255,16 +319,21 @@ namespace lexls
 #pragma unroll
                                 for (int r = 0; r < MD; r++) blk[s][r] = dfma(-lr[r], ucur[s], blk[s][r]);
                             }
-#pragma unroll
-                            for (int s = 0; s < NS; s++) ucur[s] = unext[s];
                         }
                     });
                 }
                 STAMP(7)
+                LSTAMP(1)
 
                 // =====================================================================================
                 // Householder QR with column pivoting of the level (lexlse.h:182-268), slots S0 .. NS-1.
-                // Straight-line per pivot: a row that has stopped keeps executing on data nobody reads again, its bookkeeping frozen by selects.
+                // Straight-line per pivot, ONE basic block: a row that has stopped keeps executing on data nobody reads again, its bookkeeping
+                // frozen by selects.  Order inside a step = the dependency chain, with everything that is not on it placed in its shadows:
+                //   read the pivot column (LDS, slot of the winning lane)  ->  tail / fresh norm  ->  1/sqrt  ->  row j of the block,
+                //   down-dated norms  ->  DECISION for pivot j+1 (local best, two butterflies)  ->  next read.
+                // Beside the chain: the raw dot products (beside the 1/sqrt), the reciprocal of c0 - beta and the rank-one update of the rows
+                // below (beside the butterflies), then every lane stores the column of its local best slot in its own LDS slot — the store
+                // does not wait for the decision, only the next step's read address does.
                 // =====================================================================================
                 auto factor_level = [&](auto s0c) __attribute__((always_inline)) {
                     constexpr int S0 = decltype(s0c)::value;
@@ -278,12 +347,12 @@ namespace lexls
                         nrm[s] = sel(pos[s] >= ColIndex && pos[s] < n, t, qt_with_hi(t, kQtSentinelHi));
                     }
                     bool go = work;
-                    // pivot search: first maximum (by position) of the down-dated norms (lexlse.h:205-206).  Local best of the lane's slots first
+                    // pivot decision: first maximum (by position) of the down-dated norms (lexlse.h:205-206).  Local best of the lane's slots first
                     // (ties to the smaller position), then one f64 max butterfly and one u32 min butterfly inside the row
-                    int lbs      = S0;
-                    bool ispl    = false;
+                    int lbs       = S0;
+                    bool ispl     = false;
                     unsigned wkey = 0;
-                    auto search = [&]() __attribute__((always_inline)) {
+                    auto decide = [&]() __attribute__((always_inline)) {
                         double bn   = nrm[S0];
                         unsigned bk = ((unsigned)pos[S0] << 8) | (unsigned)(S0 << 4) | (unsigned)gl;
                         lbs         = S0;
@@ -291,7 +360,7 @@ namespace lexls
                         for (int s = S0 + 1; s < NS; s++)
                         {
                             const unsigned ks = ((unsigned)pos[s] << 8) | (unsigned)(s << 4) | (unsigned)gl;
-                            const bool better = nrm[s] > bn || (nrm[s] == bn && ks < bk);
+                            const bool better = (nrm[s] > bn) | ((nrm[s] == bn) & (ks < bk)); // (no short-circuit: straight-line code)
                             bn                = sel(better, nrm[s], bn);
                             bk                = sel(better, ks, bk);
                             lbs               = sel(better, s, lbs);
@@ -301,53 +370,51 @@ namespace lexls
                         wkey             = w;
                         ispl             = bk == w;
                     };
-                    search();
+                    // rows jj.. of the column in the lane's local best slot -> this lane's hand-off slot
+                    auto handoff_store = [&](auto jjc) __attribute__((always_inline)) {
+                        constexpr int ce = decltype(jjc)::value & ~1;
+                        double colv[MD];
+#pragma unroll
+                        for (int r = ce; r < MD; r++) colv[r] = blk[S0][r];
+#pragma unroll
+                        for (int s = S0 + 1; s < NS; s++)
+                        {
+                            const bool pick = lbs == s;
+#pragma unroll
+                            for (int r = ce; r < MD; r++) colv[r] = sel(pick, blk[s][r], colv[r]);
+                        }
+#pragma unroll
+                        for (int r = ce; r < MD; r += 2) D2(o_stage + gl * (8 * MD) + 8 * r) = make_double2(colv[r], colv[r + 1]);
+                    };
+                    decide();
+                    handoff_store(std::integral_constant<int, 0>{});
 
                     for_each_index<0, MD>([&](auto cnt) __attribute__((always_inline)) {
                         constexpr int j  = decltype(cnt)::value;
                         constexpr int ce = j & ~1;
-                        // the next level's pieces, a few per pivot step (executed whether or not this step still has work)
+                        // the next level's pieces: PF_PER per pivot step from the first step on (executed whether or not this step still has work)
                         if (prefetch)
                         {
-                            constexpr int TOT = NH * NIH;
-                            constexpr int lo = j * TOT / MD, hi = (j + 1) * TOT / MD;
-                            for_each_index<lo, hi>([&](auto tt) __attribute__((always_inline)) {
-                                constexpr int t = decltype(tt)::value;
-                                issue_load(std::integral_constant<int, t / NIH>{}, std::integral_constant<int, t % NIH>{}, F + MD);
-                            });
+                            constexpr int TOT = NH * NIH, PF_PER = (TOT + PF_STEPS - 1) / PF_STEPS;
+                            for_each_index<(j * PF_PER < TOT ? j * PF_PER : TOT), ((j + 1) * PF_PER < TOT ? (j + 1) * PF_PER : TOT)>(
+                                [&](auto tt) __attribute__((always_inline)) { prefetch_piece(tt, F + MD); });
                         }
                         const bool act = go;
                         if (__ballot(act) == 0ull) return;
-
-                        // the pivot's lane hands its column to the row through LDS
-                        {
-                            double colv[MD];
-#pragma unroll
-                            for (int r = ce; r < MD; r++) colv[r] = blk[S0][r];
-#pragma unroll
-                            for (int s = S0 + 1; s < NS; s++)
-                            {
-                                const bool pick = lbs == s;
-#pragma unroll
-                                for (int r = ce; r < MD; r++) colv[r] = sel(pick, blk[s][r], colv[r]);
-                            }
-                            if (ispl)
-                            {
-#pragma unroll
-                                for (int r = ce; r < MD; r += 2) D2(o_ex + 8 * r) = make_double2(colv[r], colv[r + 1]);
-                            }
-                        }
-                        STAMP(2)
                         quad_lds_fence();
                         double col[MD];
-#pragma unroll
-                        for (int r = ce; r < MD; r += 2)
                         {
-                            const double2 v = D2(o_ex + 8 * r);
-                            col[r]          = v.x;
-                            col[r + 1]      = v.y;
+                            const int src = o_stage + (int)(wkey & 15u) * (8 * MD);
+#pragma unroll
+                            for (int r = ce; r < MD; r += 2)
+                            {
+                                const double2 v = D2(src + 8 * r);
+                                col[r]          = v.x;
+                                col[r + 1]      = v.y;
+                            }
                         }
                         quad_lds_fence();
+                        FSTAMP(2)
                         const double c0 = col[j];
                         // tail norm in three partial sums, fresh norm = c0^2 + tail (lexlse.h:210-211, :241)
                         double t0 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -360,23 +427,25 @@ namespace lexls
                         }
                         const double tailSq = (t0 + t1) + t2;
                         const double fresh  = dfma(c0, c0, tailSq);
-                        STAMP(3)
-                        const bool cont = act && !(fresh < a.tol); // rank test on the squared norm (lexlse.h:214)
-                        go              = cont;
-                        if (__ballot(cont) == 0ull) return;
-
-                        // column "swap": update the position map (lexlse.h:222-232)
-                        const int ppos = (int)(wkey >> 8);
-#pragma unroll
-                        for (int s = S0; s < NS; s++)
+                        const bool cont     = act && !(fresh < a.tol); // rank test on the squared norm (lexlse.h:214); no branch: a stopped row runs on
+                        go                  = cont;
+                        // 1 / sqrt(fresh): v_rsq_f64 and two coupled iterations (g -> sqrt, h -> 1 / (2 sqrt))
+                        double g, h;
                         {
-                            const bool front = cont && pos[s] == ColIndex;
-                            pos[s]           = sel(front, ppos, pos[s]);
-                            pos[s]           = sel(cont && ispl && lbs == s, ColIndex, pos[s]);
+                            const double y = __builtin_amdgcn_rsq(fresh);
+                            g              = fresh * y;
+                            h              = 0.5 * y;
+                            double r       = dfma(-h, g, 0.5);
+                            g              = dfma(g, r, g);
+                            h              = dfma(h, r, h);
+                            r              = dfma(-h, g, 0.5);
+                            g              = dfma(g, r, g);
+                            h              = dfma(h, r, h);
                         }
-                        if (cont && ispl) B8(o_perm + ColIndex) = (uint8_t)ppos;
-
-                        // raw dot products w.a of every live column, beside the scalar chain
+                        const bool neg    = c0 >= 0.0;       // beta = -sign(c0) sqrt(fresh)
+                        const double beta = neg ? -g : g;
+                        const double ibet = (neg ? -2.0 : 2.0) * h; // 1 / beta
+                        // raw dot products col . a of every live column (beside the chain above)
                         double dw[NS];
 #pragma unroll
                         for (int s = S0; s < NS; s++)
@@ -390,40 +459,50 @@ namespace lexls
                                 else
                                     d1 = dfma(col[r], blk[s][r], d1);
                             }
-                            dw[s] = d0 + d1;
+                            dw[s] = dfma(c0, blk[s][j], d0 + d1);
                         }
-                        // beta = -sign(c0) sqrt(fresh), den = c0 - beta, q = 1 / (den beta), 1 / beta = den q
-                        const double rt   = qt_sqrt(fresh);
-                        const double beta = c0 >= 0.0 ? -rt : rt;
-                        const double den  = c0 - beta;
-                        const double q    = qt_rcp(den * beta);
-                        const double ibet = den * q;
-                        STAMP(4)
-                        // row j of the block (final after this reflector), norm down-date (lexlse.h:262-266), normalisation by 1 / R_jj
-                        double gs[NS];
+                        FSTAMP(3)
+                        // row j of the block: R_js = (col . a_s) / beta (final after this reflector); norm down-date (lexlse.h:262-266); the pivot
+                        // column leaves the candidates; the row is kept normalised by 1 / R_jj
+                        double dlt[NS];
 #pragma unroll
                         for (int s = S0; s < NS; s++)
                         {
-                            gs[s]          = q * dfma(den, blk[s][j], dw[s]);
-                            const double t = dfma(gs[s], den, blk[s][j]);
+                            const double t = dw[s] * ibet;
+                            dlt[s]         = t - blk[s][j];
                             nrm[s]         = dfma(-t, t, nrm[s]);
                             nrm[s]         = sel(cont && ispl && lbs == s, qt_with_hi(nrm[s], kQtSentinelHi), nrm[s]);
                             blk[s][j]      = t * ibet;
                         }
+                        // column "swap": update the position map (lexlse.h:222-232)
+                        const int ppos = (int)(wkey >> 8);
+#pragma unroll
+                        for (int s = S0; s < NS; s++)
+                        {
+                            const bool front = cont && pos[s] == ColIndex;
+                            pos[s]           = sel(front, ppos, pos[s]);
+                            pos[s]           = sel(cont && ispl && lbs == s, ColIndex, pos[s]);
+                        }
+                        B8(sel(cont && ispl, o_perm + ColIndex, o_ex)) = (uint8_t)ppos; // (o_ex: dump slot)
                         ColIndex += cont ? 1 : 0;
                         rank += cont ? 1 : 0;
                         const bool full = cont && ColIndex == n;
                         exh             = exh || full;
                         go              = go && !full;
-                        // the search for the next pivot starts here, in front of the rank-one update of the rows below
-                        if constexpr (j + 1 < MD) search();
+                        FSTAMP(4)
+                        // the decision for the next pivot starts here, in front of the rank-one update of the rows below
+                        if constexpr (j + 1 < MD) decide();
+                        // rows below: a_s[r] += ((R_js - a_s[j]) / (c0 - beta)) col[r]   (= a_s - tau v v.a_s, lexlse.h:243-246)
+                        const double rden = qt_rcp(c0 - beta);
 #pragma unroll
                         for (int s = S0; s < NS; s++)
                         {
+                            const double gs = dlt[s] * rden;
 #pragma unroll
-                            for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs[s], col[r], blk[s][r]);
+                            for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs, col[r], blk[s][r]);
                         }
-                        STAMP(5)
+                        if constexpr (j + 1 < MD) handoff_store(std::integral_constant<int, j + 1>{});
+                        FSTAMP(5)
                     });
                 };
                 {
@@ -437,6 +516,8 @@ namespace lexls
                     else
                         factor_level(std::integral_constant<int, 0>{});
                 }
+                STAMP(5)
+                LSTAMP(2)
 
                 // =====================================================================================
                 // level end: triangular image [R_k T_k | rhs_k] / diag in end-of-level position order, maps
@@ -464,6 +545,7 @@ namespace lexls
                     rq[s]          = sel(piv, 0x0c0c0c00 | k, rq[s]);
                 }
                 STAMP(6)
+                LSTAMP(3)
                 if (gl == 0)
                 {
                     U32(o_meta + 16 * k)      = (uint32_t)Fc;
@@ -560,7 +642,7 @@ namespace lexls
         template <int NS, int MD>
         inline size_t qtol_group_bytes(uint32_t n, uint32_t nObj)
         {
-            return (8 * ((size_t)qtol_image_doubles(n, nObj, MD) + 16 * NS + MD) + 64 + 64 + 16 * kQuadMaxObj + 8 * 16 * NS + 8 * (size_t)(n + 1) * (MD / 2) + 15) &
+            return (8 * ((size_t)qtol_image_doubles(n, nObj, MD) + 16 * NS + MD) + 64 + 64 + 16 * kQuadMaxObj + 8 * 16 * NS + 8 * (size_t)((n + 1) * (MD / 2) > 16u * MD ? (n + 1) * (MD / 2) : 16u * MD) + 15) &
                    ~(size_t)15;
         }
 
@@ -578,7 +660,8 @@ namespace lexls
                 if (e != hipSuccess) return e;
             }
             const uint32_t blocks = (a.batch + 3u) / 4u;
-            hipLaunchKernelGGL((lqr_qtol_kernel<NS, MD, SIG>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes);
+            static const uint32_t stagger = std::getenv("LEXLS_QTOL_STAGGER") ? (uint32_t)std::atoi(std::getenv("LEXLS_QTOL_STAGGER")) : 0u; // x 512 cycles per SIMD index
+            hipLaunchKernelGGL((lqr_qtol_kernel<NS, MD, SIG>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes, stagger);
             return hipGetLastError();
         }
     } // namespace
