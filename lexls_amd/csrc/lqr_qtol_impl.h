@@ -65,6 +65,32 @@ namespace lexls
 #else
 #define FSTAMP(i)
 #endif
+// Chain stamps (-DLEXLS_QTOL_CHAIN=<S0>): s_memtime behind an instruction that depends on the named value — the time at which that value is
+// READY, without draining anything (the plain stamps wait for lgkmcnt(0) and disturb the chain they measure).  Seven points per pivot step.
+#ifdef LEXLS_QTOL_CHAIN
+#define CSTAMP(i, val)                                                                                     \
+    if constexpr (S0 == LEXLS_QTOL_CHAIN)                                                                  \
+    {                                                                                                      \
+        int dummy_;                                                                                        \
+        asm volatile("v_mov_b32 %1, %2\n\ts_memtime %0" : "=s"(ct[i]), "=v"(dummy_) : "v"(val));         \
+    }
+#define CSTAMP_COLLECT                                                                                     \
+    if constexpr (S0 == LEXLS_QTOL_CHAIN)                                                                  \
+    {                                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        if (cvalid)                                                                                        \
+        {                                                                                                  \
+            cacc[2] += ct[2] - cp1; cacc[3] += ct[3] - ct[2]; cacc[4] += ct[4] - ct[3];                     \
+            cacc[5] += ct[5] - ct[4]; cacc[6] += ct[6] - ct[5]; cacc[0] += ct[0] - ct[6];                   \
+        }                                                                                                  \
+        cacc[1] += ct[1] - ct[0];                                                                          \
+        cp1    = ct[1];                                                                                    \
+        cvalid = true;                                                                                     \
+    }
+#else
+#define CSTAMP(i, val)
+#define CSTAMP_COLLECT
+#endif
 // per-level phase stamps of the diagnostic build: lambda[11 + 4 k + {0 load, 1 eliminate, 2 Householder, 3 level end}]
 #ifdef LEXLS_WAVE_STAMPS
 #define LSTAMP(ph)                                                                                   \
@@ -205,6 +231,9 @@ namespace lexls
             bool have_next = false; // the pieces of the level about to start are already in flight / in registers (wave-uniform)
             STAMP_DECL
             STAMP(0)
+#ifdef LEXLS_QTOL_CHAIN
+            unsigned long long cacc[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
 #ifdef LEXLS_WAVE_STAMPS
             unsigned long long lst_t0 = clock64();
 #endif
@@ -226,7 +255,7 @@ namespace lexls
                     continue;
                 }
                 const int F = k * MD;
-                if (!have_next) // the first level, or a level whose predecessor could have exhausted the columns: all pieces at once
+                if (k > 0 && !have_next) // a level whose predecessor could have exhausted the columns: all pieces at once
                     for_each_index<0, NH * NIH>([&](auto tt) __attribute__((always_inline)) { prefetch_piece(tt, F); });
 
                 // =====================================================================================
@@ -240,6 +269,27 @@ namespace lexls
                     pos[s]      = (P >= 0 && P <= n) ? P : 0x3fffff;
                     em[s]       = *reinterpret_cast<const unsigned long long *>(L + o_emap + 8 * pc[s]);
                 }
+                if (k == 0)
+                {
+                    // The first level: the position layout is the identity, so lane = column loads the block directly (no staging).  Every wave
+                    // of the chip asks for its first level at once; for such a burst this pattern is also the fastest of those measured
+                    // (scripts/ubench/loadpat.hip: 7.7-8.4 k cycles per level against 9.5 k for the 48-byte pieces)
+#pragma unroll
+                    for (int s = 0; s < NS; s++)
+                    {
+                        const int P       = 16 * s + gl - SIG;
+                        const int c       = (P >= 0 && P <= n) ? P : 0;
+                        const qt_d2 *src2 = reinterpret_cast<const qt_d2 *>(inw + (poff + (uint32_t)(c * cap)));
+#pragma unroll
+                        for (int r = 0; r < MD / 2; r++)
+                        {
+                            const qt_d2 v     = src2[r];
+                            blk[s][2 * r]     = v.x;
+                            blk[s][2 * r + 1] = v.y;
+                        }
+                    }
+                }
+                else
                 for_each_index<0, NH>([&](auto hh) __attribute__((always_inline)) {
                     constexpr int h = decltype(hh)::value;
                     // the pieces come out of their fixed registers (requested during the level in front, or just now)
@@ -337,6 +387,7 @@ namespace lexls
                 // =====================================================================================
                 auto factor_level = [&](auto s0c) __attribute__((always_inline)) {
                     constexpr int S0 = decltype(s0c)::value;
+                    constexpr int SL = NS - S0; // live slots
                     double nrm[NS];
 #pragma unroll
                     for (int s = S0; s < NS; s++)
@@ -347,51 +398,57 @@ namespace lexls
                         nrm[s] = sel(pos[s] >= ColIndex && pos[s] < n, t, qt_with_hi(t, kQtSentinelHi));
                     }
                     bool go = work;
-                    // pivot decision: first maximum (by position) of the down-dated norms (lexlse.h:205-206).  Local best of the lane's slots first
-                    // (ties to the smaller position), then one f64 max butterfly and one u32 min butterfly inside the row
-                    int lbs       = S0;
-                    bool ispl     = false;
-                    unsigned wkey = 0;
-                    auto decide = [&]() __attribute__((always_inline)) {
-                        double bn   = nrm[S0];
-                        unsigned bk = ((unsigned)pos[S0] << 8) | (unsigned)(S0 << 4) | (unsigned)gl;
-                        lbs         = S0;
+#ifdef LEXLS_QTOL_CHAIN
+                    unsigned long long ct[7] = {0, 0, 0, 0, 0, 0, 0}, cp1 = 0;
+                    bool cvalid = false;
+#endif
+                    // Pivot decision: first maximum (by position) of the down-dated norms (lexlse.h:205-206) as ONE f64 max butterfly: the low twelve
+                    // bits of a candidate's norm are replaced by 4095 - (position << 6 | slot << 4 | lane) for the comparison, so that equal
+                    // norms order by position and the winner's identity comes out of the maximum itself.  (Norms that agree in their upper
+                    // 52 - 12 mantissa bits also order by position: a 2^-40 window in which the reference's own choice depends on its summation
+                    // order.  The norms themselves stay untouched.)
+                    int cur_lbs = S0, nxt_lbs = S0;     // slot of the lane's local best candidate: for this pivot / the next one
+                    bool cur_ispl = false, nxt_ispl = false; // this lane holds the pivot column
+                    unsigned cur_w = 0, nxt_w = 0;      // the winner's 12-bit key (position << 6 | slot << 4 | lane)
+                    double pbest = 0.0;                 // the lane's local best, packed
+                    auto decide_local = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                        for (int s = S0 + 1; s < NS; s++)
+                        for (int s = S0; s < NS; s++)
                         {
-                            const unsigned ks = ((unsigned)pos[s] << 8) | (unsigned)(s << 4) | (unsigned)gl;
-                            const bool better = (nrm[s] > bn) | ((nrm[s] == bn) & (ks < bk)); // (no short-circuit: straight-line code)
-                            bn                = sel(better, nrm[s], bn);
-                            bk                = sel(better, ks, bk);
-                            lbs               = sel(better, s, lbs);
+                            const int kinv  = (0xFFF - ((s << 4) | gl)) - (pos[s] << 6);
+                            const double pv = __hiloint2double(__double2hiint(nrm[s]), (__double2loint(nrm[s]) & ~0xFFF) | kinv);
+                            pbest           = s == S0 ? pv : vmax(pbest, pv);
                         }
-                        const double m   = row_max16(bn);
-                        const unsigned w = row_min16(bn == m ? bk : 0x7fffffffu);
-                        wkey             = w;
-                        ispl             = bk == w;
+                        nxt_lbs = ((0xFFF - (__double2loint(pbest) & 0xFFF)) >> 4) & 3;
                     };
-                    // rows jj.. of the column in the lane's local best slot -> this lane's hand-off slot
-                    auto handoff_store = [&](auto jjc) __attribute__((always_inline)) {
-                        constexpr int ce = decltype(jjc)::value & ~1;
+                    auto decide_finish = [&](double m) __attribute__((always_inline)) {
+                        const int mlo = __double2loint(m);
+                        nxt_w         = (unsigned)(0xFFF - (mlo & 0xFFF));
+                        nxt_ispl      = ((__double2loint(pbest) ^ mlo) & 0xFFF) == 0;
+                    };
+                    // prologue: decision for pivot 0, every lane's best column to its hand-off slot
+                    {
+                        decide_local();
+                        decide_finish(row_max16(pbest));
                         double colv[MD];
 #pragma unroll
-                        for (int r = ce; r < MD; r++) colv[r] = blk[S0][r];
+                        for (int r = 0; r < MD; r++) colv[r] = blk[S0][r];
 #pragma unroll
                         for (int s = S0 + 1; s < NS; s++)
                         {
-                            const bool pick = lbs == s;
+                            const bool pick = nxt_lbs == s;
 #pragma unroll
-                            for (int r = ce; r < MD; r++) colv[r] = sel(pick, blk[s][r], colv[r]);
+                            for (int r = 0; r < MD; r++) colv[r] = sel(pick, blk[s][r], colv[r]);
                         }
 #pragma unroll
-                        for (int r = ce; r < MD; r += 2) D2(o_stage + gl * (8 * MD) + 8 * r) = make_double2(colv[r], colv[r + 1]);
-                    };
-                    decide();
-                    handoff_store(std::integral_constant<int, 0>{});
+                        for (int r = 0; r < MD; r += 2) D2(o_stage + gl * (8 * MD) + 8 * r) = make_double2(colv[r], colv[r + 1]);
+                        cur_lbs = nxt_lbs, cur_ispl = nxt_ispl, cur_w = nxt_w;
+                    }
 
                     for_each_index<0, MD>([&](auto cnt) __attribute__((always_inline)) {
-                        constexpr int j  = decltype(cnt)::value;
-                        constexpr int ce = j & ~1;
+                        constexpr int j   = decltype(cnt)::value;
+                        constexpr int ce  = j & ~1;       // first (even) row of this step's hand-off
+                        constexpr int cen = (j + 1) & ~1; // ... of the next step's
                         // the next level's pieces: PF_PER per pivot step from the first step on (executed whether or not this step still has work)
                         if (prefetch)
                         {
@@ -401,10 +458,11 @@ namespace lexls
                         }
                         const bool act = go;
                         if (__ballot(act) == 0ull) return;
+                        CSTAMP(0, (int)cur_w)
                         quad_lds_fence();
                         double col[MD];
                         {
-                            const int src = o_stage + (int)(wkey & 15u) * (8 * MD);
+                            const int src = o_stage + (int)(cur_w & 15u) * (8 * MD);
 #pragma unroll
                             for (int r = ce; r < MD; r += 2)
                             {
@@ -415,6 +473,8 @@ namespace lexls
                         }
                         quad_lds_fence();
                         FSTAMP(2)
+                        CSTAMP(1, __double2loint(col[MD - 1]))
+                        CSTAMP_COLLECT
                         const double c0 = col[j];
                         // tail norm in three partial sums, fresh norm = c0^2 + tail (lexlse.h:210-211, :241)
                         double t0 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -427,6 +487,7 @@ namespace lexls
                         }
                         const double tailSq = (t0 + t1) + t2;
                         const double fresh  = dfma(c0, c0, tailSq);
+                        CSTAMP(2, __double2loint(fresh))
                         const bool cont     = act && !(fresh < a.tol); // rank test on the squared norm (lexlse.h:214); no branch: a stopped row runs on
                         go                  = cont;
                         // 1 / sqrt(fresh): v_rsq_f64 and two coupled iterations (g -> sqrt, h -> 1 / (2 sqrt))
@@ -445,6 +506,8 @@ namespace lexls
                         const bool neg    = c0 >= 0.0;       // beta = -sign(c0) sqrt(fresh)
                         const double beta = neg ? -g : g;
                         const double ibet = (neg ? -2.0 : 2.0) * h; // 1 / beta
+                        CSTAMP(3, __double2loint(ibet))
+                        const double rden = qt_rcp(c0 - beta);      // (for the rows below; not on the chain to the next decision)
                         // raw dot products col . a of every live column (beside the chain above)
                         double dw[NS];
 #pragma unroll
@@ -463,47 +526,84 @@ namespace lexls
                         }
                         FSTAMP(3)
                         // row j of the block: R_js = (col . a_s) / beta (final after this reflector); norm down-date (lexlse.h:262-266); the pivot
-                        // column leaves the candidates; the row is kept normalised by 1 / R_jj
-                        double dlt[NS];
+                        // column leaves the candidates; the row is kept normalised by 1 / R_jj.  gs: a_s[r] += gs col[r] for the rows below,
+                        // gs = (R_js - a_s[j]) / (c0 - beta)   (= a_s - tau v v.a_s, lexlse.h:243-246)
+                        double gs[NS];
 #pragma unroll
                         for (int s = S0; s < NS; s++)
                         {
                             const double t = dw[s] * ibet;
-                            dlt[s]         = t - blk[s][j];
+                            gs[s]          = (t - blk[s][j]) * rden;
                             nrm[s]         = dfma(-t, t, nrm[s]);
-                            nrm[s]         = sel(cont && ispl && lbs == s, qt_with_hi(nrm[s], kQtSentinelHi), nrm[s]);
+                            nrm[s]         = sel(cont && cur_ispl && cur_lbs == s, qt_with_hi(nrm[s], kQtSentinelHi), nrm[s]);
                             blk[s][j]      = t * ibet;
                         }
+                        CSTAMP(4, __double2hiint(nrm[NS - 1]))
                         // column "swap": update the position map (lexlse.h:222-232)
-                        const int ppos = (int)(wkey >> 8);
+                        const int ppos = (int)(cur_w >> 6);
 #pragma unroll
                         for (int s = S0; s < NS; s++)
                         {
                             const bool front = cont && pos[s] == ColIndex;
                             pos[s]           = sel(front, ppos, pos[s]);
-                            pos[s]           = sel(cont && ispl && lbs == s, ColIndex, pos[s]);
+                            pos[s]           = sel(cont && cur_ispl && cur_lbs == s, ColIndex, pos[s]);
                         }
-                        B8(sel(cont && ispl, o_perm + ColIndex, o_ex)) = (uint8_t)ppos; // (o_ex: dump slot)
+                        B8(sel(cont && cur_ispl, o_perm + ColIndex, o_ex)) = (uint8_t)ppos; // (o_ex: dump slot)
                         ColIndex += cont ? 1 : 0;
                         rank += cont ? 1 : 0;
                         const bool full = cont && ColIndex == n;
                         exh             = exh || full;
                         go              = go && !full;
                         FSTAMP(4)
-                        // the decision for the next pivot starts here, in front of the rank-one update of the rows below
-                        if constexpr (j + 1 < MD) decide();
-                        // rows below: a_s[r] += ((R_js - a_s[j]) / (c0 - beta)) col[r]   (= a_s - tau v v.a_s, lexlse.h:243-246)
-                        const double rden = qt_rcp(c0 - beta);
+                        if constexpr (j + 1 < MD)
+                        {
+                            // The decision for the next pivot: local part, then the four butterfly stages.  In the stalls of the stages: the lane's
+                            // best column (for the next hand-off) is picked out of the slots BEFORE the rank-one update, updated on its own and
+                            // stored — the store does not wait for the decision, only the next step's read address does
+                            decide_local();
+                            double colv[MD];
+                            double gsb = gs[S0];
+                            double m   = pbest;
+                            auto pick_rows = [&](auto qq) __attribute__((always_inline)) {
+                                constexpr int q = decltype(qq)::value;
+#pragma unroll
+                                for (int r = cen; r < MD; r++)
+                                    if ((r - cen) % 4 == q)
+                                    {
+                                        colv[r] = blk[S0][r];
+#pragma unroll
+                                        for (int s = S0 + 1; s < NS; s++) colv[r] = sel(nxt_lbs == s, blk[s][r], colv[r]);
+                                    }
+                            };
+                            m = dpp_max<0xB1>(m);
+                            pick_rows(std::integral_constant<int, 0>{});
+                            m = dpp_max<0x4E>(m);
+                            pick_rows(std::integral_constant<int, 1>{});
+                            m = dpp_max<0x141>(m);
+                            pick_rows(std::integral_constant<int, 2>{});
+                            m = dpp_max<0x140>(m);
+                            pick_rows(std::integral_constant<int, 3>{});
+#pragma unroll
+                            for (int s = S0 + 1; s < NS; s++) gsb = sel(nxt_lbs == s, gs[s], gsb);
+#pragma unroll
+                            for (int r = (cen > j + 1 ? cen : j + 1); r < MD; r++) colv[r] = dfma(gsb, col[r], colv[r]);
+#pragma unroll
+                            for (int r = cen; r < MD; r += 2) D2(o_stage + gl * (8 * MD) + 8 * r) = make_double2(colv[r], colv[r + 1]);
+                            decide_finish(m);
+                        }
+                        CSTAMP(5, (int)nxt_w)
+                        // rows below of every live column
 #pragma unroll
                         for (int s = S0; s < NS; s++)
                         {
-                            const double gs = dlt[s] * rden;
 #pragma unroll
-                            for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs, col[r], blk[s][r]);
+                            for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs[s], col[r], blk[s][r]);
                         }
-                        if constexpr (j + 1 < MD) handoff_store(std::integral_constant<int, j + 1>{});
+                        cur_lbs = nxt_lbs, cur_ispl = nxt_ispl, cur_w = nxt_w;
+                        CSTAMP(6, __double2loint(blk[NS - 1][MD - 1]))
                         FSTAMP(5)
                     });
+                    (void)SL;
                 };
                 {
                     const int s0 = (rows_min(work ? Fc : 0x3fffffff) + SIG) >> 4;
@@ -624,6 +724,10 @@ namespace lexls
             }
             STAMP(10)
             STAMP_WRITE
+#ifdef LEXLS_QTOL_CHAIN
+            if (lane == 0)
+                for (int i_ = 0; i_ < 7; i_++) a.lambda[(size_t)b * (n + cap) + 30 + i_] = (double)cacc[i_];
+#endif
         }
 
         /// exact worst case of the triangular images: sum_k ((n+1-Fc_k) rank_k - rank_k (rank_k - 1) / 2) over rank distributions with rank_k <= md

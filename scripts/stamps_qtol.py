@@ -19,3 +19,11 @@ print("batch", batch, "total", tot, "cycles/wave (median); kernel", s.last_kerne
 lv = np.median(ws[::4, 11:11 + 16], axis=0).reshape(4, 4)
 print("per level:      load  eliminate  Householder  level end")
 for k in range(4): print(f"  level {k}: " + "  ".join(f"{v:9.0f}" for v in lv[k]))
+if os.environ.get("CHAIN"):
+    ch = np.median(ws[::4, 30:37], axis=0)
+    npiv = {"0": 12, "1": 24, "2": 4}[os.environ["CHAIN"]]
+    names = ["handoff stored -> step top (decision ready, branch)", "step top -> pivot column arrived (LDS read)", "-> fresh norm", "-> 1/beta", "-> row j, norms down-dated",
+             "-> decision for the next pivot", "-> rows below updated, hand-off stored"]
+    print(f"chain stamps, S0 = {os.environ['CHAIN']} ({npiv} pivots), cycles per pivot:")
+    for nm, v in zip(names, ch): print(f"  {nm:55s} {v / npiv:8.0f}")
+    print(f"  {'sum':55s} {ch.sum() / npiv:8.0f}")
