@@ -353,10 +353,6 @@ namespace lexls
                         double(&unext)[NS] = (C & 1) ? ua : ub;
                         if (C < Fcmax) // wave-uniform
                         {
-                            if constexpr (C + 1 < 16 * NS - SIG)
-                            {
-                                if (C + 1 < Fcmax) fetch_u(std::integral_constant<int, C + 1>{}, unext);
-                            }
                             // a row of the wavefront whose own pivots end before Fcmax meets the zeros of the x block as "U'": every fma adds a zero product
                             double lr[MD];
                             for_each_index<0, MD>([&](auto rr) {
@@ -364,7 +360,14 @@ namespace lexls
                                 lr[r]           = gbc<lc>(blk[sc][r]);
                             });
 #pragma unroll
-                            for (int s = sc; s < NS; s++)
+                            for (int r = 0; r < MD; r++) blk[sc][r] = dfma(-lr[r], ucur[sc], blk[sc][r]);
+                            // (the next step's U' behind the first slot's work: its address chain does not stall the step's start)
+                            if constexpr (C + 1 < 16 * NS - SIG)
+                            {
+                                if (C + 1 < Fcmax) fetch_u(std::integral_constant<int, C + 1>{}, unext);
+                            }
+#pragma unroll
+                            for (int s = sc + 1; s < NS; s++)
                             {
 #pragma unroll
                                 for (int r = 0; r < MD; r++) blk[s][r] = dfma(-lr[r], ucur[s], blk[s][r]);
@@ -658,13 +661,16 @@ namespace lexls
                 TotalRank += rank;
             }
 
-            // ---- solve(): block back-substitution on the normalised images (lexlse.h:1015-1045); lane p <-> row p of a level ----
+            // ---- solve(): block back-substitution on the normalised images (lexlse.h:1015-1045); lane p <-> row p of a level.  Straight-line
+            // per level: what does not apply reads a zero (position 16 NS - 1 of the x block is never written) or goes to the dump slot ----
+            const int o_zero = o_xs + 8 * (16 * NS - 1);
             for (int k = nObj; k--;)
             {
-                const int rank = live ? (int)U32(o_meta + 16 * k + 4) : 0;
+                const uint4 mt = *reinterpret_cast<const uint4 *>(L + o_meta + 16 * k); // {first column, rank, image offset, image width}
+                const int rank = live ? (int)mt.y : 0;
                 const int rmax = rows_max(rank);
                 if (rmax == 0) continue;
-                const int Fc = (int)U32(o_meta + 16 * k), ok = (int)U32(o_meta + 16 * k + 8), wk = (int)U32(o_meta + 16 * k + 12);
+                const int Fc = (int)mt.x, ok = (int)mt.z, wk = (int)mt.w;
                 const int c0   = Fc + rank;
                 const int acc  = rank > 0 ? TotalRank - c0 : 0;
                 const int amax = rows_max(acc);
@@ -672,33 +678,29 @@ namespace lexls
                 const int row  = o_img + 8 * (ok + p * wk - p * (p + 1) / 2);
                 double col[MD];
 #pragma unroll
-                for (int j = 0; j < MD; j++) col[j] = (j < rank && gl < j) ? D(row + 8 * j) : 0.0;
-                double sv = rank > 0 ? D(row + 8 * (n - Fc)) : 0.0;
+                for (int j = 1; j < MD; j++) col[j] = D(sel(j < rank && gl < j, row + 8 * j, o_zero));
+                double sv = D(sel(gl < rank, row + 8 * (n - Fc), o_zero));
                 // rhs'_k - T'_k x_later (lexlse.h:1029-1033): the column at final position c sits at its level-k index inside the image;
                 // sixteen solved positions per trip — lane j looks up index and x of position c0 + base + j, the row-broadcast hands them out
                 for (int base = 0; base < amax; base += 16)
                 {
-                    const int c     = c0 + base + gl;
                     const bool have = base + gl < acc;
-                    const int ph    = have ? (int)B8(o_phys + c) : 0;
+                    const int c     = have ? c0 + base + gl : 16 * NS - 1;
+                    const int ph    = (int)B8(o_phys + c);
                     const int offv  = have ? (int)B8(o_emap + 8 * ph + k) : 0;
-                    const double xv = have ? D(o_xs + 8 * c) : 0.0;
+                    const double xv = D(o_xs + 8 * c); // (zero where the position does not apply)
                     for_each_index<0, 16>([&](auto jj) {
-                        constexpr int j   = decltype(jj)::value;
-                        const double uj   = D(row + 8 * gbci<j>(offv));
-                        const double tnew = dfma(-uj, gbc<j>(xv), sv);
-                        sv                = sel(base + j < acc, tnew, sv);
+                        constexpr int j = decltype(jj)::value;
+                        const double uj = D(row + 8 * gbci<j>(offv));
+                        sv              = dfma(-uj, gbc<j>(xv), sv);
                     });
                 }
-                for_each_index<0, MD>([&](auto jj) {
-                    constexpr int j = MD - 1 - decltype(jj)::value;
-                    if (j < rmax)
-                    {
-                        const double xj = gbc<j>(sv); // unit diagonal
-                        if (j < rank && gl < j) sv = dfma(-col[j], xj, sv);
-                    }
+                sv = sel(gl < rank, sv, 0.0);
+                for_each_index<1, MD>([&](auto jj) {
+                    constexpr int j = MD - decltype(jj)::value; // MD-1 .. 1
+                    sv = dfma(-col[j], gbc<j>(sv), sv); // unit diagonal; col[j] is zero at and below the diagonal and beyond the rank
                 });
-                if (gl < rank) D(o_xs + 8 * (Fc + gl)) = sv;
+                D(sel(gl < rank, o_xs + 8 * (Fc + gl), o_ex)) = sv;
                 quad_lds_fence();
             }
             STAMP(9)
