@@ -42,6 +42,13 @@ namespace lexls
             return dfma(y, e, y);
         }
 
+        /// 1 / x to ~2^-50 (v_rcp_f64 + one Newton step): the factor of a rank-one update, whose own rounding is of that size
+        __device__ __forceinline__ double qt_rcp1(double x)
+        {
+            const double y = __builtin_amdgcn_rcp(x);
+            return dfma(y, dfma(-x, y, 1.0), y);
+        }
+
         /// sqrt(x) for normal x (v_rsq_f64, one coupled iteration, two correction steps — the unscaled core of the library routine)
         __device__ __forceinline__ double qt_sqrt(double x)
         {
@@ -102,6 +109,20 @@ namespace lexls
 #else
 #define LSTAMP(ph)
 #endif
+        /// f(integral_constant<int, I>) for I = B, B+1, ... while pred(I) holds: the first failing test leaves the whole remainder behind one branch
+        template <int B, int E, class P, class F>
+        __device__ __forceinline__ void qt_for_each_while(P &&pred, F &&f)
+        {
+            if constexpr (B < E)
+            {
+                if (pred(std::integral_constant<int, B>{}))
+                {
+                    f(std::integral_constant<int, B>{});
+                    qt_for_each_while<B + 1, E>(pred, f);
+                }
+            }
+        }
+
         typedef double qt_d2 __attribute__((ext_vector_type(2))); // 16 bytes as a native vector (the level pieces stay in registers)
 
 
@@ -141,6 +162,7 @@ namespace lexls
             constexpr int NH  = 2;        // row parts of the staging transposition
             constexpr int RP  = MD / NH;  // rows per part
             constexpr int HP  = RP / 2;   // 16-byte pieces per column and part
+            constexpr int kHandoffStride = 8 * MD + 16; // bytes between the lanes' hand-off slots: 16-byte aligned, b128 stores of 8 lanes on 32 banks
             constexpr int NIH = NS * HP;  // load instructions per part (16 NS columns x HP pieces / 16 lanes)
 #ifndef LEXLS_QTOL_PF_STEPS
 #define LEXLS_QTOL_PF_STEPS 9
@@ -164,7 +186,7 @@ namespace lexls
             // ---- LDS carve-up of this row's slice (byte offsets; launch_qtol_t computes group_bytes) ----
             const int o_img   = g * (int)group_bytes;
             const int o_xs    = o_img + 8 * (int)img_doubles; // 16*NS : x by position (zero until the back-substitution: also the "U" of a position that is no pivot yet)
-            const int o_ex    = o_xs + 8 * 16 * NS;           // MD    : dump slot of stores that do not apply
+            const int o_ex    = o_xs + 8 * 16 * NS;           // MD    : dump slots (one dword per lane) of byte stores that do not apply
             const int o_phys  = o_ex + 8 * MD;                // 64 B  : physical column at each position
             const int o_perm  = o_phys + 64;                  // 64 B  : column_permutations
             const int o_meta  = o_perm + 64;                  // kQuadMaxObj x {first column, rank, image offset, image width}
@@ -197,15 +219,19 @@ namespace lexls
             const int CH = (n + 1) * HP; // pieces per problem, level and row part
             static_assert(NH * NIH <= 18, "eighteen piece registers");
             // piece t = (row part t / NIH, instruction t % NIH) of the level whose first row is Frow -> its fixed registers
-            auto prefetch_piece = [&](auto tt, int Frow) __attribute__((always_inline)) {
+            // byte-free offsets (doubles) of this lane's pieces inside a level, computed once (the division by HP is not repeated per request)
+            uint32_t pieceoff[NH * NIH];
+            for_each_index<0, NH * NIH>([&](auto tt) __attribute__((always_inline)) {
                 constexpr int t = decltype(tt)::value, h = t / NIH, i = t % NIH;
+                int ch        = 16 * i + gl;
+                ch            = ch < CH ? ch : CH - 1; // lanes past the end repeat the last piece (same bytes to the same LDS address)
+                const int col = ch / HP, m = ch - col * HP;
+                pieceoff[t]   = poff + (uint32_t)(col * cap + h * RP + 2 * m);
+            });
+            auto prefetch_piece = [&](auto tt, int Frow) __attribute__((always_inline)) {
+                constexpr int t = decltype(tt)::value, i = t % NIH;
                 if (16 * i < CH) // wave-uniform
-                {
-                    int ch        = 16 * i + gl;
-                    ch            = ch < CH ? ch : CH - 1; // lanes past the end repeat the last piece (same bytes to the same LDS address)
-                    const int col = ch / HP, m = ch - col * HP;
-                    qt_pf_load<t>(inw + (poff + (uint32_t)(col * cap + Frow + h * RP + 2 * m)));
-                }
+                    qt_pf_load<t>(inw + (pieceoff[t] + (uint32_t)Frow));
             };
 
             double blk[NS][MD]; // the level block, position layout
@@ -346,13 +372,13 @@ namespace lexls
 #pragma unroll
                     for (int s = 0; s < NS; s++) ua[s] = ub[s] = 0.0;
                     if (Fcmax > 0) fetch_u(std::integral_constant<int, 0>{}, ua);
-                    for_each_index<0, 16 * NS - SIG>([&](auto cc) __attribute__((always_inline)) {
-                        constexpr int C  = decltype(cc)::value;
-                        constexpr int sc = (C + SIG) / 16, lc = (C + SIG) % 16;
-                        double(&ucur)[NS]  = (C & 1) ? ub : ua;
-                        double(&unext)[NS] = (C & 1) ? ua : ub;
-                        if (C < Fcmax) // wave-uniform
-                        {
+                    qt_for_each_while<0, 16 * NS - SIG>(
+                        [&](auto cc) __attribute__((always_inline)) { return decltype(cc)::value < Fcmax; }, // wave-uniform
+                        [&](auto cc) __attribute__((always_inline)) {
+                            constexpr int C  = decltype(cc)::value;
+                            constexpr int sc = (C + SIG) / 16, lc = (C + SIG) % 16;
+                            double(&ucur)[NS]  = (C & 1) ? ub : ua;
+                            double(&unext)[NS] = (C & 1) ? ua : ub;
                             // a row of the wavefront whose own pivots end before Fcmax meets the zeros of the x block as "U'": every fma adds a zero product
                             double lr[MD];
                             for_each_index<0, MD>([&](auto rr) {
@@ -372,8 +398,7 @@ namespace lexls
 #pragma unroll
                                 for (int r = 0; r < MD; r++) blk[s][r] = dfma(-lr[r], ucur[s], blk[s][r]);
                             }
-                        }
-                    });
+                        });
                 }
                 STAMP(7)
                 LSTAMP(1)
@@ -444,7 +469,7 @@ namespace lexls
                             for (int r = 0; r < MD; r++) colv[r] = sel(pick, blk[s][r], colv[r]);
                         }
 #pragma unroll
-                        for (int r = 0; r < MD; r += 2) D2(o_stage + gl * (8 * MD) + 8 * r) = make_double2(colv[r], colv[r + 1]);
+                        for (int r = 0; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = make_double2(colv[r], colv[r + 1]);
                         cur_lbs = nxt_lbs, cur_ispl = nxt_ispl, cur_w = nxt_w;
                     }
 
@@ -465,7 +490,7 @@ namespace lexls
                         quad_lds_fence();
                         double col[MD];
                         {
-                            const int src = o_stage + (int)(cur_w & 15u) * (8 * MD);
+                            const int src = o_stage + (int)(cur_w & 15u) * kHandoffStride;
 #pragma unroll
                             for (int r = ce; r < MD; r += 2)
                             {
@@ -510,7 +535,7 @@ namespace lexls
                         const double beta = neg ? -g : g;
                         const double ibet = (neg ? -2.0 : 2.0) * h; // 1 / beta
                         CSTAMP(3, __double2loint(ibet))
-                        const double rden = qt_rcp(c0 - beta);      // (for the rows below; not on the chain to the next decision)
+                        const double rden = qt_rcp1(c0 - beta);     // (for the rows below; not on the chain to the next decision)
                         // raw dot products col . a of every live column (beside the chain above)
                         double dw[NS];
 #pragma unroll
@@ -551,14 +576,37 @@ namespace lexls
                             pos[s]           = sel(front, ppos, pos[s]);
                             pos[s]           = sel(cont && cur_ispl && cur_lbs == s, ColIndex, pos[s]);
                         }
-                        B8(sel(cont && cur_ispl, o_perm + ColIndex, o_ex)) = (uint8_t)ppos; // (o_ex: dump slot)
+                        B8(sel(cont && cur_ispl, o_perm + ColIndex, o_ex + 4 * gl)) = (uint8_t)ppos; // (o_ex: dump slots, one bank per lane — same-address stores of many lanes serialise)
                         ColIndex += cont ? 1 : 0;
                         rank += cont ? 1 : 0;
                         const bool full = cont && ColIndex == n;
                         exh             = exh || full;
                         go              = go && !full;
                         FSTAMP(4)
-                        if constexpr (j + 1 < MD)
+                        if constexpr (j + 1 < MD && SL == 1)
+                        {
+                            // one live slot: the lane's best column IS the slot — update it (in the stalls of the butterfly), store it
+                            decide_local();
+                            double m = pbest;
+                            auto upd_rows = [&](auto qq) __attribute__((always_inline)) {
+                                constexpr int q = decltype(qq)::value;
+#pragma unroll
+                                for (int r = j + 1; r < MD; r++)
+                                    if ((r - j - 1) % 4 == q) blk[S0][r] = dfma(gs[S0], col[r], blk[S0][r]);
+                            };
+                            m = dpp_max<0xB1>(m);
+                            upd_rows(std::integral_constant<int, 0>{});
+                            m = dpp_max<0x4E>(m);
+                            upd_rows(std::integral_constant<int, 1>{});
+                            m = dpp_max<0x141>(m);
+                            upd_rows(std::integral_constant<int, 2>{});
+                            m = dpp_max<0x140>(m);
+                            upd_rows(std::integral_constant<int, 3>{});
+#pragma unroll
+                            for (int r = cen; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = make_double2(blk[S0][r], blk[S0][r + 1]);
+                            decide_finish(m);
+                        }
+                        else if constexpr (j + 1 < MD)
                         {
                             // The decision for the next pivot: local part, then the four butterfly stages.  In the stalls of the stages: the lane's
                             // best column (for the next hand-off) is picked out of the slots BEFORE the rank-one update, updated on its own and
@@ -591,16 +639,19 @@ namespace lexls
 #pragma unroll
                             for (int r = (cen > j + 1 ? cen : j + 1); r < MD; r++) colv[r] = dfma(gsb, col[r], colv[r]);
 #pragma unroll
-                            for (int r = cen; r < MD; r += 2) D2(o_stage + gl * (8 * MD) + 8 * r) = make_double2(colv[r], colv[r + 1]);
+                            for (int r = cen; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = make_double2(colv[r], colv[r + 1]);
                             decide_finish(m);
                         }
                         CSTAMP(5, (int)nxt_w)
                         // rows below of every live column
-#pragma unroll
-                        for (int s = S0; s < NS; s++)
+                        if constexpr (!(j + 1 < MD && SL == 1))
                         {
 #pragma unroll
-                            for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs[s], col[r], blk[s][r]);
+                            for (int s = S0; s < NS; s++)
+                            {
+#pragma unroll
+                                for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs[s], col[r], blk[s][r]);
+                            }
                         }
                         cur_lbs = nxt_lbs, cur_ispl = nxt_ispl, cur_w = nxt_w;
                         CSTAMP(6, __double2loint(blk[NS - 1][MD - 1]))
@@ -626,18 +677,22 @@ namespace lexls
                 // level end: triangular image [R_k T_k | rhs_k] / diag in end-of-level position order, maps
                 // =====================================================================================
                 const int wk   = n + 1 - Fc;
-                const int dump = o_ex; // stores that do not apply go to a dump slot (the hand-off block is idle here): no divergent regions
+                const int dump = o_stage + 8 * gl; // stores that do not apply go to a dump slot of the lane's own (the staging block is idle here): no divergent regions, no bank conflicts
+                int roff[MD];          // byte offset of image row p (triangular packing), the same for every slot
+#pragma unroll
+                for (int p = 0; p < MD; p++) roff[p] = 8 * (p * wk - p * (p + 1) / 2);
 #pragma unroll
                 for (int s = 0; s < NS; s++)
                 {
                     const int P0  = 16 * s + gl - SIG;
                     const bool mv = work && P0 <= n && P0 >= Fc; // columns that were live in this level (the RHS included)
+                    const int e   = pos[s] - Fc;                 // index of this column in the level's image: end-of-level position order
+                    const int lim = mv ? (e < rank - 1 ? e : rank - 1) : -1; // rows 0 .. lim of the column go to the image (p < rank, p <= e)
+                    const int base = o_img + 8 * (imgoff + e);
                     if (mv)
                     {
-                        const int e    = pos[s] - Fc; // index of this column in the level's image: end-of-level position order
-                        const int base = o_img + 8 * (imgoff + e);
 #pragma unroll
-                        for (int p = 0; p < MD; p++) D(sel(p < rank && p <= e, base + 8 * (p * wk - p * (p + 1) / 2), dump)) = blk[s][p];
+                        for (int p = 0; p < MD; p++) D(sel(p <= lim, base + roff[p], dump)) = blk[s][p];
                         B8(o_emap + 8 * pc[s] + k) = (uint8_t)e;
                         if (P0 < n) B8(o_phys + pos[s]) = (uint8_t)pc[s];
                     }
@@ -700,7 +755,7 @@ namespace lexls
                     constexpr int j = MD - decltype(jj)::value; // MD-1 .. 1
                     sv = dfma(-col[j], gbc<j>(sv), sv); // unit diagonal; col[j] is zero at and below the diagonal and beyond the rank
                 });
-                D(sel(gl < rank, o_xs + 8 * (Fc + gl), o_ex)) = sv;
+                D(sel(gl < rank, o_xs + 8 * (Fc + gl), o_stage + 8 * gl)) = sv;
                 quad_lds_fence();
             }
             STAMP(9)
@@ -748,8 +803,12 @@ namespace lexls
         template <int NS, int MD>
         inline size_t qtol_group_bytes(uint32_t n, uint32_t nObj)
         {
-            return (8 * ((size_t)qtol_image_doubles(n, nObj, MD) + 16 * NS + MD) + 64 + 64 + 16 * kQuadMaxObj + 8 * 16 * NS + 8 * (size_t)((n + 1) * (MD / 2) > 16u * MD ? (n + 1) * (MD / 2) : 16u * MD) + 15) &
-                   ~(size_t)15;
+            // staging block: the level pieces (half the rows at a time) or the sixteen hand-off slots of the pivot steps, whichever is larger
+            const size_t stage = 8 * (size_t)(n + 1) * (MD / 2) > 16u * (8 * MD + 16) ? 8 * (size_t)(n + 1) * (MD / 2) : 16u * (8 * MD + 16);
+            const size_t raw   = 8 * ((size_t)qtol_image_doubles(n, nObj, MD) + 16 * NS + MD) + 64 + 64 + 16 * kQuadMaxObj + 8 * 16 * NS + stage;
+            // rounded up to an ODD multiple of 128 bytes: the four problems of a wavefront read the same relative addresses of their slices at
+            // the same time; slices half a bank row apart do not collide
+            return ((raw + 127) / 256) * 256 + 128;
         }
 
         template <int NS, int MD, int SIG>
