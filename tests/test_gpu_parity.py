@@ -92,7 +92,12 @@ def test_x_only_variant_matches(hip, oracle, force_generic):
     dims, n = [12] * 5, 40
     lod = P.lse_batch(7, 32, n, dims)
     s, ref = run_both(hip, oracle, lod, dims, n, keep_factor=False, force_generic=force_generic)
-    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    if force_generic == 0:
+        # automatic dispatch: the tolerance-contract kernel (north_star: pivots / ranks exact, x within 1e-10; tests/test_gpu_qtol.py)
+        assert s.last_kernel() == "lqr_qtol<3,12,shift 7>"
+        assert np.abs(s.get_x() - ref["x"]).max() <= 1e-10
+    else:
+        np.testing.assert_array_equal(s.get_x(), ref["x"])
     np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
     np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
     if force_generic == 4:
@@ -736,12 +741,14 @@ def test_full_size_batch_4096(hip, oracle):
     lod = P.lse_batch_fast(20260100, batch, n, dims)
     ref = oracle.lse_run(lod, dims, n, nthreads=8)
     s = hip.BatchedLexLSE(batch, n, dims)
+    s.set_kernel_policy(4)  # the bit-exact four-per-wavefront kernel (automatic dispatch: the tolerance-contract one, tests/test_gpu_qtol.py)
     s.setProblem(lod)
     s.factorize_solve(keep_factor=False)
     assert s.last_kernel() == "lqr_quad<3,12,shift 7>"  # more problems than one round of the register-resident kernel holds: four per wavefront
     np.testing.assert_array_equal(s.get_x(), ref["x"])
     np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
     small = hip.BatchedLexLSE(1024, n, dims)
+    small.set_kernel_policy(4)
     small.setProblem(lod[:1024])
     small.factorize_solve(keep_factor=False)
     assert small.last_kernel() == "lqr_quad<3,12,shift 7>"  # x only: four per wavefront at every batch size (scripts/crossover.py)

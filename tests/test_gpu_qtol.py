@@ -1,0 +1,143 @@
+"""The tolerance-contract bench kernel (lexls_amd/csrc/lqr_qtol_impl.h; automatic dispatch of x-only solves of the IK shape, kernel policy 6)
+against the CPU oracle, through the C ABI.  Contract = BASELINE north_star: column permutation, ranks and first columns EXACT, x within 1e-10
+(relative to max(1, |x|_inf)); the bit-exact kernel stays behind lexls_lse_set_kernel_policy(h, 4) and is compared with it here as well."""
+import numpy as np
+import pytest
+
+from lexls_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+
+N, DIMS = 40, [12] * 5
+TOL = 1e-10
+
+
+def solve(hip, lod, dims=DIMS, policy=6):
+    s = hip.BatchedLexLSE(lod.shape[0], N, dims)
+    s.set_kernel_policy(policy)
+    s.setProblem(lod)
+    s.factorize_solve(keep_factor=False)
+    return s
+
+
+def check(hip, oracle, lod, dims=DIMS, policy=6, expect="lqr_qtol<3,12,shift 7>"):
+    ref = oracle.lse_run(lod, dims, N, nthreads=8)
+    s = solve(hip, lod, dims, policy)
+    assert s.last_kernel() == expect
+    r, fc, tr = s.getRanks()
+    np.testing.assert_array_equal(r, ref["rank"])
+    np.testing.assert_array_equal(fc, ref["fcol"])
+    np.testing.assert_array_equal(tr, ref["totalrank"])
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    x = s.get_x()
+    assert np.isfinite(x).all()
+    assert np.abs(x - ref["x"]).max() <= TOL * max(1.0, float(np.abs(ref["x"]).max()))
+    return s, ref
+
+
+def rank_deficient(seed, batch, ranks):
+    return np.stack([P.rank_deficient_problem(seed + b, N, DIMS, list(ranks)) for b in range(batch)])
+
+
+@pytest.mark.parametrize("batch", [1, 3, 4, 5, 64, 1023])
+def test_ik_batches_and_wavefront_tails(hip, oracle, batch):
+    check(hip, oracle, P.lse_batch_fast(100 + batch, batch, N, DIMS))
+
+
+def test_full_size_batch_4096_tolerance_contract(hip, oracle):
+    """BASELINE.json configs[2] on the kernel bench.py times: every one of the 4096 problems against the oracle"""
+    s, ref = check(hip, oracle, P.lse_batch_fast(20260100, 4096, N, DIMS))
+    assert (ref["rank"] == [12, 12, 12, 4, 0]).all()
+    # and against the bit-exact kernel of the same mapping: same pivots, x within the tolerance
+    e = solve(hip, P.lse_batch_fast(20260100, 4096, N, DIMS), policy=4)
+    assert e.last_kernel() == "lqr_quad<3,12,shift 7>"
+    np.testing.assert_array_equal(e.get_column_permutations(), s.get_column_permutations())
+    assert np.abs(e.get_x() - s.get_x()).max() <= TOL * max(1.0, float(np.abs(e.get_x()).max()))
+
+
+@pytest.mark.parametrize("ranks", [(9, 12, 7, 12, 12), (3, 3, 3, 3, 3), (12, 1, 12, 1, 12), (12, 12, 12, 2, 12), (1, 1, 1, 1, 1)])
+def test_rank_deficient_levels(hip, oracle, ranks):
+    """exact linear dependence inside levels (the reference's define_problem.m construction): the rank break of lexlse.h:214"""
+    check(hip, oracle, rank_deficient(300 + sum(ranks), 21, ranks))
+
+
+def test_mixed_ranks_inside_wavefronts(hip, oracle):
+    """full-rank and rank-deficient problems side by side in one wavefront: rows of a wavefront stop at different pivots and levels"""
+    lod = P.lse_batch(900, 32, N, DIMS)
+    lod[1::3] = rank_deficient(700, 32, (5, 12, 12, 12, 12))[1::3]
+    lod[2::5] = rank_deficient(800, 32, (12, 12, 2, 12, 12))[2::5]
+    check(hip, oracle, lod)
+
+
+def test_tied_norms_first_maximum_by_position(hip, oracle):
+    """duplicated columns: equal norms at every level, the first maximum BY POSITION must win (lexlse.h:205-206) — the packed comparison
+    key of the kernel orders equal norms by position"""
+    lod = P.lse_batch(1200, 16, N, DIMS)
+    lod[:, 7, :] = lod[:, 3, :]
+    lod[:, 30, :] = lod[:, 3, :]
+    lod[:, 20, :] = lod[:, 19, :]
+    lod[:, 39, :] = lod[:, 0, :]
+    check(hip, oracle, lod)
+
+
+@pytest.mark.parametrize("nobj", [1, 2, 3, 4])
+def test_fewer_levels(hip, oracle, nobj):
+    dims = [12] * nobj
+    lod = P.lse_batch(40 + nobj, 19, N, dims)
+    ref = oracle.lse_run(lod, dims, N)
+    s = hip.BatchedLexLSE(19, N, dims)
+    s.set_kernel_policy(6)
+    s.setProblem(lod)
+    s.factorize_solve(keep_factor=False)
+    assert s.last_kernel() == "lqr_qtol<3,12,shift 7>"
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+    np.testing.assert_array_equal(s.getRanks()[0], ref["rank"])
+    assert np.abs(s.get_x() - ref["x"]).max() <= TOL * max(1.0, float(np.abs(ref["x"]).max()))
+
+
+def test_dispatch_rules(hip, oracle):
+    """automatic dispatch takes the tolerance kernel for x-only solves of the IK shape only; a kept factor, ragged levels, fixed variables,
+    another n or the bit-exact policies take the bit-exact kernels (whose x is identical to the oracle's, bit for bit)"""
+    lod = P.lse_batch(31, 64, N, DIMS)
+    ref = oracle.lse_run(lod, DIMS, N)
+    s = solve(hip, lod, policy=0)
+    assert s.last_kernel() == "lqr_qtol<3,12,shift 7>"
+    s.factorize_solve(keep_factor=True)
+    assert not s.last_kernel().startswith("lqr_qtol")
+    np.testing.assert_array_equal(s.get_x(), ref["x"])
+    for policy in (2, 3, 4):
+        e = solve(hip, lod, policy=policy)
+        assert not e.last_kernel().startswith("lqr_qtol")
+        np.testing.assert_array_equal(e.get_x(), ref["x"])
+    ragged = np.array([[12, 12, 12, 12, 12]] * 63 + [[12, 11, 12, 12, 12]], np.uint32)
+    r = hip.BatchedLexLSE(64, N, DIMS)
+    r.setObjDim(ragged)
+    r.setProblem(lod)
+    r.factorize_solve(keep_factor=False)
+    assert not r.last_kernel().startswith("lqr_qtol")
+    n2 = 39
+    lod2 = P.lse_batch(32, 8, n2, DIMS)
+    o = hip.BatchedLexLSE(8, n2, DIMS)
+    o.setProblem(lod2)
+    o.factorize_solve(keep_factor=False)
+    assert not o.last_kernel().startswith("lqr_qtol")
+    np.testing.assert_array_equal(o.get_x(), oracle.lse_run(lod2, DIMS, n2)["x"])
+
+
+def test_scaled_data(hip, oracle):
+    """columns and rows of very different magnitude (1e-3 .. 1e3): the normalised images and the raw-column reflector keep the tolerance"""
+    lod = P.lse_batch(77, 48, N, DIMS)
+    scale_c = 10.0 ** (3 * (P.uniform(5, N) * 2 - 1))
+    scale_r = 10.0 ** (2 * (P.uniform(6, 60) * 2 - 1))
+    lod[:, :N, :] *= scale_c[None, :, None]
+    lod *= scale_r[None, None, :]
+    check(hip, oracle, lod)
+
+
+def test_repeated_solves_are_deterministic(hip):
+    lod = P.lse_batch_fast(5, 256, N, DIMS)
+    s = solve(hip, lod)
+    x0 = s.get_x().copy()
+    for _ in range(5):
+        s.factorize_solve(keep_factor=False)
+    np.testing.assert_array_equal(s.get_x(), x0)
