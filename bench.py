@@ -48,16 +48,27 @@ def main():
                     help="lse (default): the headline metric, BASELINE configs[2]/[3]; lsi: configs[4], a lock-step batch of 1024 LexLSI instances "
                          "warm-started to ~30 factorizations each, instance blocks sharded over the ranks (strong scaling)")
     ap.add_argument("--lsi-batch", type=int, default=1024, help="--workload lsi: instances in the whole job")
+    ap.add_argument("--no-extras", action="store_true", help="N=1: skip the config1_large / config4_lsi / factor_kept side measurements (profiling runs)")
+    ap.add_argument("--dry-run", action="store_true", help="control flow only (launcher, process group, barriers, max-over-ranks, rank-0 line): no GPU, no kernels; "
+                                                            "what the non-GPU test of the self-launcher runs with --dist-backend gloo")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    # Started plainly with --gpus N > 1 (no launcher around it): spawn the N ranks as fresh child processes BEFORE anything touches the GPU
+    # (never re-exec a process that has initialised HIP), one per GPU, rendezvous on 127.0.0.1; rank 0's JSON line is this process's output
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     device_index = local_rank if args.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
@@ -202,8 +213,13 @@ def main():
         total = batch * world * args.steps
         value = total / elapsed
         bytes_per = P.algorithmic_bytes(NVAR, DIMS, write_factor=args.keep_factor)
-        flops_per = P.flop_model(NVAR, DIMS)["total"]
+        fm = P.flop_model(NVAR, DIMS)
+        flops_per = fm["total"]
         achieved = bytes_per * batch / (kernel_ms * 1e-3) / 1e9
+        # what the x-only kernel actually touches / executes: the columns are exhausted inside level 3 (ranks 12,12,12,4,0), so the rows of
+        # level 4 are never read and their elimination never runs (legitimate for x; the model above counts them)
+        touched = P.bytes_touched_x_only(NVAR, DIMS) if not args.keep_factor else bytes_per
+        executed = P.flops_executed_x_only(NVAR, DIMS) if not args.keep_factor else flops_per
         line = {
             "metric": "batched fp64 l-QR factorizations/s (factorize+solve)",
             "value": value,
@@ -225,14 +241,22 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": _committed_traffic(args.keep_factor), "traffic_source": "profiles/pmc_summary.json (committed rocprofv3 PMC passes of this command, corrected as the summary states)",
                          "algorithmic_bytes_per_launch": bytes_per * batch, "kernel_ms": kernel_ms, "resident_batches": nres,
-                         "resident_bytes": int(nres * lod_host.nbytes)},
+                         "resident_bytes": int(nres * lod_host.nbytes),
+                         "bytes_touched_per_launch": touched * batch, "frac_on_bytes_touched": touched * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "contract": "pivots / ranks exact, x within 1e-10 (lqr_qtol)" if solver.last_kernel().startswith("lqr_qtol") else "bit-identical to the oracle"},
             # the same launch against the fp64 vector peak (the path is issue-bound, not byte-bound: DESIGN.md section 5)
             "roofline_fp64": {"bound": "fp64 vector", "achieved": flops_per * batch / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": flops_per * batch / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                              "flops_per_problem": flops_per},
+                              "flops_per_problem": flops_per, "flops_executed_per_problem": executed,
+                              "frac_on_flops_executed": executed * batch / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
         }
+        if world == 1 and not args.no_extras and not args.keep_factor:
+            line["factor_kept"] = side_factor_kept(solver, stream, ptrs, nres, batch, torch)
+            line["config1_large"] = side_config1_large(device_index, not args.no_cpu_baseline)
+            line["config4_lsi"] = side_config4_lsi(device_index, not args.no_cpu_baseline)
         if scatter_gather is not None:
             line["scatter_gather"] = scatter_gather
+            line["scatter_gather_ok"] = bool("error" not in scatter_gather and scatter_gather.get("blocks_verified"))
         if world == 1 and overlapped is not None:
             line["overlapped"] = overlapped
         if world == 1 and not args.no_cpu_baseline:
@@ -298,6 +322,185 @@ def bench_lsi(args, world, rank, device_index, coll_device, torch, dist):
         dist.destroy_process_group()
 
 
+def host_cpu_share():
+    """What this job may use of the host: CPUs in the affinity mask, the cgroup CPU quota, and the smaller of the two ("effective_cores")."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        aff = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    quota = float(parts[0]) / float(parts[1])
+            else:
+                q = float(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        quota = q / float(f.read().split()[0])
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    eff = aff if quota is None else max(1.0, min(float(aff), quota))
+    return {"affinity_cpus": aff, "cgroup_cpu_quota": quota, "effective_cores": eff}
+
+
+def self_launch(n):
+    """python bench.py --gpus N without a launcher: N child processes (one rank per GPU), 127.0.0.1 rendezvous, rank 0's stdout is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py: rank exit codes {codes}")
+
+
+def dry_run(args, world, rank):
+    """The multi-rank control flow without a GPU: process group, barriers, max-over-ranks of the elapsed time, rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=2))
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))  # ranks finish at different times: the reported time is the slowest rank's
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    ids = torch.tensor([float(rank)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ids, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "max_rank_seconds": float(t.item()), "rank_id_sum": float(ids.item()), "workload": args.workload}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def side_factor_kept(solver, stream, ptrs, nres, batch, torch):
+    """Next to the metric, never in `value`: the same batches with the factor kept in HBM (all the work of factorize(): the last level too,
+    factor / Householder scalars / pivots written), bit-identical kernels, against ITS algorithmic bytes (40,360 B per problem)."""
+    from lexls_amd import problems as P
+    try:
+        reps = 40
+        with torch.cuda.stream(stream):
+            for i in range(8):
+                solver.setProblemDevice(ptrs[i % nres])
+                solver.factorize_solve(keep_factor=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for i in range(reps):
+                solver.setProblemDevice(ptrs[i % nres])
+                solver.factorize_solve(keep_factor=True)
+            e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        kern = solver.last_kernel()
+        b = P.algorithmic_bytes(NVAR, DIMS, write_factor=True)
+        f = P.flop_model(NVAR, DIMS)["total"]
+        solver.setProblemDevice(ptrs[0])
+        solver.factorize_solve(keep_factor=False)  # leave the x-only solution of batch 0 behind, as the timed steps did
+        torch.cuda.synchronize()
+        return {"kernel": kern, "kernel_ms": ms, "value": batch / (ms * 1e-3), "unit": "factorizations/s", "algorithmic_bytes_per_problem": b,
+                "roofline": {"bound": "hbm", "achieved": b * batch / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "roofline_fp64_frac": f * batch / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "contract": "bit-identical to the oracle"}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def side_config1_large(device_index, with_cpu):
+    """BASELINE configs[1]: ONE equality problem, n = 512, 4 levels x 256 rows, the whole chip on it (lqr_large)."""
+    import lexls_amd
+    from lexls_amd import problems as P
+    try:
+        n, dims = 512, [256] * 4
+        lod = P.lse_batch(20260001, 1, n, dims)
+        s = lexls_amd.BatchedLexLSE(1, n, dims, device=device_index)
+        s.setProblem(lod)
+        for _ in range(3):
+            s.factorize_solve(True)
+        s.synchronize()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s.factorize_solve(True)
+        s.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        flops = P.flop_model(n, dims)["total"]
+        out = {"workload": "single equality l-QR, n=512, 4 levels x 256 rows (BASELINE configs[1])", "kernel": s.last_kernel(), "ms": ms, "gflops": flops / ms / 1e6,
+               "roofline": {"bound": "fp64", "achieved": flops / ms / 1e9, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / FP64_VECTOR_PEAK_TFLOPS},
+               "algorithmic_bytes": P.algorithmic_bytes(n, dims, write_factor=True), "contract": "pivots / ranks exact, values within 1e-10 (step-per-pivot path)"}
+        if with_cpu:
+            from oracle import oracle_ctypes as oc
+            tc, _ = oc.lse_time(lod, dims, n, 1, 2)
+            out["cpu_baseline"] = {"value": 1e3 * tc / 2, "unit": "ms per factorize+solve", "cores": 1, "kind": "port", "gflops": flops / (tc / 2) / 1e9,
+                                   "sample": "2 solves of the same problem, scalar g++ -O3 restatement (oracle/), one thread"}
+        return out
+    except Exception as exc:  # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def side_config4_lsi(device_index, with_cpu, total=1024):
+    """BASELINE configs[4]: lock-step LexLSI batch of 1024 instances, warm-started to ~30 factorizations each (as --workload lsi)."""
+    try:
+        from lexls_amd import lexlsi, problems as P
+        n, dims = NVAR, DIMS
+        base = lexlsi.pack_batch(n, [P.lsi_problem(20260500 + i, n, dims) for i in range(total)])
+        pert = lexlsi.pack_batch(n, [P.lsi_problem(20260500 + i, n, dims, perturb=0.9) for i in range(total)])
+        srv = lexlsi.LsiBatch(n, base.dims, base.types, total, device=device_index)
+        cold = srv.run(base)
+        guess = np.where(cold["active"] == 3, 0, cold["active"]).astype(np.uint8)
+        for _ in range(2):
+            r = srv.run(pert, active_guess=guess, x0=cold["x"])
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = srv.run(pert, active_guess=guess, x0=cold["x"])
+        dt = (time.perf_counter() - t0) / reps
+        f = np.array([i["factorizations"] for i in r["info"]], np.float64)
+        solved = int(sum(i["status"] == 0 for i in r["info"]))
+        stats = srv.stats()
+        srv.close()
+        flops = P.flop_model(n, dims)["total"]  # per factorization of a full problem (an upper bound: working sets hold fewer rows)
+        out = {"workload": f"LexLSI lock-step batch, {total} instances x (n=40, 5 levels x 12 rows, level 0 simple bounds), warm-started (BASELINE configs[4])",
+               "ms_per_batch": 1e3 * dt, "factorizations_per_s": float(f.sum()) / dt, "mean_factorizations": float(f.mean()), "max_factorizations": float(f.max()),
+               "solved": solved, "stages": stats,
+               "roofline": {"bound": "fp64", "achieved": float(f.sum()) * flops / dt / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": float(f.sum()) * flops / dt / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "note": "flops of a full 60 x 41 problem per factorization (upper bound)"}}
+        if with_cpu:
+            from oracle import oracle_ctypes as oc
+            # instances of the same batch through the oracle-backed host driver, one thread, for ~3 s (problem generation not timed)
+            nf, tc, m = 0, 0.0, 0
+            while tc < 3.0 and m < total:
+                objs = P.lsi_problem(20260500 + m, n, dims, perturb=0.9)
+                t0 = time.perf_counter()
+                ro = oc.lsi_run(n, objs, active_guess=np.split(guess[m], np.cumsum(base.dims)[:-1]), x0=cold["x"][m])
+                tc += time.perf_counter() - t0
+                nf += int(ro["info"]["factorizations"])
+                m += 1
+            out["cpu_baseline"] = {"value": nf / tc, "unit": "factorizations/s", "cores": 1, "kind": "port",
+                                   "sample": f"{m} instances of the same warm-started batch ({nf} factorizations, {tc:.2f} s) through the host driver over the oracle, one thread"}
+        return out
+    except Exception as exc:  # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def _committed_traffic(keep_factor):
     """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command (profiles/), if present."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -337,7 +540,10 @@ def cpu_baseline(lod_host, target_seconds):
         t += ts_
         slice_passes = int(max(2, min(5000, 2.0 * repeats / max(t, 1e-9))))
     ts, _ = oc.lse_time(sample[:256], DIMS, NVAR, 1, 8)  # one thread alone, for the per-thread rate without contention
-    return {"value": len(sample) * repeats / t, "unit": "factorizations/s", "cores": threads, "kind": "port",
+    share = host_cpu_share()
+    # `cores` = what the job can actually run on (affinity mask and cgroup quota), not the number of threads the probe preferred
+    return {"value": len(sample) * repeats / t, "unit": "factorizations/s", "cores": int(round(min(threads, share["effective_cores"]))), "threads": threads,
+            "kind": "port", **share,
             "per_thread": len(sample) * repeats / t / threads, "single_thread_alone": 256 * 8 / ts,
             "sample": f"{repeats} passes over {len(sample)} problems of the bench batch ({t:.1f} s in ~2-s slices, g++ -O3 scalar restatement, {threads} std::threads started once per slice, "
                       f"one solver object per thread; {hw} hardware threads on the host, thread count chosen by a probe)"}

@@ -215,6 +215,47 @@ def algorithmic_bytes(nvar: int, dims, write_factor: bool = False) -> int:
     return b
 
 
+def _levels_reached_x_only(nvar: int, dims, ranks=None):
+    """Number of leading levels an x-only solve has to read: those that start before the columns are exhausted."""
+    dims = list(dims)
+    if ranks is None:
+        ranks, left = [], nvar
+        for d in dims:
+            r = min(d, left)
+            ranks.append(r)
+            left -= r
+    c, reached = 0, 0
+    for r in ranks:
+        if c >= nvar:
+            break
+        reached += 1
+        c += r
+    return reached, ranks
+
+
+def bytes_touched_x_only(nvar: int, dims, ranks=None) -> int:
+    """Bytes the x-only kernels actually move per problem: the rows of the levels reached before the columns are exhausted (the rows below
+    never influence x), x, the column permutation, ranks / first columns, TotalRank."""
+    reached, _ = _levels_reached_x_only(nvar, dims, ranks)
+    dims = list(dims)
+    return 8 * sum(dims[:reached]) * (nvar + 1) + 8 * nvar + 4 * nvar + 8 * len(dims) + 4
+
+
+def flops_executed_x_only(nvar: int, dims, ranks=None) -> int:
+    """flop_model() without the elimination of the rows of the levels that are never reached (their multipliers and Schur complements are
+    part of the factor, not of x)."""
+    reached, ranks = _levels_reached_x_only(nvar, dims, ranks)
+    dims = list(dims)
+    total = flop_model(nvar, dims, ranks)["total"]
+    skipped_rows = sum(dims[reached:])
+    c = 0
+    for k, r in enumerate(ranks[:reached]):
+        if k < len(dims) - 1 and r > 0:
+            total -= skipped_rows * r * r + 2 * skipped_rows * r * (nvar - (c + r) + 1)
+        c += r
+    return total
+
+
 # --- inequality (LexLSI) problems: BASELINE.md C5 -------------------------------------------------
 
 def lsi_problem(seed: int, nvar: int = 40, dims=(12, 12, 12, 12, 12), simple_bounds: bool = True, perturb: float = 0.0, perturb_seed: int = 0):
