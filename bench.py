@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 NVAR, DIMS, PER_GPU_BATCH, SEED0 = 40, [12] * 5, 4096, 20260100
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz (the fp64 MFMA rate is the same)
-MIN_WARMUP = 20  # launches before the timed region, whatever --warmup says: clocks and caches in steady state
+MIN_WARMUP = 20  # launches before the timed region, whatever --warmup says: caches in steady state
+MIN_WARMUP_SECONDS = 0.5  # ... and at least this long: the timed region of a short run (--steps 20 is 1 ms) must not fall into the clock ramp
 
 
 def main():
@@ -112,8 +113,12 @@ def main():
         solver.factorize_solve(keep_factor=args.keep_factor)
 
     with torch.cuda.stream(stream):
-        for i in range(max(args.warmup, MIN_WARMUP)):
-            step(i)
+        warm_run, t_w = 0, time.perf_counter()
+        while warm_run < max(args.warmup, MIN_WARMUP) or time.perf_counter() - t_w < MIN_WARMUP_SECONDS:
+            for i in range(50):
+                step(warm_run + i)
+            warm_run += 50
+            torch.cuda.synchronize()
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -227,7 +232,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "warmup_run": max(args.warmup, MIN_WARMUP),
+            "warmup_run": warm_run,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
