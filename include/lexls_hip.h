@@ -183,13 +183,23 @@ int lexls_lse_device_ptr(lexls_lse_t h, int which, void **d_ptr);
 
 /* name of the kernel variant the last factorize/factorize_solve call dispatched to (diagnostics) */
 const char *lexls_lse_last_kernel(lexls_lse_t h);
-/* diagnostics (parity tests run every path): policy 0 = automatic dispatch (small shapes: x-only solves without fixed variables take the
- * four-problems-per-wavefront kernel at every batch size; with the factor kept the register-resident wave kernel while the batch fits one
- * round of it, beyond that the four-per-wavefront kernel's factor-keeping form (the left-looking wave kernel where that does not fit); problems beyond one CU's LDS: the step-per-pivot path with the trailing update on the matrix cores — pivots / ranks
- * exact, values within 1e-10 of the ordered-chain arithmetic); 1 = only the generic one-workgroup-per-problem kernel; 2 = automatic, but
- * never the left-looking / four-per-wavefront kernels; 3 = the left-looking wave kernel whenever the shape allows it, whatever the batch
- * size; 4 = the four-problems-per-wavefront kernel whenever the shape allows it (x-only solves; else as 3); 5 = automatic, but large
- * problems take the bit-exact multi-launch path (ordered chains, two launches per pivot) */
+/* Kernel policy — which CONTRACT a solve is held to, and which kernel family serves it.
+ *   Contracts: (B) bit-identical to the arithmetic contract of oracle/lexlse_oracle.h (pivots, ranks, Householder scalars, factor, x, multipliers);
+ *              (T) BASELINE north_star's: column permutation, ranks and first columns exact, x (and factor MAGNITUDES) within 1e-10.
+ *   policy 0 = automatic dispatch.  (T) for x-only solves of the IK shape — n = 40, every level 12 rows, no fixed variables, no regularization:
+ *              lqr_qtol, the bench kernel — and for problems beyond one CU's LDS (the step-per-pivot path with the trailing update on the matrix
+ *              cores; there the reflector of a row that exactly repeats a row of an earlier level may come out with the opposite SIGN — that row of R
+ *              and its essential part are negated, x and everything else agree: consumers of get_lexqr / hh scalars that need sign parity with the
+ *              ordered-chain arithmetic ask for policy 5).  (B) for everything else: with the factor kept the register-resident wave kernel while
+ *              the batch fits one round of it, beyond that the four-per-wavefront kernel's factor-keeping form (the left-looking wave kernel
+ *              where that does not fit); x-only solves of other small shapes the four-per-wavefront kernel.  LEXLS_QTOL=0 in the environment keeps
+ *              every small-shape solve on (B).
+ *   1 = only the generic one-workgroup-per-problem kernel (B);  2 = automatic, but never the left-looking / four-per-wavefront kernels (B);
+ *   3 = the left-looking wave kernel whenever the shape allows it, whatever the batch size (B);
+ *   4 = the bit-exact four-problems-per-wavefront kernel whenever the shape allows it (x-only solves; else as 3) (B);
+ *   5 = automatic with (B) everywhere: small shapes as under LEXLS_QTOL=0, large problems on the bit-exact multi-launch path (ordered chains, two
+ *       launches per pivot) — the policy for factor / sign parity;
+ *   6 = the tolerance-contract kernel lqr_qtol wherever it serves (T), else as 0. */
 int lexls_lse_set_kernel_policy(lexls_lse_t h, int policy);
 
 /* ---- inequality problems: the reference's LexLSI active-set driver (lexlsi.h), kept on the host -------------

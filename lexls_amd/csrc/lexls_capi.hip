@@ -280,9 +280,24 @@ extern "C"
         return LEXLS_OK;
     }
 
+    /// A round whose rows are read by reference inside the register-resident wave kernel (fused_gather) leaves `in` unassembled.  Anything that
+    /// can send the next factorization to ANOTHER kernel (kernel policy, regularization type) assembles the rows first.
+    static hipError_t materialize_fused_gather(lexls_lse_t h)
+    {
+        if (!h->fused_gather) return hipSuccess;
+        hipError_t e = hipSetDevice(h->device);
+        if (e != hipSuccess) return e;
+        h->fused_gather = false;
+        LseArgs a       = h->args();
+        e = launch_gather_rows(a, h->d_cdata, h->cdata_per_problem, h->d_row_src, h->d_row_ld, h->d_in_owned, h->stream);
+        h->d_in = h->d_in_owned;
+        return e;
+    }
+
     int lexls_lse_set_regularization(lexls_lse_t h, int type, const double *h_factors, int per_problem, double variable_factor)
     {
         CHECK_HANDLE(h);
+        if ((uint32_t)type != h->reg_type) HIP_TRY(materialize_fused_gather(h));
         switch (type)
         {
         case 0: case 1: case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: break;
@@ -926,6 +941,7 @@ extern "C"
     int lexls_lse_set_kernel_policy(lexls_lse_t h, int force_generic)
     {
         CHECK_HANDLE(h);
+        if (force_generic != h->force_generic) HIP_TRY(materialize_fused_gather(h)); // another kernel may read `in`: the rows named by the round must be there
         h->force_generic = force_generic;
         return LEXLS_OK;
     }

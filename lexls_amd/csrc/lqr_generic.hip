@@ -2160,11 +2160,15 @@ namespace lexls
         // Factor staged into LDS when latency is what counts: few problems per CU (a lock-step LSI stage) — with thousands of problems
         // the 20 KB per workgroup would cost the wavefronts in flight that hide the chains instead (4096 problems: 0.090 -> 0.126 ms)
         const size_t lds_staged = lds + 8 * ((size_t)(a.cap | 1u) * (a.nVar + 1) + a.cap) + (((size_t)a.cap + a.nVar + 15) & ~(size_t)15);
-        static int cus          = 0;
-        if (!cus)
+        int cus = 256; // of the CURRENT device (a process may drive several)
         {
+            static int cus_of[64] = {0};
             int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64)
+            {
+                if (!cus_of[dev] && (hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus_of[dev] <= 0)) cus_of[dev] = 256;
+                cus = cus_of[dev];
+            }
         }
         // the single-sweep form (sensitivity_sweep_kernel): level dims <= 16, at most 8 objectives per sweep, one wavefront per problem with
         // the factor staged in LDS — what a lock-step LSI stage asks for.  max_level_dim comes from the caller (0 = unknown: not taken)

@@ -1524,7 +1524,26 @@ namespace lexls
         // (configs[1]: 2.74 ms vs 3.45 ms).  Its hand-offs spin (bounded); a launch whose spins ran out raises `abort`, ends, and the level
         // is redone with a launch per pivot (LEXLS_LARGE_PERSIST=0: always a launch per pivot; =2: raise `abort` at once, for the tests)
         const size_t persist_lds = 8 * ((size_t)PTC * (maxdim | 1u) + 3 * (size_t)maxdim + PTC) + 8 * (size_t)(n + 1);
-        const bool persist       = B == 1 && G <= 256 && persist_lds <= kMaxLdsBytes && a.skip == nullptr && !(std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) == 0);
+        // The workgroups of that launch wait for each other, so ALL G of them must be resident at once: checked against what THIS device can hold
+        // (occupancy query x CU count; one workgroup fewer per CU than the query says where the SGPR count sits at an edge — MI355X_MICROARCH.md,
+        // "Residency and cooperative launch"); otherwise the launch-per-pivot form.  A plain launch has the same residency as a cooperative
+        // one (same guide), and every spin is bounded, so a partitioned or busy device costs a fallback, never a hang.
+        bool persist = B == 1 && G <= 256 && persist_lds <= kMaxLdsBytes && a.skip == nullptr && !(std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) == 0);
+        if (persist)
+        {
+            int dev = 0, cus = 0, per_cu = 0;
+            if (persist_lds > 64 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void *>(fast_level_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds) != hipSuccess)
+                persist = false;
+            if (persist && (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+                            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fast_level_persist, 256, persist_lds) != hipSuccess))
+                persist = false;
+            if (persist)
+            {
+                const long resident = (long)cus * (per_cu > 1 ? per_cu - 1 : per_cu); // (margin of one workgroup per CU where more than one fits)
+                if (per_cu < 1 || resident < (long)G) persist = false;
+            }
+        }
         const bool persist_test_abort = persist && std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) == 2;
 
         hipError_t e         = hipSuccess;

@@ -57,14 +57,16 @@ namespace lexls
     /// waves of the register-resident kernel the device holds at once (2 per SIMD): up to that many problems run in ONE round of it
     static uint32_t resident_wave_capacity()
     {
-        static uint32_t cap = 0;
-        if (!cap)
+        static uint32_t cap_of[64] = {0}; // per device (a process may drive several)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256u * 4u * 2u;
+        if (!cap_of[dev])
         {
-            int dev = 0, cus = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-            cap = (uint32_t)cus * 4u * 2u;
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            cap_of[dev] = (uint32_t)cus * 4u * 2u;
         }
-        return cap;
+        return cap_of[dev];
     }
 
     /// which four-per-wavefront instantiation (0: none) automatic dispatch / the policies take for these arguments
