@@ -473,19 +473,21 @@ namespace lexls
                         cur_lbs = nxt_lbs, cur_ispl = nxt_ispl, cur_w = nxt_w;
                     }
 
-                    for_each_index<0, MD>([&](auto cnt) __attribute__((always_inline)) {
+                    int pf_issued = 0; // pieces of the next level requested so far (wave-uniform)
+                    qt_for_each_while<0, MD>(
+                        [&](auto) __attribute__((always_inline)) { return __ballot(go) != 0ull; }, // no row of the wavefront has work left: ONE branch leaves the level
+                        [&](auto cnt) __attribute__((always_inline)) {
                         constexpr int j   = decltype(cnt)::value;
                         constexpr int ce  = j & ~1;       // first (even) row of this step's hand-off
                         constexpr int cen = (j + 1) & ~1; // ... of the next step's
-                        // the next level's pieces: PF_PER per pivot step from the first step on (executed whether or not this step still has work)
-                        if (prefetch)
+                        // the next level's pieces: PF_PER per pivot step from the first step on (what an early end leaves over is requested behind the loop)
                         {
                             constexpr int TOT = NH * NIH, PF_PER = (TOT + PF_STEPS - 1) / PF_STEPS;
-                            for_each_index<(j * PF_PER < TOT ? j * PF_PER : TOT), ((j + 1) * PF_PER < TOT ? (j + 1) * PF_PER : TOT)>(
-                                [&](auto tt) __attribute__((always_inline)) { prefetch_piece(tt, F + MD); });
+                            constexpr int lo = (j * PF_PER < TOT ? j * PF_PER : TOT), hi = ((j + 1) * PF_PER < TOT ? (j + 1) * PF_PER : TOT);
+                            if (prefetch) for_each_index<lo, hi>([&](auto tt) __attribute__((always_inline)) { prefetch_piece(tt, F + MD); });
+                            pf_issued = hi;
                         }
                         const bool act = go;
-                        if (__ballot(act) == 0ull) return;
                         CSTAMP(0, (int)cur_w)
                         quad_lds_fence();
                         double col[MD];
@@ -657,6 +659,10 @@ namespace lexls
                         CSTAMP(6, __double2loint(blk[NS - 1][MD - 1]))
                         FSTAMP(5)
                     });
+                    if (prefetch)
+                        for_each_index<0, NH * NIH>([&](auto tt) __attribute__((always_inline)) {
+                            if (decltype(tt)::value >= pf_issued) prefetch_piece(tt, F + MD);
+                        });
                     (void)SL;
                 };
                 {
