@@ -472,6 +472,22 @@ namespace lexls
                         for (int r = 0; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = make_double2(colv[r], colv[r + 1]);
                         cur_lbs = nxt_lbs, cur_ispl = nxt_ispl, cur_w = nxt_w;
                     }
+                    // the winner's column is read AHEAD: as soon as a step knows the next pivot's lane, the read is issued — the rest of the step (rank-one
+                    // update of the other columns) runs while it is on its way
+                    double coln[MD];
+                    auto fetch_column = [&](auto jjc, unsigned w) __attribute__((always_inline)) {
+                        constexpr int ce0 = decltype(jjc)::value & ~1;
+                        quad_lds_fence();
+                        const int src = o_stage + (int)(w & 15u) * kHandoffStride;
+#pragma unroll
+                        for (int r = ce0; r < MD; r += 2)
+                        {
+                            const double2 v = D2(src + 8 * r);
+                            coln[r]         = v.x;
+                            coln[r + 1]     = v.y;
+                        }
+                    };
+                    fetch_column(std::integral_constant<int, 0>{}, cur_w);
 
                     int pf_issued = 0; // pieces of the next level requested so far (wave-uniform)
                     qt_for_each_while<0, MD>(
@@ -489,19 +505,9 @@ namespace lexls
                         }
                         const bool act = go;
                         CSTAMP(0, (int)cur_w)
-                        quad_lds_fence();
                         double col[MD];
-                        {
-                            const int src = o_stage + (int)(cur_w & 15u) * kHandoffStride;
 #pragma unroll
-                            for (int r = ce; r < MD; r += 2)
-                            {
-                                const double2 v = D2(src + 8 * r);
-                                col[r]          = v.x;
-                                col[r + 1]      = v.y;
-                            }
-                        }
-                        quad_lds_fence();
+                        for (int r = ce; r < MD; r++) col[r] = coln[r];
                         FSTAMP(2)
                         CSTAMP(1, __double2loint(col[MD - 1]))
                         CSTAMP_COLLECT
@@ -607,6 +613,7 @@ namespace lexls
 #pragma unroll
                             for (int r = cen; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = make_double2(blk[S0][r], blk[S0][r + 1]);
                             decide_finish(m);
+                            fetch_column(std::integral_constant<int, j + 1>{}, nxt_w);
                         }
                         else if constexpr (j + 1 < MD)
                         {
@@ -643,6 +650,7 @@ namespace lexls
 #pragma unroll
                             for (int r = cen; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = make_double2(colv[r], colv[r + 1]);
                             decide_finish(m);
+                            fetch_column(std::integral_constant<int, j + 1>{}, nxt_w);
                         }
                         CSTAMP(5, (int)nxt_w)
                         // rows below of every live column
