@@ -155,7 +155,9 @@ namespace lexls
 
         constexpr int kQtSentinelHi = (int)0xFFE00000; // -2^1023 * 1.x: below every down-dated norm, finite whatever the low word
 
-        template <int NS, int MD, int SIG>
+        /// NV: the number of variables when the instantiation serves ONE n (0: taken from the arguments) — the piece counts of the level loads and
+        /// the layout tests then fold at compile time
+        template <int NS, int MD, int SIG, int NV>
         __global__ __launch_bounds__(64) void lqr_qtol_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes, uint32_t stagger)
         {
             static_assert(NS >= 1 && NS <= 4 && MD <= 16 && (MD % 4) == 0, "shape limits of the row layout / two row parts of even size");
@@ -173,7 +175,7 @@ namespace lexls
             const int lane = threadIdx.x & 63;
             const int g    = lane >> 4; // row = problem inside the wave
             const int gl   = lane & 15;
-            const int n    = (int)a.nVar;
+            const int n    = NV ? NV : (int)a.nVar;
             const int cap  = (int)a.cap;
             const int nObj = (int)a.nObj;
             const uint32_t b  = blockIdx.x * 4u + (uint32_t)g;
@@ -290,11 +292,13 @@ namespace lexls
 #pragma unroll
                 for (int s = 0; s < NS; s++)
                 {
-                    const int P = 16 * s + gl - SIG;
-                    pc[s]       = (P >= 0 && P < n) ? (int)B8(o_phys + P) : (P == n ? n : 0);
-                    pos[s]      = (P >= 0 && P <= n) ? P : 0x3fffff;
-                    em[s]       = *reinterpret_cast<const unsigned long long *>(L + o_emap + 8 * pc[s]);
+                    const int P  = 16 * s + gl - SIG;
+                    const int ph = (int)B8(o_phys + (P >= 0 && P < n ? P : 0)); // (unconditional reads: the three slots' look-ups go out together)
+                    pc[s]        = (P >= 0 && P < n) ? ph : (P == n ? n : 0);
+                    pos[s]       = (P >= 0 && P <= n) ? P : 0x3fffff;
                 }
+#pragma unroll
+                for (int s = 0; s < NS; s++) em[s] = *reinterpret_cast<const unsigned long long *>(L + o_emap + 8 * pc[s]);
                 if (k == 0)
                 {
                     // The first level: the position layout is the identity, so lane = column loads the block directly (no staging).  Every wave
@@ -825,27 +829,27 @@ namespace lexls
             return ((raw + 127) / 256) * 256 + 128;
         }
 
-        template <int NS, int MD, int SIG>
+        template <int NS, int MD, int SIG, int NV>
         hipError_t launch_qtol_t(const LseArgs &a, hipStream_t s)
         {
             const uint32_t img  = qtol_image_doubles(a.nVar, a.nObj, MD);
             const size_t gbytes = qtol_group_bytes<NS, MD>(a.nVar, a.nObj);
             const size_t lds    = 4 * gbytes;
-            if (lds > kMaxLdsBytes || a.nObj > (uint32_t)kQuadMaxObj || a.nVar + 1 + SIG > 16u * NS || a.nVar > 63u) return hipErrorInvalidValue;
+            if (lds > kMaxLdsBytes || a.nObj > (uint32_t)kQuadMaxObj || a.nVar + 1 + SIG > 16u * NS || a.nVar > 63u || (NV && a.nVar != (uint32_t)NV)) return hipErrorInvalidValue;
             if (a.uniform_dim != (uint32_t)MD || (a.cap & 1u) || (reinterpret_cast<uintptr_t>(a.in) & 15u) || a.nfixed || a.reg_type != 0) return hipErrorInvalidValue;
             if (lds > 64 * 1024)
             {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_qtol_kernel<NS, MD, SIG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_qtol_kernel<NS, MD, SIG, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
             }
             const uint32_t blocks = (a.batch + 3u) / 4u;
             static const uint32_t stagger = std::getenv("LEXLS_QTOL_STAGGER") ? (uint32_t)std::atoi(std::getenv("LEXLS_QTOL_STAGGER")) : 0u; // x 512 cycles per SIMD index
-            hipLaunchKernelGGL((lqr_qtol_kernel<NS, MD, SIG>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes, stagger);
+            hipLaunchKernelGGL((lqr_qtol_kernel<NS, MD, SIG, NV>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes, stagger);
             return hipGetLastError();
         }
     } // namespace
 } // namespace lexls
 
-#define LEXLS_QTOL_INSTANCE(NAME, NS, MD, SIG) \
-    namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_qtol_t<NS, MD, SIG>(a, s); } \
+#define LEXLS_QTOL_INSTANCE(NAME, NS, MD, SIG, NV) \
+    namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_qtol_t<NS, MD, SIG, NV>(a, s); } \
                       size_t NAME##_lds(uint32_t nVar, uint32_t nObj) { return 4 * qtol_group_bytes<NS, MD>(nVar, nObj); } }
