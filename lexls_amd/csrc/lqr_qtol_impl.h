@@ -171,7 +171,10 @@ namespace lexls
 #endif
             constexpr int PF_STEPS = LEXLS_QTOL_PF_STEPS < MD ? LEXLS_QTOL_PF_STEPS : MD; // pivot steps over which a level's requests are spread
             extern __shared__ double smem[];
-            char *const L  = reinterpret_cast<char *>(smem);
+            // LDS is addressed by 32-bit byte addresses turned into address-space-3 pointers directly (base of the dynamic block folded into the
+            // slice offset once): an access through a generic pointer costs an extra add of the block's base (zero) per access
+            typedef __attribute__((address_space(3))) char lds_char;
+            const int lds0 = (int)(unsigned)(size_t)(lds_char *)smem;
             const int lane = threadIdx.x & 63;
             const int g    = lane >> 4; // row = problem inside the wave
             const int gl   = lane & 15;
@@ -186,7 +189,7 @@ namespace lexls
             const uint32_t poff    = (bb - blockIdx.x * 4u) * pstride;
 
             // ---- LDS carve-up of this row's slice (byte offsets; launch_qtol_t computes group_bytes) ----
-            const int o_img   = g * (int)group_bytes;
+            const int o_img   = lds0 + g * (int)group_bytes;
             const int o_xs    = o_img + 8 * (int)img_doubles; // 16*NS : x by position (zero until the back-substitution: also the "U" of a position that is no pivot yet)
             const int o_ex    = o_xs + 8 * 16 * NS;           // MD    : dump slots (one dword per lane) of byte stores that do not apply
             const int o_phys  = o_ex + 8 * MD;                // 64 B  : physical column at each position
@@ -194,10 +197,13 @@ namespace lexls
             const int o_meta  = o_perm + 64;                  // kQuadMaxObj x {first column, rank, image offset, image width}
             const int o_emap  = o_meta + 16 * kQuadMaxObj;    // 16 NS x 8 B: byte k of entry j = column index of PHYSICAL column j in the image of level k
             const int o_stage = o_emap + 8 * 16 * NS;         // max((n + 1) RP, 16 MD) doubles: staging block of the level loads; 16 hand-off slots of the pivot steps
-            auto D   = [&](int off) -> double & { return *reinterpret_cast<double *>(L + off); };
-            auto D2  = [&](int off) -> double2 & { return *reinterpret_cast<double2 *>(L + off); };
-            auto B8  = [&](int off) -> uint8_t & { return *reinterpret_cast<uint8_t *>(L + off); };
-            auto U32 = [&](int off) -> uint32_t & { return *reinterpret_cast<uint32_t *>(L + off); };
+            auto D   = [&](int off) -> __attribute__((address_space(3))) double & { return *(__attribute__((address_space(3))) double *)(size_t)(unsigned)off; };
+            auto D2  = [&](int off) -> __attribute__((address_space(3))) qt_d2 & { return *(__attribute__((address_space(3))) qt_d2 *)(size_t)(unsigned)off; };
+            auto B8  = [&](int off) -> __attribute__((address_space(3))) uint8_t & { return *(__attribute__((address_space(3))) uint8_t *)(size_t)(unsigned)off; };
+            auto U32 = [&](int off) -> __attribute__((address_space(3))) uint32_t & { return *(__attribute__((address_space(3))) uint32_t *)(size_t)(unsigned)off; };
+            auto U64 = [&](int off) -> __attribute__((address_space(3))) unsigned long long & { return *(__attribute__((address_space(3))) unsigned long long *)(size_t)(unsigned)off; };
+            typedef unsigned qt_u4 __attribute__((ext_vector_type(4)));
+            auto U4 = [&](int off) -> __attribute__((address_space(3))) qt_u4 & { return *(__attribute__((address_space(3))) qt_u4 *)(size_t)(unsigned)off; };
 
 #pragma unroll
             for (int s = 0; s < 4; s++) B8(o_phys + 16 * s + gl) = (uint8_t)(16 * s + gl);
@@ -298,7 +304,7 @@ namespace lexls
                     pos[s]       = (P >= 0 && P <= n) ? P : 0x3fffff;
                 }
 #pragma unroll
-                for (int s = 0; s < NS; s++) em[s] = *reinterpret_cast<const unsigned long long *>(L + o_emap + 8 * pc[s]);
+                for (int s = 0; s < NS; s++) em[s] = U64(o_emap + 8 * pc[s]);
                 if (k == 0)
                 {
                     // The first level: the position layout is the identity, so lane = column loads the block directly (no staging).  Every wave
@@ -340,7 +346,7 @@ namespace lexls
 #pragma unroll
                         for (int m = 0; m < HP; m++)
                         {
-                            const double2 v          = D2(o_stage + 16 * (pc[s] * HP + m));
+                            const qt_d2 v            = D2(o_stage + 16 * (pc[s] * HP + m));
                             blk[s][h * RP + 2 * m]     = v.x;
                             blk[s][h * RP + 2 * m + 1] = v.y;
                         }
@@ -473,7 +479,7 @@ namespace lexls
                             for (int r = 0; r < MD; r++) colv[r] = sel(pick, blk[s][r], colv[r]);
                         }
 #pragma unroll
-                        for (int r = 0; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = make_double2(colv[r], colv[r + 1]);
+                        for (int r = 0; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = qt_d2{colv[r], colv[r + 1]};
                         cur_lbs = nxt_lbs, cur_ispl = nxt_ispl, cur_w = nxt_w;
                     }
                     // the winner's column is read AHEAD: as soon as a step knows the next pivot's lane, the read is issued — the rest of the step (rank-one
@@ -486,7 +492,7 @@ namespace lexls
 #pragma unroll
                         for (int r = ce0; r < MD; r += 2)
                         {
-                            const double2 v = D2(src + 8 * r);
+                            const qt_d2 v   = D2(src + 8 * r);
                             coln[r]         = v.x;
                             coln[r + 1]     = v.y;
                         }
@@ -615,7 +621,7 @@ namespace lexls
                             m = dpp_max<0x140>(m);
                             upd_rows(std::integral_constant<int, 3>{});
 #pragma unroll
-                            for (int r = cen; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = make_double2(blk[S0][r], blk[S0][r + 1]);
+                            for (int r = cen; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = qt_d2{blk[S0][r], blk[S0][r + 1]};
                             decide_finish(m);
                             fetch_column(std::integral_constant<int, j + 1>{}, nxt_w);
                         }
@@ -652,7 +658,7 @@ namespace lexls
 #pragma unroll
                             for (int r = (cen > j + 1 ? cen : j + 1); r < MD; r++) colv[r] = dfma(gsb, col[r], colv[r]);
 #pragma unroll
-                            for (int r = cen; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = make_double2(colv[r], colv[r + 1]);
+                            for (int r = cen; r < MD; r += 2) D2(o_stage + gl * kHandoffStride + 8 * r) = qt_d2{colv[r], colv[r + 1]};
                             decide_finish(m);
                             fetch_column(std::integral_constant<int, j + 1>{}, nxt_w);
                         }
@@ -739,7 +745,7 @@ namespace lexls
             const int o_zero = o_xs + 8 * (16 * NS - 1);
             for (int k = nObj; k--;)
             {
-                const uint4 mt = *reinterpret_cast<const uint4 *>(L + o_meta + 16 * k); // {first column, rank, image offset, image width}
+                const qt_u4 mt = U4(o_meta + 16 * k); // {first column, rank, image offset, image width}
                 const int rank = live ? (int)mt.y : 0;
                 const int rmax = rows_max(rank);
                 if (rmax == 0) continue;
