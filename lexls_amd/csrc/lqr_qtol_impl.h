@@ -188,6 +188,26 @@ namespace lexls
             const double *inw      = a.in + (size_t)blockIdx.x * 4u * pstride; // wave-uniform base; lane offsets stay 32-bit
             const uint32_t poff    = (bb - blockIdx.x * 4u) * pstride;
 
+            // ---- the first level's rows are requested before anything else (every wave of the chip asks for its first level at once: the HBM serves
+            //      this burst at its full rate, and nothing can be computed before it lands).  Its position layout is the identity, so lane = column
+            //      loads the block directly, no staging; for such a burst this pattern is also the fastest of those measured
+            //      (scripts/ubench/loadpat.hip: 7.7-8.4 k cycles per level against 9.5 k for the 48-byte pieces) ----
+            double blk[NS][MD]; // the level block, position layout
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+            {
+                const int P       = 16 * s + gl - SIG;
+                const int c       = (P >= 0 && P <= n) ? P : 0;
+                const qt_d2 *src2 = reinterpret_cast<const qt_d2 *>(inw + (poff + (uint32_t)(c * cap)));
+#pragma unroll
+                for (int r = 0; r < MD / 2; r++)
+                {
+                    const qt_d2 v     = src2[r];
+                    blk[s][2 * r]     = v.x;
+                    blk[s][2 * r + 1] = v.y;
+                }
+            }
+
             // ---- LDS carve-up of this row's slice (byte offsets; launch_qtol_t computes group_bytes) ----
             const int o_img   = lds0 + g * (int)group_bytes;
             const int o_xs    = o_img + 8 * (int)img_doubles; // 16*NS : x by position (zero until the back-substitution: also the "U" of a position that is no pivot yet)
@@ -242,7 +262,6 @@ namespace lexls
                     qt_pf_load<t>(inw + (pieceoff[t] + (uint32_t)Frow));
             };
 
-            double blk[NS][MD]; // the level block, position layout
             int rp[NS];         // slot s, lane l: LDS byte address of the (triangular) image row of pivot position c = 16 s + l - SIG
             int rq[NS];         // slot s, lane l: v_perm selector that picks the byte of pivot position c's LEVEL out of a column's index word
             unsigned long long em[NS]; // the index word of the column held in slot s
@@ -305,27 +324,7 @@ namespace lexls
                 }
 #pragma unroll
                 for (int s = 0; s < NS; s++) em[s] = U64(o_emap + 8 * pc[s]);
-                if (k == 0)
-                {
-                    // The first level: the position layout is the identity, so lane = column loads the block directly (no staging).  Every wave
-                    // of the chip asks for its first level at once; for such a burst this pattern is also the fastest of those measured
-                    // (scripts/ubench/loadpat.hip: 7.7-8.4 k cycles per level against 9.5 k for the 48-byte pieces)
-#pragma unroll
-                    for (int s = 0; s < NS; s++)
-                    {
-                        const int P       = 16 * s + gl - SIG;
-                        const int c       = (P >= 0 && P <= n) ? P : 0;
-                        const qt_d2 *src2 = reinterpret_cast<const qt_d2 *>(inw + (poff + (uint32_t)(c * cap)));
-#pragma unroll
-                        for (int r = 0; r < MD / 2; r++)
-                        {
-                            const qt_d2 v     = src2[r];
-                            blk[s][2 * r]     = v.x;
-                            blk[s][2 * r + 1] = v.y;
-                        }
-                    }
-                }
-                else
+                if (k > 0)
                 for_each_index<0, NH>([&](auto hh) __attribute__((always_inline)) {
                     constexpr int h = decltype(hh)::value;
                     // the pieces come out of their fixed registers (requested during the level in front, or just now)
@@ -768,11 +767,21 @@ namespace lexls
                     const int ph    = (int)B8(o_phys + c);
                     const int offv  = have ? (int)B8(o_emap + 8 * ph + k) : 0;
                     const double xv = D(o_xs + 8 * c); // (zero where the position does not apply)
+                    double uj[16]; // all sixteen reads in flight before the first is used (issued a few at a time, each group pays the LDS latency)
                     for_each_index<0, 16>([&](auto jj) {
                         constexpr int j = decltype(jj)::value;
-                        const double uj = D(row + 8 * gbci<j>(offv));
-                        sv              = dfma(-uj, gbc<j>(xv), sv);
+                        uj[j]           = D(row + 8 * gbci<j>(offv));
                     });
+                    __builtin_amdgcn_sched_barrier(0);
+                    double s0 = 0.0, s1 = 0.0; // two chains
+                    for_each_index<0, 16>([&](auto jj) {
+                        constexpr int j = decltype(jj)::value;
+                        if (j & 1)
+                            s1 = dfma(-uj[j], gbc<j>(xv), s1);
+                        else
+                            s0 = dfma(-uj[j], gbc<j>(xv), s0);
+                    });
+                    sv += s0 + s1;
                 }
                 sv = sel(gl < rank, sv, 0.0);
                 for_each_index<1, MD>([&](auto jj) {
