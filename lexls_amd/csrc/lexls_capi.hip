@@ -710,8 +710,11 @@ extern "C"
         else if (shape_kernels && h->force_generic != 2 && h->max_rows > 64 && h->max_level_dim <= 16 && a.nObj <= 16 &&
                  deep_kernel_supports(a, h->max_level_dim, write_factor, h->has_fixed))
         {
-            // deep hierarchies (more than 64 rows in all): the left-looking kernels, whose LDS holds pivot rows only
-            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, 2, h->stream, &variant));
+            // deep hierarchies (more than 64 rows in all): the left-looking kernels, whose LDS holds pivot rows only (x-only solves of the IK
+            // shape: the tolerance-contract kernel under the same rules as above — it reads a level's rows when the level starts, too)
+            static const bool qtol_env2 = !(std::getenv("LEXLS_QTOL") && std::atoi(std::getenv("LEXLS_QTOL")) == 0);
+            const bool tol_ok2 = !h->fused_gather && (h->force_generic == 6 || (h->force_generic == 0 && qtol_env2));
+            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, 2, h->stream, &variant, tol_ok2));
         }
         else if (shape_kernels && h->reg_type == 0 && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
         {

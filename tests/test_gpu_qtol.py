@@ -80,8 +80,8 @@ def test_tied_norms_first_maximum_by_position(hip, oracle):
     check(hip, oracle, lod)
 
 
-@pytest.mark.parametrize("nobj", [1, 2, 3, 4])
-def test_fewer_levels(hip, oracle, nobj):
+@pytest.mark.parametrize("nobj", [1, 2, 3, 4, 6, 8])
+def test_fewer_and_more_levels(hip, oracle, nobj):
     dims = [12] * nobj
     lod = P.lse_batch(40 + nobj, 19, N, dims)
     ref = oracle.lse_run(lod, dims, N)
