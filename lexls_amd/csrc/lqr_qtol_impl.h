@@ -136,11 +136,12 @@ namespace lexls
         // (scripts/check_qtol_regs.py, run by the Makefile).
 #define QT_PF_LIST(X) X(0, 184, 187) X(1, 188, 191) X(2, 192, 195) X(3, 196, 199) X(4, 200, 203) X(5, 204, 207) X(6, 208, 211) X(7, 212, 215) X(8, 216, 219) \
     X(9, 220, 223) X(10, 224, 227) X(11, 228, 231) X(12, 232, 235) X(13, 236, 239) X(14, 240, 243) X(15, 244, 247) X(16, 248, 251) X(17, 252, 255)
+        /// piece T <- 16 bytes at base (wave-uniform, in scalar registers) + byte offset (per lane): no vector address arithmetic per request
         template <int T>
-        __device__ __forceinline__ void qt_pf_load(const double *p)
+        __device__ __forceinline__ void qt_pf_load(const double *base, uint32_t byte_offset)
         {
 #define QT_PF_LOAD(t, lo, hi) \
-    if constexpr (T == t) asm volatile("global_load_dwordx4 a[" #lo ":" #hi "], %0, off" ::"v"(p) : "memory", "a" #lo, "a" #hi);
+    if constexpr (T == t) asm volatile("global_load_dwordx4 a[" #lo ":" #hi "], %0, %1" ::"v"(byte_offset), "s"(base) : "memory", "a" #lo, "a" #hi);
             QT_PF_LIST(QT_PF_LOAD)
 #undef QT_PF_LOAD
         }
@@ -247,19 +248,19 @@ namespace lexls
             const int CH = (n + 1) * HP; // pieces per problem, level and row part
             static_assert(NH * NIH <= 18, "eighteen piece registers");
             // piece t = (row part t / NIH, instruction t % NIH) of the level whose first row is Frow -> its fixed registers
-            // byte-free offsets (doubles) of this lane's pieces inside a level, computed once (the division by HP is not repeated per request)
+            // byte offsets of this lane's pieces inside a level, computed once (the division by HP is not repeated per request)
             uint32_t pieceoff[NH * NIH];
             for_each_index<0, NH * NIH>([&](auto tt) __attribute__((always_inline)) {
                 constexpr int t = decltype(tt)::value, h = t / NIH, i = t % NIH;
                 int ch        = 16 * i + gl;
                 ch            = ch < CH ? ch : CH - 1; // lanes past the end repeat the last piece (same bytes to the same LDS address)
                 const int col = ch / HP, m = ch - col * HP;
-                pieceoff[t]   = poff + (uint32_t)(col * cap + h * RP + 2 * m);
+                pieceoff[t]   = 8u * (poff + (uint32_t)(col * cap + h * RP + 2 * m)); // bytes
             });
             auto prefetch_piece = [&](auto tt, int Frow) __attribute__((always_inline)) {
                 constexpr int t = decltype(tt)::value, i = t % NIH;
                 if (16 * i < CH) // wave-uniform
-                    qt_pf_load<t>(inw + (pieceoff[t] + (uint32_t)Frow));
+                    qt_pf_load<t>(inw + Frow, pieceoff[t]);
             };
 
             int rp[NS];         // slot s, lane l: LDS byte address of the (triangular) image row of pivot position c = 16 s + l - SIG
@@ -500,7 +501,7 @@ namespace lexls
 
                     int pf_issued = 0; // pieces of the next level requested so far (wave-uniform)
                     qt_for_each_while<0, MD>(
-                        [&](auto) __attribute__((always_inline)) { return __ballot(go) != 0ull; }, // no row of the wavefront has work left: ONE branch leaves the level
+                        [&](auto jc) __attribute__((always_inline)) { return (decltype(jc)::value % 4 != 0) || __ballot(go) != 0ull; }, // tested every fourth step: no row of the wavefront has work left -> ONE branch leaves the level
                         [&](auto cnt) __attribute__((always_inline)) {
                         constexpr int j   = decltype(cnt)::value;
                         constexpr int ce  = j & ~1;       // first (even) row of this step's hand-off
