@@ -28,6 +28,10 @@
 
 #include <cstdlib>
 
+#ifndef QT_WPB
+#define QT_WPB 4 // wavefronts per workgroup of lqr_qtol (1 or 4)
+#endif
+
 namespace lexls
 {
     namespace
@@ -159,7 +163,7 @@ namespace lexls
         /// NV: the number of variables when the instantiation serves ONE n (0: taken from the arguments) — the piece counts of the level loads and
         /// the layout tests then fold at compile time
         template <int NS, int MD, int SIG, int NV>
-        __global__ __launch_bounds__(64) void lqr_qtol_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes, uint32_t stagger)
+        __global__ __launch_bounds__(64 * QT_WPB) void lqr_qtol_kernel(LseArgs a, uint32_t img_doubles, uint32_t group_bytes, uint32_t stagger)
         {
             static_assert(NS >= 1 && NS <= 4 && MD <= 16 && (MD % 4) == 0, "shape limits of the row layout / two row parts of even size");
             constexpr int NH  = 2;        // row parts of the staging transposition
@@ -177,17 +181,20 @@ namespace lexls
             typedef __attribute__((address_space(3))) char lds_char;
             const int lds0 = (int)(unsigned)(size_t)(lds_char *)smem;
             const int lane = threadIdx.x & 63;
+            // QT_WPB wavefronts per workgroup (independent of each other; one per SIMD): a quarter of the workgroups to dispatch
+            const uint32_t wq = QT_WPB > 1 ? blockIdx.x * QT_WPB + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : blockIdx.x; // this wavefront's quad of problems (in scalar registers)
+            if (wq * 4u >= a.batch) return; // (a wavefront beyond the batch: nothing of it is waited for)
             const int g    = lane >> 4; // row = problem inside the wave
             const int gl   = lane & 15;
             const int n    = NV ? NV : (int)a.nVar;
             const int cap  = (int)a.cap;
             const int nObj = (int)a.nObj;
-            const uint32_t b  = blockIdx.x * 4u + (uint32_t)g;
+            const uint32_t b  = wq * 4u + (uint32_t)g;
             const uint32_t bb = b < a.batch ? b : a.batch - 1u; // rows beyond the batch idle on a valid address
             const bool live   = b < a.batch && !(a.skip && a.skip[bb]);
             const uint32_t pstride = (uint32_t)cap * (uint32_t)(n + 1);
-            const double *inw      = a.in + (size_t)blockIdx.x * 4u * pstride; // wave-uniform base; lane offsets stay 32-bit
-            const uint32_t poff    = (bb - blockIdx.x * 4u) * pstride;
+            const double *inw      = a.in + (size_t)wq * 4u * pstride; // wave-uniform base; lane offsets stay 32-bit
+            const uint32_t poff    = (bb - wq * 4u) * pstride;
 
             // ---- the first level's rows are requested before anything else (every wave of the chip asks for its first level at once: the HBM serves
             //      this burst at its full rate, and nothing can be computed before it lands).  Its position layout is the identity, so lane = column
@@ -210,7 +217,7 @@ namespace lexls
             }
 
             // ---- LDS carve-up of this row's slice (byte offsets; launch_qtol_t computes group_bytes) ----
-            const int o_img   = lds0 + g * (int)group_bytes;
+            const int o_img   = lds0 + (int)((QT_WPB > 1 ? (threadIdx.x >> 6) * 4u : 0u) + (uint32_t)g) * (int)group_bytes;
             const int o_xs    = o_img + 8 * (int)img_doubles; // 16*NS : x by position (zero until the back-substitution: also the "U" of a position that is no pivot yet)
             const int o_ex    = o_xs + 8 * 16 * NS;           // MD    : dump slots (one dword per lane) of byte stores that do not apply
             const int o_phys  = o_ex + 8 * MD;                // 64 B  : physical column at each position
@@ -850,17 +857,24 @@ namespace lexls
         {
             const uint32_t img  = qtol_image_doubles(a.nVar, a.nObj, MD);
             const size_t gbytes = qtol_group_bytes<NS, MD>(a.nVar, a.nObj);
-            const size_t lds    = 4 * gbytes;
+            const size_t lds    = 4 * QT_WPB * gbytes;
             if (lds > kMaxLdsBytes || a.nObj > (uint32_t)kQuadMaxObj || a.nVar + 1 + SIG > 16u * NS || a.nVar > 63u || (NV && a.nVar != (uint32_t)NV)) return hipErrorInvalidValue;
             if (a.uniform_dim != (uint32_t)MD || (a.cap & 1u) || (reinterpret_cast<uintptr_t>(a.in) & 15u) || a.nfixed || a.reg_type != 0) return hipErrorInvalidValue;
             if (lds > 64 * 1024)
             {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_qtol_kernel<NS, MD, SIG, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
+                static size_t granted[64] = {0}; // per device: the attribute is set once, not per launch
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+                if (dev < 0 || granted[dev] < lds)
+                {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_qtol_kernel<NS, MD, SIG, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) return e;
+                    if (dev >= 0) granted[dev] = lds;
+                }
             }
-            const uint32_t blocks = (a.batch + 3u) / 4u;
+            const uint32_t blocks = (a.batch + 4u * QT_WPB - 1u) / (4u * QT_WPB);
             static const uint32_t stagger = std::getenv("LEXLS_QTOL_STAGGER") ? (uint32_t)std::atoi(std::getenv("LEXLS_QTOL_STAGGER")) : 0u; // x 512 cycles per SIMD index
-            hipLaunchKernelGGL((lqr_qtol_kernel<NS, MD, SIG, NV>), dim3(blocks), dim3(64), lds, s, a, img, (uint32_t)gbytes, stagger);
+            hipLaunchKernelGGL((lqr_qtol_kernel<NS, MD, SIG, NV>), dim3(blocks), dim3(64 * QT_WPB), lds, s, a, img, (uint32_t)gbytes, stagger);
             return hipGetLastError();
         }
     } // namespace
@@ -868,4 +882,4 @@ namespace lexls
 
 #define LEXLS_QTOL_INSTANCE(NAME, NS, MD, SIG, NV) \
     namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_qtol_t<NS, MD, SIG, NV>(a, s); } \
-                      size_t NAME##_lds(uint32_t nVar, uint32_t nObj) { return 4 * qtol_group_bytes<NS, MD>(nVar, nObj); } }
+                      size_t NAME##_lds(uint32_t nVar, uint32_t nObj) { return 4 * QT_WPB * qtol_group_bytes<NS, MD>(nVar, nObj); } }
