@@ -38,13 +38,22 @@ namespace lexls
     size_t quad_lds_bytes(uint32_t slots, uint32_t md, uint32_t nVar, uint32_t nObj);
     hipError_t launch_qtol_3x12s7(const LseArgs &a, hipStream_t s);
     size_t launch_qtol_3x12s7_lds(uint32_t nVar, uint32_t nObj);
+    hipError_t launch_qtol_3x12(const LseArgs &a, hipStream_t s);
+    size_t launch_qtol_3x12_lds(uint32_t nVar, uint32_t nObj);
+    hipError_t launch_qtol_2x12(const LseArgs &a, hipStream_t s);
+    size_t launch_qtol_2x12_lds(uint32_t nVar, uint32_t nObj);
 
-    /// the tolerance-contract four-per-wavefront kernel (lqr_qtol_impl.h) serves: x-only solves of batches in which every level of every
-    /// problem has exactly 12 rows, n = 40 (the IK shape of BASELINE configs[2]/[3]), no fixed variables, no regularization
-    static bool qtol_serves(const LseArgs &a, bool write_factor, bool has_fixed)
+    /// which instantiation of the tolerance-contract four-per-wavefront kernel (lqr_qtol_impl.h) serves these arguments (0: none): x-only
+    /// solves of batches in which every level of every problem has exactly 12 rows, no fixed variables, no regularization, n + 1 <= 48 —
+    /// 1: n = 40, the IK shape of BASELINE configs[2]/[3] (n a compile-time constant, columns right-aligned in the slots); 2: other n with
+    /// 33 .. 48 columns; 3: up to 32 columns
+    static int qtol_choice(const LseArgs &a, bool write_factor, bool has_fixed)
     {
-        return !write_factor && !has_fixed && a.reg_type == 0 && a.uniform_dim == 12 && a.nVar == 40 && a.nObj <= 8 && (a.cap & 1u) == 0 &&
-               (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0 && !a.g_cdata && launch_qtol_3x12s7_lds(a.nVar, a.nObj) <= kMaxLdsBytes;
+        if (write_factor || has_fixed || a.reg_type != 0 || a.uniform_dim != 12 || a.nObj > 8 || (a.cap & 1u) != 0 || (reinterpret_cast<uintptr_t>(a.in) & 15u) != 0 || a.g_cdata) return 0;
+        if (a.nVar == 40) return launch_qtol_3x12s7_lds(a.nVar, a.nObj) <= kMaxLdsBytes ? 1 : 0;
+        if (a.nVar + 1 <= 32) return (a.nVar >= 2 && launch_qtol_2x12_lds(a.nVar, a.nObj) <= kMaxLdsBytes) ? 3 : 0;
+        if (a.nVar + 1 <= 48) return launch_qtol_3x12_lds(a.nVar, a.nObj) <= kMaxLdsBytes ? 2 : 0;
+        return 0;
     }
 
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed)
@@ -127,11 +136,14 @@ namespace lexls
                                const char **variant, bool allow_tolerance)
     {
         const uint32_t nc = a.nVar + 1;
-        if (allow_tolerance && qtol_serves(a, write_factor, has_fixed))
-        {
-            *variant = "lqr_qtol<3,12,shift 7>";
-            return launch_qtol_3x12s7(a, s);
-        }
+        if (allow_tolerance)
+            switch (qtol_choice(a, write_factor, has_fixed))
+            {
+            case 1: *variant = "lqr_qtol<3,12,shift 7>"; return launch_qtol_3x12s7(a, s);
+            case 2: *variant = "lqr_qtol<3,12>"; return launch_qtol_3x12(a, s);
+            case 3: *variant = "lqr_qtol<2,12>"; return launch_qtol_2x12(a, s);
+            default: break;
+            }
         if (a.reg_type != 0) // the regularization family: the register-resident kernel's REG instantiations (factor always kept)
         {
             if (max_level_dim <= 12 && nc <= 41)

@@ -12,17 +12,17 @@ N, DIMS = 40, [12] * 5
 TOL = 1e-10
 
 
-def solve(hip, lod, dims=DIMS, policy=6):
-    s = hip.BatchedLexLSE(lod.shape[0], N, dims)
+def solve(hip, lod, dims=DIMS, policy=6, n=N):
+    s = hip.BatchedLexLSE(lod.shape[0], n, dims)
     s.set_kernel_policy(policy)
     s.setProblem(lod)
     s.factorize_solve(keep_factor=False)
     return s
 
 
-def check(hip, oracle, lod, dims=DIMS, policy=6, expect="lqr_qtol<3,12,shift 7>"):
-    ref = oracle.lse_run(lod, dims, N, nthreads=8)
-    s = solve(hip, lod, dims, policy)
+def check(hip, oracle, lod, dims=DIMS, policy=6, expect="lqr_qtol<3,12,shift 7>", n=N):
+    ref = oracle.lse_run(lod, dims, n, nthreads=8)
+    s = solve(hip, lod, dims, policy, n)
     assert s.last_kernel() == expect
     r, fc, tr = s.getRanks()
     np.testing.assert_array_equal(r, ref["rank"])
@@ -53,6 +53,19 @@ def test_full_size_batch_4096_tolerance_contract(hip, oracle):
     assert e.last_kernel() == "lqr_quad<3,12,shift 7>"
     np.testing.assert_array_equal(e.get_column_permutations(), s.get_column_permutations())
     assert np.abs(e.get_x() - s.get_x()).max() <= TOL * max(1.0, float(np.abs(e.get_x()).max()))
+
+
+@pytest.mark.parametrize("n,nobj,expect", [(2, 1, "lqr_qtol<2,12>"), (7, 2, "lqr_qtol<2,12>"), (12, 1, "lqr_qtol<2,12>"), (24, 3, "lqr_qtol<2,12>"),
+                                            (31, 4, "lqr_qtol<2,12>"), (32, 3, "lqr_qtol<3,12>"), (36, 5, "lqr_qtol<3,12>"), (41, 4, "lqr_qtol<3,12>"),
+                                            (47, 4, "lqr_qtol<3,12>")])
+def test_other_numbers_of_variables(hip, oracle, n, nobj, expect):
+    """levels of 12 rows with n other than the IK shape's 40: the instantiations that read n from the arguments (identity position layout)"""
+    dims = [12] * nobj
+    for batch in (1, 6, 67):
+        check(hip, oracle, P.lse_batch(9000 + 10 * n + batch, batch, n, dims), dims, expect=expect, n=n)
+    ranks = [max(1, min(12, n - 12 * k) - 3) if k % 2 == 0 else 12 for k in range(nobj)]
+    lod = np.stack([P.rank_deficient_problem(9500 + n + b, n, dims, ranks) for b in range(13)])
+    check(hip, oracle, lod, dims, expect=expect, n=n)
 
 
 @pytest.mark.parametrize("ranks", [(9, 12, 7, 12, 12), (3, 3, 3, 3, 3), (12, 1, 12, 1, 12), (12, 12, 12, 2, 12), (1, 1, 1, 1, 1)])
