@@ -56,10 +56,11 @@ def test_full_size_batch_4096_tolerance_contract(hip, oracle):
 
 
 @pytest.mark.parametrize("n,nobj,expect", [(2, 1, "lqr_qtol<2,12>"), (7, 2, "lqr_qtol<2,12>"), (12, 1, "lqr_qtol<2,12>"), (24, 3, "lqr_qtol<2,12>"),
-                                            (31, 4, "lqr_qtol<2,12>"), (32, 3, "lqr_qtol<3,12>"), (36, 5, "lqr_qtol<3,12>"), (41, 4, "lqr_qtol<3,12>"),
-                                            (47, 4, "lqr_qtol<3,12>")])
+                                            (31, 4, "lqr_qtol<2,12>"), (32, 3, "lqr_qtol<3,12>"), (36, 5, "lqr_qtol<3,12>"), (39, 8, "lqr_qtol<3,12>"),
+                                            (41, 4, "lqr_quad<3,12>"), (47, 4, "lqr_quad<3,12>")])
 def test_other_numbers_of_variables(hip, oracle, n, nobj, expect):
-    """levels of 12 rows with n other than the IK shape's 40: the instantiations that read n from the arguments (identity position layout)"""
+    """levels of 12 rows with n other than the IK shape's 40: the instantiations that read n from the arguments (identity position layout).
+    Beyond n = 40 the four slices of four wavefronts no longer fit the 160 KB of a CU: those shapes stay on the bit-exact kernel"""
     dims = [12] * nobj
     for batch in (1, 6, 67):
         check(hip, oracle, P.lse_batch(9000 + 10 * n + batch, batch, n, dims), dims, expect=expect, n=n)
@@ -109,8 +110,9 @@ def test_fewer_and_more_levels(hip, oracle, nobj):
 
 
 def test_dispatch_rules(hip, oracle):
-    """automatic dispatch takes the tolerance kernel for x-only solves of the IK shape only; a kept factor, ragged levels, fixed variables,
-    another n or the bit-exact policies take the bit-exact kernels (whose x is identical to the oracle's, bit for bit)"""
+    """automatic dispatch takes the tolerance kernel for x-only solves of levels of exactly 12 rows that fit its LDS slices; a kept factor,
+    ragged levels, levels of another size, an n beyond the slices or the bit-exact policies take the bit-exact kernels (whose x is identical to
+    the oracle's, bit for bit)"""
     lod = P.lse_batch(31, 64, N, DIMS)
     ref = oracle.lse_run(lod, DIMS, N)
     s = solve(hip, lod, policy=0)
@@ -128,13 +130,13 @@ def test_dispatch_rules(hip, oracle):
     r.setProblem(lod)
     r.factorize_solve(keep_factor=False)
     assert not r.last_kernel().startswith("lqr_qtol")
-    n2 = 39
-    lod2 = P.lse_batch(32, 8, n2, DIMS)
-    o = hip.BatchedLexLSE(8, n2, DIMS)
-    o.setProblem(lod2)
-    o.factorize_solve(keep_factor=False)
-    assert not o.last_kernel().startswith("lqr_qtol")
-    np.testing.assert_array_equal(o.get_x(), oracle.lse_run(lod2, DIMS, n2)["x"])
+    for n2, dims2 in ((44, [12] * 5), (40, [8] * 5), (30, [16, 16])):
+        lod2 = P.lse_batch(32, 8, n2, dims2)
+        o = hip.BatchedLexLSE(8, n2, dims2)
+        o.setProblem(lod2)
+        o.factorize_solve(keep_factor=False)
+        assert not o.last_kernel().startswith("lqr_qtol")
+        np.testing.assert_array_equal(o.get_x(), oracle.lse_run(lod2, dims2, n2)["x"])
 
 
 def test_scaled_data(hip, oracle):
