@@ -17,6 +17,7 @@
 #include "lqr_wave_common.h"
 
 #include <cfloat>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -533,6 +534,12 @@ namespace lexls
             const int hi2 = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
             return v + __hiloint2double(hi2, lo2);
         }
+        __device__ __forceinline__ double wave_vmax(double x, double y)
+        {
+            double r;
+            asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+            return r;
+        }
         /// sum over the 64 lanes in a FIXED tree order (the same in every workgroup), wave-uniform result
         __device__ __forceinline__ double wave_sum(double v)
         {
@@ -861,9 +868,22 @@ namespace lexls
         // added to an agent-scope counter and polled it: 6.4 us per pivot, no faster than a launch per pivot).  What made the difference,
         // measured with the stamps below: (1) no counter — 129 atomic adds to one address serialise; (2) records 256 bytes apart — 129
         // workgroups polling 129 records that share sixteen lines made one memory channel the bottleneck (2.80 -> 2.49 ms); (3) four polls per
-        // lane in flight; (4) 4 columns per workgroup instead of 8 (the tile update is on the critical path).  Now 4.1 us per pivot:
-        // publish 0.7, record latency 1.8, winner's column 0.6, reflector + tile 1.1.  The tags restart with every level, so the records and
-        // the column granules are cleared in front of every launch.  Every spin is bounded: a workgroup that gives up raises `abort`, which
+        // lane in flight; (4) 4 columns per workgroup instead of 8 (the tile update is on the critical path).  Round 3 (3.5 -> 3.2 us per
+        // pivot, rocprofv3: 816 us per 256-pivot level): what the next record depends on no longer goes through LDS — every wavefront keeps the
+        // positions and down-dated norms of its own columns in registers, the wavefronts exchange their best through ONE 16-byte slot each and
+        // one barrier, and pick by a maximum tree + a minimum tree over packed {position, column} keys (the scan of the workgroup's columns by
+        // every thread cost 370 cycles per column, a compare-and-select chain 150 per wavefront); the owner of a candidate column ships its
+        // fresh / tail squared norms behind the column (two more granules), so the readers need no reduction of their own; a thread's
+        // column granule and the two sums are requested together (one wait); the reflector's scalars come from v_rsq_f64 / v_rcp_f64 +
+        // Newton steps instead of three division / square-root sequences.  Per pivot now (scripts/persist_stamps.py, shader cycles at
+        // ~2.3 GHz): records 2500 (1.2 polls of 129 records each), winner's column 1300, dot + scalars + pivot row 1400, exchange between the
+        // wavefronts + record 800; column update, publication and bookkeeping (1100) overlap the others' waiting.
+        // Tried and not kept as defaults (LEXLS_PERSIST_FORM="nw,cpw", LEXLS_LARGE_ONE_XCD=1): all workgroups on ONE XCD so that hand-offs stay in
+        // its L2 (a plain store + sc1 load round trip is 1040 cycles there against 1800 across XCDs, scripts/ubench/xcd_pingpong.hip; an
+        // all-to-all exchange of 32 workgroups 0.49 us against 1.0 us, scripts/ubench/xcd_exchange.hip) — but 129 workgroups then share 32 CUs,
+        // the slowest one is 1-2 polls late every pivot, and the level is slower (2.26-2.6 ms against 2.16); 8 or 16 wavefronts per workgroup
+        // (fewer records to poll, longer barriers: equal or slower); 2 or 4 columns per wavefront (+350 cycles per column on the chain).
+        // The tags restart with every level, so the records and the column granules are cleared in front of every launch.  Every spin is bounded: a workgroup that gives up raises `abort`, which
         // every spin watches — the launch then ends WITHOUT committing anything and the host redoes the level with a launch per pivot.
         // -----------------------------------------------------------------------------------------------------------------
         struct PersistCtl
@@ -885,69 +905,123 @@ namespace lexls
         {
             return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
-#ifndef LEXLS_PERSIST_PTC
-#define LEXLS_PERSIST_PTC 4
-#endif
-        constexpr int PTC = LEXLS_PERSIST_PTC; // columns per workgroup: one per wavefront
-        static_assert(PTC == 4, "fast_level_persist: one column per wavefront");
+        constexpr int PTC_MIN = 4; // fewest columns per workgroup (= wavefronts per workgroup) of the forms below: sizes the workspace
 #ifndef LEXLS_PERSIST_RSTRIDE
 #define LEXLS_PERSIST_RSTRIDE 16
 #endif
         constexpr size_t PRS = LEXLS_PERSIST_RSTRIDE; // a workgroup's record sits PRS x 16 bytes from its neighbour's: G workgroups poll all G records
                                                       // at once, and records in one line would make that line's memory channel the bottleneck
-        /// 16-byte accesses with agent scope (sc0 sc1): a record {norm, pos, tag | column} travels as ONE store and is read as ONE load
-        /// (observed untorn on gfx950, MI355X_MICROARCH.md "R2's granule"); payload columns go two doubles per lane
+        /// 16-byte hand-off accesses: a record {norm, pos, tag | column} travels as ONE store and is read as ONE load (observed untorn on gfx950,
+        /// MI355X_MICROARCH.md "R2's granule"); payload columns go one {value, tag} per lane.
+        /// L2LOCAL = false: writers and readers on any XCD — system-scope store and load (sc0 sc1), served by memory.
+        /// L2LOCAL = true: ALL workgroups of the launch sit on ONE XCD and share its L2 — a plain store leaves the line in that L2 and an
+        /// agent-scope (sc1) load, which misses the CU's vector cache, is served by it: 0.49 us per all-to-all exchange of 32 workgroups
+        /// against 1.0 us across XCDs (scripts/ubench/xcd_exchange.hip; sc0 / unscoped loads never see the store: they hit the vector cache)
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        __device__ __forceinline__ void st16_sc1(void *p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-        __device__ __forceinline__ u32x4 ld16_sc1(const void *p)
+        template <bool L2LOCAL> __device__ __forceinline__ void st16_x(void *p, u32x4 v)
+        {
+#ifndef LEXLS_ONEXCD_STORE
+#define LEXLS_ONEXCD_STORE 0
+#endif
+            if (L2LOCAL)
+            {
+                if (LEXLS_ONEXCD_STORE == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+                if (LEXLS_ONEXCD_STORE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+                if (LEXLS_ONEXCD_STORE == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+                if (LEXLS_ONEXCD_STORE == 3) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" ::"v"(p), "v"(v) : "memory");
+                if (LEXLS_ONEXCD_STORE == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+                if (LEXLS_ONEXCD_STORE == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+            }
+            else
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        }
+        template <bool L2LOCAL> __device__ __forceinline__ void ld16_issue(u32x4 &v, const void *p)
+        {
+            if (L2LOCAL)
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+            else
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory");
+        }
+        template <bool L2LOCAL> __device__ __forceinline__ u32x4 ld16_x(const void *p)
         {
             u32x4 v;
-            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+            ld16_issue<L2LOCAL>(v, p);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");
             return v;
         }
-
-        __global__ __launch_bounds__(256) void fast_level_persist(LseArgs a, FastBuffers fb, PersistCtl *ctl, PersistCand *cand, double *colbuf, uint32_t colld,
-                                                                  uint32_t cur, uint32_t pp, uint32_t level, uint32_t G)
+        __device__ __forceinline__ unsigned persist_xcc_id()
         {
+            unsigned v;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+            return v & 15u;
+        }
+
+        /// NW: wavefronts per workgroup = columns per workgroup (one each).  ONEXCD: the launch is nx times as large as the G workgroups it
+        /// needs (nx = XCDs of the device; workgroups go to the XCDs round robin); the workgroups that find themselves on XCD 0 claim the tile
+        /// indices in arrival order, all others leave at once — so every hand-off stays inside one L2 (see st16_x)
+        template <int NW, int CPW, bool ONEXCD>
+        __global__ __launch_bounds__(64 * NW) void fast_level_persist(LseArgs a, FastBuffers fb, PersistCtl *ctl, PersistCand *cand, double *colbuf, uint32_t colld,
+                                                                      uint32_t cur, uint32_t pp, uint32_t level, uint32_t G)
+        {
+            constexpr int PTC      = NW * CPW; // columns per workgroup, CPW per wavefront
+            constexpr uint32_t NT  = 64u * NW;
+            // records of neighbouring workgroups: PRS x 16 bytes apart when they are polled through memory (a line shared by sixteen records made its
+            // channel the bottleneck), side by side inside ONE L2 — there the G x G record reads of a poll are what costs, and a wavefront's
+            // load of 64 consecutive records is 8 lines instead of 64
+            constexpr size_t RS = ONEXCD ? 1 : PRS;
             extern __shared__ double smem[];
-            __shared__ double sums[8];
+            __shared__ u32x4 slot[NW]; // the wavefronts' own candidates of the next pivot: {norm, position, column}
             __shared__ uint32_t flag;
-            __shared__ uint32_t win_p, win_i, win_w, colbad;
-            const uint32_t b = 0, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, t = blockIdx.x;
+            __shared__ uint32_t win_p, win_i, win_w, colbad, claimed;
+            const uint32_t b = 0, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
             const LargeState s = fb.st[pp][b];
             const uint32_t n = a.nVar, cap = a.cap;
             if (s.exhausted || s.dim == 0) return; // the same in every workgroup: nobody waits for anybody
             if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (raised before the launch: the tests' way into the fallback)
+            uint32_t t = blockIdx.x;
+            if (ONEXCD)
+            {
+                if (persist_xcc_id() != 0u) return;
+                if (tid == 0) claimed = atomicAdd(&ctl->arrive, 1u);
+                __syncthreads();
+                t = claimed;
+                if (t >= G) return;
+            }
             const uint32_t dim = s.dim, F = s.F;
             double *W          = fb.W[cur] + (size_t)b * cap * (n + 1);
             const uint32_t ldt = dim | 1u;
             double *tile   = smem;                      // PTC x ldt
             double *cv0    = tile + (size_t)PTC * ldt;  // 2 x dim: the pivot column, by pivot parity (the previous pivot's essential part leaves one step late)
-            double *nrm    = cv0 + 2 * dim;             // PTC: down-dated norms of the own columns
-            uint32_t *posm = reinterpret_cast<uint32_t *>(nrm + PTC); // n + 1: position of every physical column (kept by every workgroup)
-            uint32_t *invm = posm + (n + 1);                          // n + 1: physical column at every position
+            uint32_t *posm = reinterpret_cast<uint32_t *>(cv0 + 2 * dim); // n + 1: position of every physical column (kept by every workgroup)
+            uint32_t *invm = posm + (n + 1);                              // n + 1: physical column at every position
 
-            for (uint32_t e = tid; e < (uint32_t)PTC * dim; e += 256)
+            for (uint32_t e = tid; e < (uint32_t)PTC * dim; e += NT)
             {
                 const uint32_t jj = e / dim, i = e - jj * dim, j = t * PTC + jj;
                 tile[jj * ldt + i] = (j <= n) ? W[F + i + (size_t)j * cap] : 0.0;
             }
-            for (uint32_t j = tid; j <= n; j += 256)
+            for (uint32_t j = tid; j <= n; j += NT)
             {
                 posm[j] = j;
                 invm[j] = j;
             }
             if (tid == 0) colbad = 0u;
-            if (tid < (uint32_t)PTC)
+            // The wavefront's own columns: physical index, position and down-dated norm live in (wave-uniform) registers — what the next pivot's
+            // record depends on never goes through LDS except for the one exchange between the wavefronts of the workgroup (slot[])
+            uint32_t jq[CPW], mypos[CPW];
+            double mynrm[CPW];
+#pragma unroll
+            for (int q = 0; q < CPW; q++)
             {
-                const uint32_t j = t * PTC + tid;
-                nrm[tid]         = (j < n) ? fb.norms[pp][(size_t)b * n + j] : -1.0;
+                jq[q]    = t * PTC + wave * CPW + q;
+                mypos[q] = jq[q];
+                mynrm[q] = (jq[q] < n) ? fb.norms[pp][(size_t)b * n + jq[q]] : -1.0;
             }
             __syncthreads();
 
             uint32_t c = s.ColIndex, rank = 0, stop = 0, exhausted = 0;
 #ifdef LEXLS_PERSIST_STAMPS
-            long long pst[6] = {0, 0, 0, 0, 0, 0}, pt0 = clock64();
+            long long pst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = clock64();
 #define PSTAMP(i) { const long long t_ = clock64(); pst[i] += t_ - pt0; pt0 = t_; }
 #else
 #define PSTAMP(i)
@@ -957,12 +1031,12 @@ namespace lexls
             // the last to publish — and everybody waits for the last.  The essential part is formed then, from the kept pivot column.
             bool pend = false, pend_degenerate = false;
             uint32_t pend_counter = 0, pend_c = 0, pend_ppos = 0, pend_R = 0;
-            double pend_diag = 0.0, pend_tau = 0.0, pend_den = 1.0;
+            double pend_diag = 0.0, pend_tau = 0.0, pend_iden = 1.0;
             auto flush_pending = [&]() {
                 if (!pend) return;
                 const double *cvp = cv0 + (size_t)(pend_counter & 1u) * dim;
                 double *E         = fb.E + ((size_t)b * fb.eld + pend_counter) * fb.eld;
-                for (uint32_t i = 1 + tid; i < pend_R; i += 256) E[i] = pend_degenerate ? 0.0 : cvp[i] / pend_den;
+                for (uint32_t i = 1 + tid; i < pend_R; i += NT) E[i] = pend_degenerate ? 0.0 : cvp[i] * pend_iden;
                 if (tid == 0)
                 {
                     fb.D[(size_t)b * n + pend_c]   = pend_diag;
@@ -971,51 +1045,90 @@ namespace lexls
                 }
                 pend = false;
             };
-            // Own candidate of pivot `cnt` (first maximum by position among the own live columns; every thread for itself: norms and positions
-            // are behind a barrier) and its RECORD — published as early as the norms allow, before the tile update of the previous pivot has
-            // finished: the others wait for records, the candidate's column follows (publish_column) and is only read by those who need it.
-            // Every 16-byte store carries the pivot's tag: nothing is drained and nothing is ordered — a reader takes a granule when its tag
-            // matches.
+            // Own candidate of pivot `cnt` (first maximum by position among the workgroup's live columns) and its RECORD — published as early as
+            // the norms allow, before the tile update of the previous pivot has finished: the others wait for records, the candidate's column
+            // follows (publish_column) and is only read by those who need it.  Every 16-byte store carries the pivot's tag: nothing is drained and
+            // nothing is ordered — a reader takes a granule when its tag matches.  The wavefronts exchange their own best through slot[] (one
+            // barrier); a scan of the workgroup's columns through LDS by every thread cost 370 cycles per column on this critical path.
             uint32_t cand_p = 0xffffffffu, cand_j = 0;
             auto publish_record = [&](uint32_t cnt, uint32_t cfirst) {
-                double myv   = -1.0;
-                uint32_t myp = 0xffffffffu, myj = 0;
+                // a candidate = {squared norm, key}, key = position << 8 | column inside the workgroup (positions are distinct: the smallest key is
+                // the smallest position), 0xffffffff = none; "first maximum by position" = largest norm, then smallest key — as a maximum
+                // tree and a minimum tree (a compare-and-select chain over the wavefronts cost ~150 cycles per wavefront)
+                double wv   = -1.0; // (norms are >= 0: -1 = no candidate)
+                uint32_t wk = 0xffffffffu;
 #pragma unroll
-                for (int jj = 0; jj < PTC; jj++)
+                for (int q = 0; q < CPW; q++)
                 {
-                    const uint32_t j = t * PTC + jj;
-                    if (j < n)
-                    {
-                        const uint32_t pj = posm[j];
-                        const double vj   = nrm[jj];
-                        if (pj >= cfirst && (vj > myv || (vj == myv && pj < myp)))
-                        {
-                            myv = vj;
-                            myp = pj;
-                            myj = j;
-                        }
-                    }
+                    const uint32_t kq = (mypos[q] << 8) | (uint32_t)(wave * CPW + q);
+                    const bool gt = (jq[q] < n) & (mypos[q] >= cfirst) & ((mynrm[q] > wv) | ((mynrm[q] == wv) & (kq < wk))); // (no short-circuit branches)
+                    wv = gt ? mynrm[q] : wv, wk = gt ? kq : wk;
                 }
+                if (lane == 0)
+                {
+                    u32x4 sq;
+                    sq.x = (unsigned)__double2loint(wv), sq.y = (unsigned)__double2hiint(wv), sq.z = wk, sq.w = 0u;
+                    slot[wave] = sq;
+                }
+                __syncthreads(); // C: the wavefronts' candidates (and the maps of this pivot) are in place
+                PSTAMP(8)
+                u32x4 sv[NW];
+                double vv[NW];
+#pragma unroll
+                for (int w2 = 0; w2 < NW; w2++) sv[w2] = slot[w2];
+#pragma unroll
+                for (int w2 = 0; w2 < NW; w2++) vv[w2] = __hiloint2double((int)sv[w2].y, (int)sv[w2].x);
+                double mx[NW];
+#pragma unroll
+                for (int w2 = 0; w2 < NW; w2++) mx[w2] = vv[w2];
+#pragma unroll
+                for (int h = NW / 2; h >= 1; h /= 2)
+#pragma unroll
+                    for (int w2 = 0; w2 < h; w2++) mx[w2] = wave_vmax(mx[2 * w2], mx[2 * w2 + 1]);
+                const double myv = mx[0];
+                uint32_t kk[NW];
+#pragma unroll
+                for (int w2 = 0; w2 < NW; w2++) kk[w2] = vv[w2] == myv ? sv[w2].z : 0xffffffffu;
+#pragma unroll
+                for (int h = NW / 2; h >= 1; h /= 2)
+#pragma unroll
+                    for (int w2 = 0; w2 < h; w2++) kk[w2] = kk[2 * w2] < kk[2 * w2 + 1] ? kk[2 * w2] : kk[2 * w2 + 1];
+                const uint32_t myk = kk[0];
+                const uint32_t myp = myk == 0xffffffffu ? 0xffffffffu : (myk >> 8), myj = t * PTC + (myk & 255u);
                 cand_p = myp, cand_j = myj;
                 if (tid == 0)
                 {
                     u32x4 q;
-                    q.x = (unsigned)__double2loint(myv), q.y = (unsigned)__double2hiint(myv), q.z = myp, q.w = ((cnt + 1u) << 8) | ((myj - t * PTC) & 255u); // (no candidate: pos says so, the index is not looked at)
-                    st16_sc1(cand + ((size_t)(cnt & 1u) * G + t) * PRS, q);
+                    q.x = (unsigned)__double2loint(myv), q.y = (unsigned)__double2hiint(myv), q.z = myp, q.w = ((cnt + 1u) << 8) | (myk & 255u); // (no candidate: pos says so, the index is not looked at)
+                    st16_x<ONEXCD>(cand + ((size_t)(cnt & 1u) * G + t) * RS, q);
                 }
             };
-            // the candidate's remaining rows, by the wavefront that owns (and has just updated) the column
+            // the candidate's remaining rows, by the wavefront that owns (and has just updated) the column — and, behind them, the column's
+            // fresh squared norm and the squared norm of its tail (rows 1..): every reader needs both for the reflector, the owner forms
+            // them while nobody waits for it
             auto publish_column = [&](uint32_t cnt) {
-                if (cand_p == 0xffffffffu || cand_j - t * PTC != wave) return;
+                if (cand_p == 0xffffffffu || (cand_j - t * PTC) / CPW != wave) return;
                 const uint32_t Rn  = dim - cnt;
                 u32x4 *mycol       = reinterpret_cast<u32x4 *>(colbuf) + ((size_t)(cnt & 1u) * G + t) * colld;
                 const double *srcc = tile + (cand_j - t * PTC) * ldt + cnt;
+                double fr = 0.0, tl = 0.0;
                 for (uint32_t i = lane; i < Rn; i += 64)
                 {
                     const double v0 = srcc[i];
                     u32x4 q;
                     q.x = (unsigned)__double2loint(v0), q.y = (unsigned)__double2hiint(v0), q.z = cnt + 1u, q.w = 0u;
-                    st16_sc1(mycol + i, q);
+                    st16_x<ONEXCD>(mycol + i, q);
+                    fr = dfma(v0, v0, fr);
+                    if (i > 0) tl = dfma(v0, v0, tl);
+                }
+                fr = wave_sum(fr);
+                tl = wave_sum(tl);
+                if (lane < 2)
+                {
+                    const double v0 = lane == 0 ? fr : tl;
+                    u32x4 q;
+                    q.x = (unsigned)__double2loint(v0), q.y = (unsigned)__double2hiint(v0), q.z = cnt + 1u, q.w = 0u;
+                    st16_x<ONEXCD>(mycol + Rn + lane, q);
                 }
             };
             publish_record(0, c);
@@ -1026,13 +1139,14 @@ namespace lexls
                 double *colv     = cv0 + (size_t)par * dim;
                 const uint32_t tag = counter + 1u;
                 flush_pending(); // (the previous pivot's bookkeeping, if it was this workgroup's turn: nobody waits for these stores)
+                const uint32_t front = invm[c]; // the column at the pivot's position (written before the last barrier C)
                 PSTAMP(0)
                 // ---- wait for the G records of this pivot and pick the winner: wave 0, lane = workgroup (no counter: a record IS its flag) ----
                 if (wave == 0)
                 {
                     // every lane keeps up to four records (G <= 256) in flight per poll: ONE round trip per poll, not one per record
-                    const PersistCand *base = cand + (size_t)par * G * PRS;
-                    u32x4 q[4];
+                    const PersistCand *base = cand + (size_t)par * G * RS;
+                    u32x4 q[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
                     uint32_t ok = 0;
                     for (uint32_t spin = 0; spin < (1u << 18); spin++)
                     {
@@ -1040,12 +1154,16 @@ namespace lexls
                         for (int kq = 0; kq < 4; kq++)
                         {
                             const uint32_t w = lane + 64u * kq;
-                            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(q[kq]) : "v"(base + (size_t)(w < G ? w : 0) * PRS) : "memory");
+                            if (kq == 0 || 64u * kq < G) // (wave-uniform)
+                                ld16_issue<ONEXCD>(q[kq], base + (size_t)(w < G ? w : 0) * RS);
                         }
                         asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3])::"memory");
                         bool mine = true;
 #pragma unroll
                         for (int kq = 0; kq < 4; kq++) mine = mine && (lane + 64u * kq >= G || (q[kq].w >> 8) == tag);
+#ifdef LEXLS_PERSIST_STAMPS
+                        pst[2] += 1; // polls
+#endif
                         if (__ballot(!mine) == 0ull)
                         {
                             ok = 1;
@@ -1099,18 +1217,64 @@ namespace lexls
                 if (!flag) return; // (uniform per workgroup; the others see `abort`)
                 const uint32_t ppos = win_p, piv = win_i, wwin = win_w;
                 PSTAMP(1)
-                PSTAMP(2)
 
-                // ---- the pivot column (published by its owner): kept in LDS, partial sums of its fresh / tail norms on the way ----
+                // ---- the pivot column (published by its owner) into LDS; every thread also takes the two sums behind it ----
                 const u32x4 *pcol = reinterpret_cast<const u32x4 *>(colbuf) + ((size_t)par * G + wwin) * colld;
-                double fr = 0.0, tl = 0.0;
-                for (uint32_t i = tid; i < R; i += 256)
+                // this thread's rows of the column and the two sums behind it: all requests in flight together, ONE wait; a granule whose tag
+                // does not match yet is asked for again (the record may overtake its column)
+                constexpr uint32_t CR = 1; // rows per thread in the batch (levels of more than 64 NW rows: the rest one by one, below)
+                double fresh = 0.0, tailSq = 0.0;
+                {
+                    u32x4 g[CR + 2];
+                    uint32_t good = 0;
+                    for (uint32_t spin = 0; spin < (1u << 18); spin++)
+                    {
+#pragma unroll
+                        for (uint32_t r = 0; r < CR; r++)
+                        {
+                            const uint32_t i = tid + r * NT;
+                            ld16_issue<ONEXCD>(g[r], pcol + (i < R ? i : R));
+                        }
+                        ld16_issue<ONEXCD>(g[CR], pcol + R);
+                        ld16_issue<ONEXCD>(g[CR + 1], pcol + R + 1u);
+                        bool all = true;
+#pragma unroll
+                        for (uint32_t r = 0; r < CR + 2; r++)
+                        {
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[r])::"memory");
+                            all = all & (g[r].z == tag);
+                        }
+#ifdef LEXLS_PERSIST_STAMPS
+                        pst[11] += 1; // column read rounds
+#endif
+                        if (all)
+                        {
+                            good = 1;
+                            break;
+                        }
+                        if ((spin & 255u) == 255u && __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    }
+                    if (!good)
+                    {
+                        __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        colbad = 1u;
+                    }
+#pragma unroll
+                    for (uint32_t r = 0; r < CR; r++)
+                    {
+                        const uint32_t i = tid + r * NT;
+                        if (i < R) colv[i] = __hiloint2double((int)g[r].y, (int)g[r].x);
+                    }
+                    fresh  = __hiloint2double((int)g[CR].y, (int)g[CR].x);
+                    tailSq = __hiloint2double((int)g[CR + 1].y, (int)g[CR + 1].x);
+                }
+                for (uint32_t i = tid + CR * NT; i < R; i += NT)
                 {
                     u32x4 q;
                     uint32_t good = 0;
-                    for (uint32_t spin = 0; spin < (1u << 18); spin++) // (the record may overtake its column: a granule is taken when its tag matches)
+                    for (uint32_t spin = 0; spin < (1u << 18); spin++)
                     {
-                        q = ld16_sc1(pcol + i);
+                        q = ld16_x<ONEXCD>(pcol + i);
                         if (q.z == tag)
                         {
                             good = 1;
@@ -1123,58 +1287,73 @@ namespace lexls
                         __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         colbad = 1u;
                     }
-                    const double w0 = __hiloint2double((int)q.y, (int)q.x);
-                    colv[i]         = w0;
-                    fr              = dfma(w0, w0, fr);
-                    if (i > 0) tl = dfma(w0, w0, tl);
-                }
-                fr = wave_sum(fr);
-                tl = wave_sum(tl);
-                if (lane == 0)
-                {
-                    sums[wave]     = fr;
-                    sums[4 + wave] = tl;
+                    colv[i] = __hiloint2double((int)q.y, (int)q.x);
                 }
                 __syncthreads(); // B
                 PSTAMP(3)
                 if (colbad) return; // (a column granule timed out in this workgroup; `abort` is raised, the others see it in their spins)
 
-                // ---- own tile, first half: the dot product of the wave's column with the RAW pivot column — it does not wait for the
-                //      reflector's scalars (sqrt, two divisions), it runs beside them.  (This path's contract is exact pivots and values
-                //      within 1e-10: es^T a = (v^T a) / den is the same number up to rounding.) ----
-                const uint32_t jj = wave, j = t * PTC + jj; // PTC == 4: one column per wavefront
-                double *col        = tile + jj * ldt + counter;
+                // ---- own tile, first half: the dot product of the wave's columns with the RAW pivot column — it does not wait for the
+                //      reflector's scalars, it runs beside them.  (This path's contract is exact pivots and values within 1e-10:
+                //      es^T a = (v^T a) / den is the same number up to rounding.) ----
                 // the column swap of this pivot (below) gives `piv` position c and the column that was there position ppos: trailing afterwards
-                // is "not the pivot and not finished before" — read off the map as it was (tid 0 rewrites two entries meanwhile: both stay >= c)
-                const bool trailing = j <= n && ((j == n) || (j != piv && posm[j] >= c));
-                double part         = 0.0;
-                if (trailing)
-                    for (uint32_t i = 1 + lane; i < R; i += 64) part = dfma(colv[i], col[i], part);
-                const double dotraw = wave_sum(part);
+                // is "not the pivot and not finished before"
+                double *col[CPW];
+                bool trailing[CPW];
+                double part[CPW], dotraw[CPW], a0[CPW];
+#pragma unroll
+                for (int q = 0; q < CPW; q++)
+                {
+                    col[q]      = tile + (wave * CPW + q) * ldt + counter;
+                    trailing[q] = jq[q] == n || (jq[q] < n && jq[q] != piv && mypos[q] >= c);
+                    part[q]     = 0.0;
+                    a0[q]       = col[q][0];
+                }
+                for (uint32_t i = 1 + lane; i < R; i += 64)
+                {
+                    const double cvi = colv[i];
+#pragma unroll
+                    for (int q = 0; q < CPW; q++) part[q] = dfma(cvi, col[q][i], part[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < CPW; q++) dotraw[q] = wave_sum(part[q]); // (columns that are not trailing: the value is not used)
+                PSTAMP(5)
 
-                const double fresh  = (sums[0] + sums[1]) + (sums[2] + sums[3]);
-                const double tailSq = (sums[4] + sums[5]) + (sums[6] + sums[7]);
                 if (fresh < a.tol) // rank test (lexlse.h:214): the level ends here, in every workgroup
                 {
                     stop = 1;
                     break;
                 }
                 const double c0v = colv[0];
-                double tau = 0.0, diag = c0v, den = 1.0;
+                // The reflector's scalars WITHOUT the division / square-root sequences (three of them, ~400 cycles each, sat on every pivot's
+                // critical path): |beta| = sqrt(nn) and 1 / |beta| from v_rsq_f64 + two coupled Newton steps, 1 / den from v_rcp_f64 + two
+                // steps — within an ulp or two of the correctly rounded values, which this path's contract (values within 1e-10) allows
+                double tau = 0.0, diag = c0v, iden = 1.0;
                 bool degenerate = true;
                 if (R > 1 && !(tailSq <= DBL_MIN))
                 {
-                    degenerate  = false;
-                    double beta = sqrt(dfma(c0v, c0v, tailSq));
-                    if (c0v >= 0.0) beta = -beta;
-                    diag = beta;
-                    den  = c0v - beta;
-                    tau  = (beta - c0v) / beta;
+                    degenerate      = false;
+                    const double nn = dfma(c0v, c0v, tailSq);
+                    double y        = __builtin_amdgcn_rsq(nn);
+                    double g = nn * y, h = 0.5 * y;
+                    double r = dfma(-h, g, 0.5);
+                    g        = dfma(g, r, g);
+                    h        = dfma(h, r, h);
+                    r        = dfma(-h, g, 0.5);
+                    h        = dfma(h, r, h);
+                    g        = dfma(dfma(-g, g, nn), h, g); // |beta|;  2 h = 1 / |beta|
+                    const double beta = c0v >= 0.0 ? -g : g;
+                    diag              = beta;
+                    tau               = dfma(fabs(c0v), 2.0 * h, 1.0); // (beta - c0v) / beta
+                    const double den  = c0v - beta;
+                    double ri         = __builtin_amdgcn_rcp(den);
+                    ri                = dfma(dfma(-den, ri, 1.0), ri, ri);
+                    iden              = dfma(dfma(-den, ri, 1.0), ri, ri);
                 }
-                // the swap of lexlse.h:222-232 on both maps (every workgroup keeps them)
+                PSTAMP(6)
+                // the swap of lexlse.h:222-232 on both maps (every workgroup keeps them; the wavefronts keep their own columns' positions)
                 if (tid == 0)
                 {
-                    const uint32_t front = invm[c];
                     posm[piv]   = c;
                     invm[c]     = piv;
                     if (front != piv)
@@ -1184,36 +1363,55 @@ namespace lexls
                     }
                 }
                 // ---- own tile, second half: the new pivot-row entry and the down-dated norm first — they decide the NEXT pivot's record ----
-                double a0n = 0.0, sc = 0.0;
-                const bool upd = trailing && tau != 0.0;
-                if (trailing)
+                double sc[CPW];
+                bool upd[CPW];
+#pragma unroll
+                for (int q = 0; q < CPW; q++)
                 {
-                    const double a0 = col[0];
-                    a0n             = a0;
-                    if (tau != 0.0)
+                    upd[q] = trailing[q] && tau != 0.0;
+                    sc[q]  = 0.0;
+                    if (trailing[q])
                     {
-                        const double tmp = dotraw / den + a0;
-                        a0n              = dfma(-tau, tmp, a0);
-                        sc               = (-tau * tmp) / den;
-                        if (lane == 0) col[0] = a0n;
+                        double a0n = a0[q];
+                        if (tau != 0.0)
+                        {
+                            const double tmp = dfma(dotraw[q], iden, a0[q]);
+                            a0n              = dfma(-tau, tmp, a0[q]);
+                            sc[q]            = (-tau * tmp) * iden;
+                            if (lane == 0) col[q][0] = a0n;
+                        }
+                        if (jq[q] < n) mynrm[q] = dfma(-a0n, a0n, mynrm[q]);
                     }
-                    if (lane == 0 && j < n) nrm[jj] = dfma(-a0n, a0n, nrm[jj]);
+                    if (jq[q] == piv)
+                        mypos[q] = c;
+                    else if (jq[q] == front)
+                        mypos[q] = ppos;
                 }
                 if (t == counter % G)
                 {
                     pend         = true;
                     pend_counter = counter, pend_c = c, pend_ppos = ppos, pend_R = R;
-                    pend_diag = diag, pend_tau = tau, pend_den = den;
+                    pend_diag = diag, pend_tau = tau, pend_iden = iden;
                     pend_degenerate = degenerate;
                 }
                 c++;
                 rank++;
-                __syncthreads(); // C: norms and maps of this pivot are in place
+                PSTAMP(7)
                 const bool last = c == n || counter + 1 == dim;
-                if (!last) publish_record(counter + 1, c);
-                // ---- the rest of the column, then (if it is the candidate) its rows for the others ----
-                if (upd)
-                    for (uint32_t i = 1 + lane; i < R; i += 64) col[i] = dfma(sc, colv[i], col[i]);
+                if (!last)
+                    publish_record(counter + 1, c);
+                else
+                    __syncthreads(); // (the barrier of publish_record: the maps are complete before they are written back)
+                PSTAMP(9)
+                // ---- the rest of the columns, then (if one of them is the candidate) its rows for the others ----
+                for (uint32_t i = 1 + lane; i < R; i += 64)
+                {
+                    const double cvi = colv[i];
+#pragma unroll
+                    for (int q = 0; q < CPW; q++)
+                        if (upd[q]) col[q][i] = dfma(sc[q], cvi, col[q][i]);
+                }
+                PSTAMP(10)
                 if (!last) publish_column(counter + 1);
                 PSTAMP(4)
                 if (c == n)
@@ -1224,7 +1422,14 @@ namespace lexls
             }
 #ifdef LEXLS_PERSIST_STAMPS
             if (t == 1 && tid == 0)
-                for (int i_ = 0; i_ < 5; i_++) a.lambda[8 * level + i_] = (double)pst[i_];
+                for (int i_ = 0; i_ < 12; i_++) a.lambda[16 * level + i_] = (double)pst[i_];
+            if (tid == 0 && level == 0 && 64u + 2u * G < a.cap) // where the workgroups ran and how long each waited for the records
+            {
+                unsigned hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                a.lambda[64 + 2 * t]     = (double)hw;
+                a.lambda[64 + 2 * t + 1] = (double)pst[1];
+            }
 #endif
             // ---- back to memory: the tile, the position map, the state — unless some workgroup gave up (then nobody commits: a workgroup that
             //      timed out did so long before any other could finish the level, every later hand-off needs its record) ----
@@ -1233,7 +1438,7 @@ namespace lexls
             __syncthreads();
             if (!flag) return;
             flush_pending();
-            for (uint32_t e = tid; e < (uint32_t)PTC * dim; e += 256)
+            for (uint32_t e = tid; e < (uint32_t)PTC * dim; e += NT)
             {
                 const uint32_t jj = e / dim, i = e - jj * dim, j = t * PTC + jj;
                 if (j <= n) W[F + i + (size_t)j * cap] = tile[jj * ldt + i];
@@ -1241,7 +1446,7 @@ namespace lexls
             if (t == 0)
             {
                 uint32_t *pos_out = fb.pos[pp ^ 1u] + (size_t)b * (n + 1);
-                for (uint32_t j = tid; j <= n; j += 256) pos_out[j] = posm[j];
+                for (uint32_t j = tid; j <= n; j += NT) pos_out[j] = posm[j];
                 if (tid == 0)
                 {
                     LargeState so   = s;
@@ -1476,12 +1681,122 @@ namespace lexls
         hipLaunchKernelGGL(large_finish, dim3((B + 63) / 64), dim3(64), 0, s, a, st);
         return hipGetLastError();
     }
+    namespace
+    {
+        __global__ __launch_bounds__(64) void persist_probe_xcc(uint32_t *out)
+        {
+            if (threadIdx.x == 0) out[blockIdx.x] = persist_xcc_id();
+        }
+        /// XCDs of the current device if its dispatcher places workgroup i on XCD i mod nx (MI355X: 8), else 0; probed once per device
+        int persist_xcds()
+        {
+            static int cached[64];
+            static bool known[64] = {false};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+            if (known[dev]) return cached[dev];
+            int nx = 0;
+            uint32_t *d = nullptr, h[128];
+            if (hipMalloc(&d, sizeof(h)) == hipSuccess)
+            {
+                hipLaunchKernelGGL(persist_probe_xcc, dim3(128), dim3(64), 0, 0, d);
+                if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+                {
+                    uint32_t mx = 0;
+                    for (uint32_t v : h) mx = v > mx ? v : mx;
+                    nx = (int)mx + 1;
+                    for (uint32_t i = 0; i < 128; i++)
+                        if (h[i] != i % (uint32_t)nx) nx = 0;
+                }
+                (void)hipFree(d);
+            }
+            cached[dev] = nx;
+            known[dev]  = true;
+            return nx;
+        }
+        struct PersistForm
+        {
+            int nw, cpw; // wavefronts per workgroup, columns per wavefront; nw == 0: no in-launch form fits this device
+            int xcds;    // > 0: the launch is xcds x G workgroups and only those on XCD 0 work
+            size_t lds;
+            uint32_t G;
+        };
+        size_t persist_lds_bytes(int ptc, uint32_t n, uint32_t maxdim) { return 8 * ((size_t)ptc * (maxdim | 1u) + 2 * (size_t)maxdim) + 8 * (size_t)(n + 1); }
+        inline uint32_t persist_colld(uint32_t maxdim) { return (maxdim + 3u) & ~1u; } // a column's granules + {fresh, tail} squared norms
+        template <int NW, int CPW, bool ONEXCD> bool persist_fits(uint32_t G, size_t lds, int xcds)
+        {
+            // The workgroups of the launch wait for each other, so ALL G of them must be resident at once — on the ONE XCD they run on, in the
+            // one-XCD form: checked against what THIS device can hold (occupancy query x CU count; one workgroup fewer per CU than the query says
+            // where more than one fits — MI355X_MICROARCH.md, "Residency and cooperative launch").  A plain launch has the same residency as a
+            // cooperative one (same guide), and every spin is bounded, so a partitioned or busy device costs a fallback, never a hang.
+            int dev = 0, cus = 0, per_cu = 0;
+            if (lds > kMaxLdsBytes || G > 256u) return false;
+            if (lds > 64 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void *>(fast_level_persist<NW, CPW, ONEXCD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return false;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fast_level_persist<NW, CPW, ONEXCD>, 64 * NW, lds) != hipSuccess)
+                return false;
+            if (ONEXCD) cus /= xcds;
+            static const int margin = std::getenv("LEXLS_PERSIST_MARGIN") ? std::atoi(std::getenv("LEXLS_PERSIST_MARGIN")) : 1;
+            const long resident     = (long)cus * (per_cu > 1 ? per_cu - margin : per_cu);
+            if (std::getenv("LEXLS_LARGE_DEBUG")) std::fprintf(stderr, "lqr_large: form nw=%d cpw=%d one_xcd=%d: G=%u, %d per CU x %d CUs\n", NW, CPW, (int)ONEXCD, G, per_cu, cus);
+            return per_cu >= 1 && resident >= (long)G;
+        }
+// the instantiated forms: (wavefronts per workgroup, columns per wavefront)
+#define LEXLS_PERSIST_FORMS(X) X(4, 1) X(4, 2) X(4, 4) X(8, 1) X(8, 2) X(16, 1)
+        PersistForm choose_persist_form(uint32_t n, uint32_t maxdim)
+        {
+            static const char *want   = std::getenv("LEXLS_PERSIST_FORM"); // "nw,cpw"
+            static const int want_one = std::getenv("LEXLS_LARGE_ONE_XCD") ? std::atoi(std::getenv("LEXLS_LARGE_ONE_XCD")) : 0; // (measured: no gain, see the kernel's comment)
+            const int xcds            = want_one ? persist_xcds() : 0;
+            PersistForm f{0, 0, 0, 0, 0};
+            auto try_form = [&](int nw, int cpw, bool one) {
+                if (f.nw) return;
+                const uint32_t ptc = (uint32_t)(nw * cpw), G = (n + ptc) / ptc;
+                const size_t lds   = persist_lds_bytes((int)ptc, n, maxdim);
+                bool ok            = false;
+#define LEXLS_X(NW_, CPW_) \
+    if (nw == NW_ && cpw == CPW_) ok = one ? persist_fits<NW_, CPW_, true>(G, lds, xcds) : persist_fits<NW_, CPW_, false>(G, lds, xcds);
+                LEXLS_PERSIST_FORMS(LEXLS_X)
+#undef LEXLS_X
+                if (ok) f = PersistForm{nw, cpw, one ? xcds : 0, lds, G};
+            };
+            int wn = 0, wc = 0;
+            if (want && std::sscanf(want, "%d,%d", &wn, &wc) != 2) wn = wc = 0;
+            if (xcds > 1)
+            {
+                if (wn) try_form(wn, wc, true);
+                try_form(4, 4, true);
+                try_form(4, 2, true);
+                try_form(4, 1, true);
+            }
+            if (wn) try_form(wn, wc, false);
+            try_form(4, 1, false);
+            return f;
+        }
+        template <typename... Args> void launch_persist(const PersistForm &pf, size_t lds, hipStream_t s, Args... args)
+        {
+            const dim3 grid(pf.xcds ? (uint32_t)pf.xcds * pf.G : pf.G);
+#define LEXLS_X(NW_, CPW_)                                                                                                      \
+    if (pf.nw == NW_ && pf.cpw == CPW_)                                                                                         \
+    {                                                                                                                           \
+        if (pf.xcds)                                                                                                            \
+            hipLaunchKernelGGL((fast_level_persist<NW_, CPW_, true>), grid, dim3(64 * NW_), lds, s, args..., pf.G);             \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((fast_level_persist<NW_, CPW_, false>), grid, dim3(64 * NW_), lds, s, args..., pf.G);            \
+    }
+            LEXLS_PERSIST_FORMS(LEXLS_X)
+#undef LEXLS_X
+        }
+    } // namespace
+
     size_t large_fast_workspace_bytes(uint32_t batch, uint32_t n, uint32_t cap, uint32_t maxdim)
     {
         const size_t ps = (size_t)cap * (n + 1);
-        const size_t G = (n + PTC) / PTC; // workgroups of the one-launch-per-level form
+        const size_t G = (n + PTC_MIN) / PTC_MIN; // most workgroups of the one-launch-per-level forms
         return 8 * ((size_t)batch * ps + 3 * (size_t)batch * n + (size_t)batch * maxdim * maxdim) + 4 * 2 * (size_t)batch * (n + 1) + 2 * sizeof(LargeState) * (size_t)batch + 256 +
-               sizeof(PersistCtl) + 2 * G * PRS * sizeof(PersistCand) + 16 * 2 * G * (size_t)((maxdim + 1u) & ~1u) + 64;
+               sizeof(PersistCtl) + 2 * G * PRS * sizeof(PersistCand) + 16 * 2 * G * (size_t)((maxdim + 3u) & ~1u) + 64;
     }
 
     /// the fast large path (see the comment above fast_level_begin); gemm_only_mfma: the bit-exact multi-launch path with its trailing update on the matrix cores
@@ -1516,34 +1831,18 @@ namespace lexls
         w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(w) + 63) & ~(uintptr_t)63);
         PersistCtl *ctl = reinterpret_cast<PersistCtl *>(w);
         w += sizeof(PersistCtl);
-        const uint32_t G  = (n + PTC) / PTC;
-        PersistCand *cand = reinterpret_cast<PersistCand *>(w);
-        w += 2 * (size_t)G * PRS * sizeof(PersistCand);
-        double *colbuf = reinterpret_cast<double *>(w);
-        // single problems: the pivots of a level in ONE launch (fast_level_persist) — 4.1 us per pivot against 6.2 us for a launch per pivot
-        // (configs[1]: 2.74 ms vs 3.45 ms).  Its hand-offs spin (bounded); a launch whose spins ran out raises `abort`, ends, and the level
-        // is redone with a launch per pivot (LEXLS_LARGE_PERSIST=0: always a launch per pivot; =2: raise `abort` at once, for the tests)
-        const size_t persist_lds = 8 * ((size_t)PTC * (maxdim | 1u) + 3 * (size_t)maxdim + PTC) + 8 * (size_t)(n + 1);
-        // The workgroups of that launch wait for each other, so ALL G of them must be resident at once: checked against what THIS device can hold
-        // (occupancy query x CU count; one workgroup fewer per CU than the query says where the SGPR count sits at an edge — MI355X_MICROARCH.md,
-        // "Residency and cooperative launch"); otherwise the launch-per-pivot form.  A plain launch has the same residency as a cooperative
-        // one (same guide), and every spin is bounded, so a partitioned or busy device costs a fallback, never a hang.
-        bool persist = B == 1 && G <= 256 && persist_lds <= kMaxLdsBytes && a.skip == nullptr && !(std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) == 0);
-        if (persist)
-        {
-            int dev = 0, cus = 0, per_cu = 0;
-            if (persist_lds > 64 * 1024 &&
-                hipFuncSetAttribute(reinterpret_cast<const void *>(fast_level_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds) != hipSuccess)
-                persist = false;
-            if (persist && (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-                            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fast_level_persist, 256, persist_lds) != hipSuccess))
-                persist = false;
-            if (persist)
-            {
-                const long resident = (long)cus * (per_cu > 1 ? per_cu - 1 : per_cu); // (margin of one workgroup per CU where more than one fits)
-                if (per_cu < 1 || resident < (long)G) persist = false;
-            }
-        }
+        // single problems: the pivots of a level in ONE launch (fast_level_persist).  Its hand-offs spin (bounded); a launch whose spins ran out
+        // raises `abort`, ends, and the level is redone with a launch per pivot (LEXLS_LARGE_PERSIST=0: always a launch per pivot; =2: raise
+        // `abort` at once, for the tests).  Form of the launch: on ONE XCD when the device's workgroup placement was seen to be round robin
+        // (persist_xcds) and that XCD can hold all workgroups (LEXLS_LARGE_ONE_XCD=0: never); LEXLS_PERSIST_FORM="nw,cpw" picks another instantiation.
+        const PersistForm pf = choose_persist_form(n, maxdim);
+        const uint32_t G     = pf.nw ? pf.G : 1u;
+        if (std::getenv("LEXLS_LARGE_DEBUG")) std::fprintf(stderr, "lqr_large: in-launch form nw=%d cpw=%d xcds=%d G=%u lds=%zu\n", pf.nw, pf.cpw, pf.xcds, pf.G, pf.lds);
+        PersistCand *cand    = reinterpret_cast<PersistCand *>(w);
+        w += 2 * ((size_t)(n + PTC_MIN) / PTC_MIN) * PRS * sizeof(PersistCand);
+        double *colbuf           = reinterpret_cast<double *>(w);
+        const size_t persist_lds = pf.lds;
+        bool persist = B == 1 && pf.nw != 0 && a.skip == nullptr && !(std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) == 0);
         const bool persist_test_abort = persist && std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) == 2;
 
         hipError_t e         = hipSuccess;
@@ -1552,8 +1851,6 @@ namespace lexls
         if (step_lds > kMaxLdsBytes) return hipErrorInvalidValue;
         if (step_lds > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(fast_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds);
         if (e == hipSuccess && lds.trsm > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(large_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.trsm);
-        if (e == hipSuccess && persist && persist_lds > 64 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(fast_level_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds);
         if (e != hipSuccess) return e;
 
         hipLaunchKernelGGL(large_init, dim3(64, B), dim3(256), 0, s, a, fb.st[0]);
@@ -1567,7 +1864,7 @@ namespace lexls
             if (!all_exhausted && persist && h_level_max[level] > 0) // (an empty level has no pivot: nothing to launch, no state parity to flip)
             {
                 // the tags restart with every level (and every call): records and column granules of earlier pivots must not match them
-                e = hipMemsetAsync(ctl, 0, sizeof(PersistCtl) + 2 * (size_t)G * PRS * sizeof(PersistCand) + 16 * 2 * (size_t)G * ((maxdim + 1u) & ~1u), s);
+                e = hipMemsetAsync(ctl, 0, sizeof(PersistCtl) + 2 * ((size_t)(n + PTC_MIN) / PTC_MIN) * PRS * sizeof(PersistCand) + 16 * 2 * (size_t)G * persist_colld(maxdim), s);
                 if (e != hipSuccess) return e;
                 if (persist_test_abort)
                 {
@@ -1575,7 +1872,7 @@ namespace lexls
                     e = hipMemcpyAsync(&ctl->abort, &one, 4, hipMemcpyHostToDevice, s);
                     if (e != hipSuccess) return e;
                 }
-                hipLaunchKernelGGL(fast_level_persist, dim3(G), dim3(256), persist_lds, s, a, fb, ctl, cand, colbuf, (maxdim + 1u) & ~1u, cur, pp, level, G);
+                launch_persist(pf, persist_lds, s, a, fb, ctl, cand, colbuf, persist_colld(maxdim), cur, pp, level);
                 PersistCtl hc;
                 e = hipMemcpyAsync(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost, s);
                 if (e != hipSuccess) return e;
