@@ -202,6 +202,25 @@ const char *lexls_lse_last_kernel(lexls_lse_t h);
  *   6 = the tolerance-contract kernel lqr_qtol wherever it serves (T), else as 0. */
 int lexls_lse_set_kernel_policy(lexls_lse_t h, int policy);
 
+/* ---- prefix reuse ------------------------------------------------------------------------------
+ * The reference refactorizes the whole hierarchy in every LexLSI iteration although one row of one level changed (README.md:14 "No update
+ * mechanism ... each iteration of the solver performs a full decomposition"; the loop at lexlsi.h:1144-1172 calls factorize() on the whole
+ * problem).  Here a factorization can pick up the previous one of the same handle: with
+ *     lexls_lse_set_prefix_reuse(h, 1)
+ * every factor-keeping factorization by the register-resident wave kernel (IK-sized problems: nVar + 1 <= 64 columns, <= 64 rows — the kernel of
+ * a LexLSI stage; lexls_lse_prefix_reuse_ready(h) says whether the last one was) also leaves the position map after each level, and
+ *     lexls_lse_set_resume_levels(h, levels[batch])
+ * tells the NEXT factorization that, for problem b, levels 0 .. levels[b]-1 — their rows, dimensions and the fixed variables — are exactly
+ * those of its previous factorization, which still sits in the factor buffer.  Those levels are read back instead of factorized (no pivot
+ * search, no reflectors: the dependent chains that make up most of the kernel's time); their elimination of the rows from level levels[b] on is
+ * redone with the same instructions on the same operands.  Factor, permutation, ranks, Householder scalars and x are IDENTICAL, bit for bit, to
+ * a full factorization (tests/test_gpu_prefix_reuse.py).  levels[b] = 0: factorize everything.  The levels are consumed by that factorization.
+ * The caller vouches for "unchanged": the kernel does not compare rows.  Regularization, x-only solves and the other kernels ignore the request
+ * (full factorization) and leave nothing to resume from. */
+int lexls_lse_set_prefix_reuse(lexls_lse_t h, int enable);
+int lexls_lse_prefix_reuse_ready(lexls_lse_t h);
+int lexls_lse_set_resume_levels(lexls_lse_t h, const int32_t *h_levels);
+
 /* ---- inequality problems: the reference's LexLSI active-set driver (lexlsi.h), kept on the host -------------
  * The driver is host C++ (include/lexls/lexlsi.h, same logic as the reference's lexlsi.h/objective.h/workingset.h);
  * every factorize / solve / ObjectiveSensitivity it issues goes to the HIP kernels above.  Call sequence = the

@@ -25,6 +25,7 @@ SYMBOLS = [
     "lexls_lse_get_x", "lexls_lse_get_factor", "lexls_lse_get_hh_scalars", "lexls_lse_get_permutation", "lexls_lse_get_ranks",
     "lexls_lse_get_v", "lexls_lse_get_mu", "lexls_lse_get_lambda", "lexls_lse_get_sensitivity", "lexls_lse_get_ctr_type",
     "lexls_lse_device_ptr", "lexls_lse_last_kernel", "lexls_lse_set_kernel_policy",
+    "lexls_lse_set_prefix_reuse", "lexls_lse_prefix_reuse_ready", "lexls_lse_set_resume_levels",
     "lexls_lsi_solve", "lexls_lsi_solve_dat", "lexls_lsi_batch_solve",
 ]
 

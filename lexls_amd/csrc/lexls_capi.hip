@@ -66,6 +66,12 @@ struct lexls_lse_s
     uint8_t *d_fixed_type, *d_ctr_type, *d_skip;
     bool has_skip;
     bool fused_gather = false; // this round's rows are read by reference inside lqr_wave_kernel (lexls_internal_round_resident)
+    // prefix reuse (lexls_lse_set_prefix_reuse): the register-resident wave kernel leaves what a later factorization needs to read levels back
+    int32_t *d_resume_level = nullptr; // batch
+    uint8_t *d_resume_state = nullptr; // batch x resume_state_bytes(nObj)
+    bool resume_enabled = false;
+    bool resume_valid   = false; // the LAST factorization of this handle left that state (same kernel, factor kept, no regularization)
+    bool resume_armed   = false; // d_resume_level holds the levels for the NEXT factorization
     int32_t *d_sens, *d_objidx;
     uint32_t reg_type;    // LexLS::RegularizationType, 0 = none
     uint32_t reg_cg_iters;
@@ -115,6 +121,8 @@ struct lexls_lse_s
         a.g_per        = cdata_per_problem;
         a.g_row_src    = d_row_src;
         a.g_row_ld     = d_row_ld;
+        a.resume_state = resume_enabled ? d_resume_state : nullptr;
+        a.resume_level = (resume_enabled && resume_armed && resume_valid) ? d_resume_level : nullptr;
         return a;
     }
     size_t problem_elems() const { return (size_t)cap * (nVar + 1); }
@@ -256,7 +264,7 @@ extern "C"
         if (!h) return LEXLS_OK;
         (void)hipSetDevice(h->device);
         void *ptrs[] = {h->d_in_owned, h->d_fac, h->d_hh, h->d_v, h->d_lambda, h->d_scratch, h->d_perm, h->d_rank, h->d_fcol, h->d_round_in, h->d_round_out,
-                        h->d_large_state, h->d_large_ws, h->d_norms, h->d_cdata, h->d_reg_factor, h->d_reg_scratch, h->d_reg_mu};
+                        h->d_large_state, h->d_large_ws, h->d_norms, h->d_cdata, h->d_reg_factor, h->d_reg_scratch, h->d_reg_mu, h->d_resume_level, h->d_resume_state};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (h->h_dims_pinned) (void)hipHostFree(h->h_dims_pinned);
@@ -749,6 +757,10 @@ extern "C"
             solved = do_solve || opportunistic_solve;
             HIP_TRY(launch_lqr_generic(a, h->max_rows, write_factor, solved, h->stream, &variant));
         }
+        // prefix reuse: the levels handed over are consumed; the state is there for the next factorization iff this one was the register-resident
+        // wave kernel keeping its factor (every other kernel ignores both pointers and factorizes everything)
+        h->resume_armed = false;
+        h->resume_valid = a.resume_state != nullptr && write_factor && h->reg_type == 0 && std::strncmp(variant, "lqr_wave<", 9) == 0;
         h->last_kernel   = variant;
         h->factor_valid  = true;
         h->factor_epoch++;
@@ -940,6 +952,44 @@ extern "C"
     }
 
     const char *lexls_lse_last_kernel(lexls_lse_t h) { return h ? h->last_kernel : ""; }
+
+    int lexls_lse_set_prefix_reuse(lexls_lse_t h, int enable)
+    {
+        CHECK_HANDLE(h);
+        HIP_TRY(hipSetDevice(h->device));
+        if (enable && !h->d_resume_state)
+        {
+            HIP_TRY(hipMalloc((void **)&h->d_resume_state, (size_t)h->batch * resume_state_bytes(h->nObj)));
+            HIP_TRY(hipMalloc((void **)&h->d_resume_level, 4 * (size_t)h->batch));
+            HIP_TRY(hipMemsetAsync(h->d_resume_level, 0, 4 * (size_t)h->batch, h->stream));
+        }
+        h->resume_enabled = enable != 0;
+        h->resume_valid   = false;
+        h->resume_armed   = false;
+        return LEXLS_OK;
+    }
+    int lexls_lse_prefix_reuse_ready(lexls_lse_t h) { return (h && h->resume_enabled && h->resume_valid) ? 1 : 0; }
+    int lexls_lse_set_resume_levels(lexls_lse_t h, const int32_t *h_levels)
+    {
+        CHECK_HANDLE(h);
+        if (!h->resume_enabled) return fail(LEXLS_ERR_INVALID, "set_resume_levels: lexls_lse_set_prefix_reuse(h, 1) first");
+        if (!h_levels) return fail(LEXLS_ERR_INVALID, "set_resume_levels: levels is NULL");
+        if (!h->resume_valid) return fail(LEXLS_ERR_INVALID, "set_resume_levels: the last factorization left nothing to resume from (another kernel, no factor kept, or none yet)");
+        for (uint32_t b = 0; b < h->batch; b++)
+            if (h_levels[b] < 0 || (uint32_t)h_levels[b] > h->nObj) return fail(LEXLS_ERR_INVALID, "set_resume_levels: a level is outside 0 .. nObj");
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpyAsync(h->d_resume_level, h_levels, 4 * (size_t)h->batch, hipMemcpyHostToDevice, h->stream));
+        if (!h->deferred_sync) HIP_TRY(hipStreamSynchronize(h->stream));
+        h->resume_armed = true;
+        return LEXLS_OK;
+    }
+    /* internal (the lock-step LexLSI driver): the device array its resident iterations write the levels into, and the promise that it holds
+     * them for the next factorization */
+    int32_t *lexls_internal_resume_levels(lexls_lse_t h) { return (h && h->resume_enabled) ? h->d_resume_level : nullptr; }
+    void lexls_internal_arm_resume(lexls_lse_t h)
+    {
+        if (h && h->resume_enabled) h->resume_armed = true;
+    }
 
     int lexls_lse_set_kernel_policy(lexls_lse_t h, int force_generic)
     {

@@ -54,5 +54,15 @@ namespace lexls
         const double *g_cdata;
         uint64_t g_per;
         const uint32_t *g_row_src, *g_row_ld;
+        // Prefix reuse (the reference refactorizes everything every iteration, README.md:14): a LexLSI iteration changes ONE
+        // row of ONE level, so the levels above it factorize to what they did before.  resume_state (batch x resume_state_bytes(nObj), NULL: off)
+        // receives what the register-resident wave kernel needs to pick a factorization up again; resume_level[b] = K > 0 (NULL: nobody)
+        // says that levels 0 .. K-1 of problem b — rows, dimensions, fixed variables — are those of its previous factorization by that
+        // kernel into the SAME factor buffer: they are read back instead of factorized, and only their elimination of the rows from level K
+        // on is redone.  Same instructions on the same operands for everything that is recomputed: results identical bit for bit.
+        const int32_t *resume_level;
+        uint8_t *resume_state;
     };
+    /// per problem: the position of every physical column after each level (nObj x 64 bytes) and after the last one (64 bytes)
+    __host__ __device__ inline size_t resume_state_bytes(uint32_t nObj) { return 64 * ((size_t)nObj + 1); }
 } // namespace lexls

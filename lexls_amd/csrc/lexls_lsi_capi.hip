@@ -22,6 +22,8 @@ extern "C" int lexls_internal_upload_round_trusted(lexls_lse_t h, const void *h_
 extern "C" const double *lexls_internal_cdata(lexls_lse_t h);                                        // lexls_capi.hip
 extern "C" char *lexls_internal_round_in(lexls_lse_t h);                                             // lexls_capi.hip
 extern "C" int lexls_internal_round_resident(lexls_lse_t h, int has_fixed);                          // lexls_capi.hip
+extern "C" int32_t *lexls_internal_resume_levels(lexls_lse_t h);                                     // lexls_capi.hip
+extern "C" void lexls_internal_arm_resume(lexls_lse_t h);                                            // lexls_capi.hip
 #include "lqr_wave_common.h" // wave_max
 
 namespace
@@ -297,6 +299,7 @@ namespace
         int32_t *objidx;
         uint32_t *row_src, *row_ld;
         uint8_t *fixed_type, *ctr_type;
+        int32_t *resume; // B: the LexLSE level this iteration's working-set change sits in = the levels the next factorization may read back (NULL: off)
     };
 
     /// LDS of one instance's wavefront: [dx n | A dx total | dv total] doubles, u16 na[STEP_MAX_OBJ], then the working-set lists
@@ -375,6 +378,15 @@ namespace
                 ina[f + nik] = (uint16_t)c;
                 ipos[f + c]  = (uint16_t)nik;
                 na[k]        = (uint16_t)(nak - 1);
+            }
+            // prefix reuse: the change touches ONE objective; the equality problem's levels above it keep their rows (an activation appends to
+            // its level, a removal erases in order: workingset.h:79-108), so the next factorization reads them back.  A change in the
+            // simple-bounds objective changes the fixed variables: everything again.
+            if (a.resume)
+            {
+                const int32_t K = blocked ? (blk_obj >= (int)a.off ? blk_obj - (int)a.off : 0) : (removed && rm_lvl > 0 ? rm_lvl : 0);
+                a.resume[b]     = K;
+                if (!done) info[6] += K, info[7] += 1;
             }
             info[0] = (!blocked && !removed) ? (int32_t)PROBLEM_SOLVED : (done ? (int32_t)MAX_NUMBER_OF_FACTORIZATIONS_EXCEEDED : info[0]);
             info[1] = niter + 1;
@@ -549,6 +561,8 @@ namespace
             for (uint32_t k = 0; k < nObjL; k++) cap += maxdim[k];
             pstride = (size_t)cap * (n + 1);
             hip_check(lexls_lse_create(&h, device, B, n, nObjL, maxdim.data()));
+            // prefix reuse in the resident iterations: LEXLS_LSI_PREFIX_REUSE=0 factorizes everything in every iteration
+            if (!(std::getenv("LEXLS_LSI_PREFIX_REUSE") && std::atoi(std::getenv("LEXLS_LSI_PREFIX_REUSE")) == 0)) hip_check(lexls_lse_set_prefix_reuse(h, 1));
             if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&stream_sens, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&ev_uploaded, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_sens_done, hipEventDisableTiming) != hipSuccess)
                 throw Exception("hipStreamCreate / hipEventCreate failed (lock-step LSI batch)");
@@ -660,6 +674,7 @@ namespace
             info[3]       = static_cast<int32_t>(inst.getDeactivationsCount());
             info[4]       = static_cast<int32_t>(inst.getFactorizationsCount());
             info[5]       = static_cast<int32_t>(totalrank[b]);
+            info[6] = info[7] = 0; // prefix reuse: levels read back, summed over the resident factorizations; their number
             reinterpret_cast<uint8_t *>(base + r_alive)[b] = 1;
             is_resident[b] = 1;
             skip[b]        = 0; // its staged equality problem is served by the first resident stage, followed by its removal sweep
@@ -700,6 +715,7 @@ namespace
             ra.row_ld    = reinterpret_cast<uint32_t *>(in + lay.row_ld);
             ra.fixed_type = reinterpret_cast<uint8_t *>(in + lay.fixed_type);
             ra.ctr_type   = reinterpret_cast<uint8_t *>(in + lay.ctr_type);
+            ra.resume     = lexls_internal_resume_levels(h);
             return ra;
         }
 
@@ -721,7 +737,10 @@ namespace
                 if (rounds_resident == 0)
                     hip_check(lexls_internal_upload_round_trusted(h, in_block.data(), 1)); // the problems the host formed last
                 else
+                {
                     hip_check(lexls_internal_round_resident(h, rshape.dim0 ? 1 : 0)); // the problems lsi_iterate_kernel formed
+                    lexls_internal_arm_resume(h);                                     // ... and the levels it found unchanged
+                }
                 hip_check(lexls_lse_factorize_solve(h, 1));
                 hip_check(lexls_lse_sensitivity_resident(h, tolW, tolC)); // speculative: used when the step is not blocked
                 hipLaunchKernelGGL(lsi_iterate_kernel, dim3((B + 3) / 4), dim3(256), 4 * resident_lds_per_wave(rshape.SD, rshape.total), stream, ra);
@@ -1599,6 +1618,20 @@ struct lexls_lsi_batch_s
             rounds_step += grp[g]->rounds_step + grp[g]->rounds_resident;
             t_enq += grp[g]->t_enqueue;
             t_wait += grp[g]->t_wait;
+        }
+        if (std::getenv("LEXLS_LSI_TIMING") && run_resident) // prefix reuse: what the lock-step stages could and what a per-instance loop would save
+        {
+            long sumK = 0, cnt = 0, worstK = 0, worstN = -1;
+            for (uint32_t g = 0; g < nGroups; g++)
+                for (uint32_t k = 0; k < grp[g]->B; k++)
+                    if (grp[g]->is_resident[k])
+                    {
+                        const int32_t *inf = grp[g]->r_info_of(k);
+                        sumK += inf[6], cnt += inf[7];
+                        if (inf[7] > worstN) worstN = inf[7], worstK = inf[6];
+                    }
+            std::fprintf(stderr, "lexls_lsi_batch_solve: prefix reuse: %ld resident factorizations behind a working-set change, %.2f levels read back on average; the instance with the most (%ld): %.2f\n",
+                         cnt, cnt ? (double)sumK / cnt : 0.0, worstN, worstN > 0 ? (double)worstK / worstN : 0.0);
         }
         if (std::getenv("LEXLS_LSI_TIMING"))
             std::fprintf(stderr, "lexls_lsi_batch_solve: setup = %.4f s reset / constraint upload + %.4f s LexLSI objects (batch created in %.4f s)\n", t_ctx, t_setup - t_ctx, t_create),

@@ -88,6 +88,17 @@ namespace lexls
             int M                = 0;
             for (int k = 0; k < nObj; k++) M += (int)dims[k];
 
+            // ---- prefix reuse (LseArgs::resume_level): levels 0 .. Kres-1 are those of this problem's previous factorization ----
+            double *fac_out = a.fac + b * pstride;
+            int Kres = 0, Fres = 0; // levels read back, their rows
+            uint8_t *rstate = (WF && !REG && a.resume_state) ? a.resume_state + (size_t)b * resume_state_bytes((uint32_t)nObj) : nullptr;
+            if (rstate && a.resume_level)
+            {
+                Kres = uni(a.resume_level[b]);
+                Kres = Kres < 0 ? 0 : (Kres > nObj ? nObj : Kres);
+                for (int k = 0; k < Kres; k++) Fres += (int)dims[k];
+            }
+
             // ---- load: row-per-lane, coalesced down each column ----
             const double *in = a.in + b * pstride;
             double T[NC];
@@ -96,18 +107,30 @@ namespace lexls
                 const uint32_t rl  = a.g_row_ld[(size_t)b * cap + (lane < cap ? lane : 0)];
                 const size_t ld    = rl & 0x7fffffffu;
                 const double *src  = a.g_cdata + (size_t)b * a.g_per + a.g_row_src[(size_t)b * cap + (lane < cap ? lane : 0)];
-                const bool on      = lane < M && ld != 0;
+                const bool on      = lane < M && ld != 0 && lane >= Fres;
 #pragma unroll
                 for (int j = 0; j < NC; j++) T[j] = (j <= n && on) ? src[(size_t)(j < n ? j : n + (int)(rl >> 31)) * ld] : 0.0;
             }
             else
             {
 #pragma unroll
-                for (int j = 0; j < NC; j++) T[j] = (j <= n && lane < M) ? in[lane + (size_t)j * cap] : 0.0;
+                for (int j = 0; j < NC; j++) T[j] = (j <= n && lane < M && lane >= Fres) ? in[lane + (size_t)j * cap] : 0.0;
+            }
+            if (Kres > 0) // the finished rows of the levels read back: from the factor, whose column = the FINAL position of the physical column then
+            {
+                const int oldpos = (int)rstate[64 * nObj + lane];
+#pragma unroll
+                for (int j = 0; j < NC; j++)
+                    if (j <= n)
+                    {
+                        const int slot = (j < n) ? __builtin_amdgcn_readlane(oldpos, j) : n;
+                        if (lane < Fres) T[j] = fac_out[lane + (size_t)slot * cap];
+                    }
             }
 
             double *hhs = a.hh + (size_t)b * cap;
-            for (int i = lane; i < cap; i += 64) hhs[i] = 0.0; // initialize(), lexlse.h:1683
+            for (int i = lane; i < cap; i += 64)
+                if (i >= Fres) hhs[i] = 0.0; // initialize(), lexlse.h:1683 (the scalars of levels read back stay)
             perm_s[lane] = lane;
             if (lane < 16) ZB[lane] = 0.0;
             for (uint32_t i = lane; i < img_doubles; i += 64) IMG[i] = 0.0; // (the trailing update of a ragged level reads past a column's rank)
@@ -119,7 +142,6 @@ namespace lexls
             }
             int pos        = (lane < n) ? lane : (lane == n ? n : 0x3fffffff);
             int rowlim     = 64; // factor output: rows of this lane's physical column that the row-per-lane image T still owns (all, until it is pivoted)
-            double *fac_out = a.fac + b * pstride;
             int ColIndex   = 0;
             int TotalRank  = 0;
 
@@ -154,12 +176,19 @@ namespace lexls
                     const int lk = (int)__builtin_ctzll(__ballot(lane < n && pos == kf));
                     shift        = dfma(select_reg<NC>(T, lk), EX[kf], shift);
                 }
+                if (lane < Fres) shift = 0.0; // (rows read back from the factor carry it already; x - 0.0 == x)
                 if (EXACT)
                     T[NC - 1] -= shift;
                 else
                     store_reg<NC>(T, n, select_reg<NC>(T, n) - shift, true);
                 ColIndex  = nf;
                 TotalRank = nf;
+                __syncthreads();
+            }
+            if (Kres > 0) // the pivots of the levels read back: their entries of column_permutations are still in the output
+            {
+                const int colK = (int)a.fcol[(size_t)b * nObj + Kres - 1] + (int)a.rank[(size_t)b * nObj + Kres - 1];
+                if (lane >= nf && lane < colK) perm_s[lane] = a.perm[(size_t)b * n + lane];
                 __syncthreads();
             }
             const bool all_fixed = ColIndex >= n; // lexlse.h:164-175: nothing left to factorise
@@ -540,7 +569,51 @@ namespace lexls
                     }
                 };
 
-                if (dim_rt > 0 && (!exhausted || write_factor))
+                // A level read back (prefix reuse): its finished rows are in T already (loaded from the factor); what the rest of the loop body
+                // needs besides — the column-per-lane block for the compact image, the pivots' lanes and reciprocal diagonals for the Gauss
+                // step, the position map as it was after this level — is restored instead of recomputed.  Everything restored is what the
+                // factorization left (1 / R_qq is the same correctly rounded quotient), so the rows from level Kres on see the same operands.
+                auto replay_level = [&]() {
+                    const int rk = uni((int)a.rank[(size_t)b * nObj + k]);
+                    pos          = (lane < n) ? (int)rstate[64 * k + lane] : (lane == n ? n : 0x3fffffff);
+                    if (lane < MD)
+                    {
+                        pivl_s[lane] = 0;
+                        idg_s[lane]  = 0.0;
+                    }
+                    __syncthreads();
+                    if (lane >= F && lane < F + dim_rt)
+                    {
+#pragma unroll
+                        for (int j = 0; j < NC; j++)
+                            if (j <= n) X[j * MD + (lane - F)] = T[j];
+                    }
+                    __syncthreads();
+                    if (lane <= n)
+                    {
+#pragma unroll
+                        for (int r = 0; r < MD; r++) hh[r] = (r < dim_rt) ? X[lane * MD + r] : 0.0;
+                    }
+                    const int q = pos - Fc;
+                    if (lane < n && q >= 0 && q < rk)
+                    {
+                        double d = 0.0;
+#pragma unroll
+                        for (int r = 0; r < MD; r++)
+                            if (r == q) d = hh[r];
+                        pivl_s[q] = lane;
+                        idg_s[q]  = 1.0 / d;
+                        rowlim    = F + dim_rt;
+                    }
+                    rank     = rk;
+                    ColIndex = Fc + rk;
+                    if (ColIndex == n) exhausted = true;
+                };
+                if (k < Kres)
+                {
+                    if (dim_rt > 0) replay_level(); // (also a level behind the last column: its rows pass through the block, as in factor_level)
+                }
+                else if (dim_rt > 0 && (!exhausted || write_factor))
                 {
 #if defined(LEXLS_WAVE_PADDED)
                     factor_level(std::true_type{});
@@ -621,7 +694,7 @@ namespace lexls
                     constexpr bool FULL = decltype(full_c)::value;
                     const int rk        = FULL ? MD : rank;
                     const int Fn        = F + dim;
-                    const bool below    = lane >= Fn && lane < M;
+                    const bool below    = lane >= Fn && lane < M && lane >= Fres; // (rows of levels read back are final)
 
                     // ---- L <- A_left R^-1, column-oriented: after L_p is final, ONE batch of loads brings row p of R and every
                     //      later column absorbs it (same accumulation order per column as the row-oriented form: p ascending) ----
@@ -787,6 +860,11 @@ namespace lexls
                         const int lim  = (j < n) ? __builtin_amdgcn_readlane(rowlim, j) : 64; // (the multipliers below a pivoted column are in place already)
                         if (lane < M && lane < lim) fac_out[lane + (size_t)slot * cap] = T[j];
                     }
+            }
+            if (rstate) // what a later factorization needs to read levels back (LseArgs::resume_level)
+            {
+                for (int k = 0; k < nObj; k++) rstate[64 * k + lane] = slotmap[k * 64 + lane];
+                rstate[64 * nObj + lane] = (uint8_t)((lane < n) ? pos : n);
             }
             if (lane < n) a.x[(size_t)b * n + lane] = xs[pos]; // x = P x: variable j sits at position pos[j]
             if (lane < n) a.perm[(size_t)b * n + lane] = (lane < TotalRank) ? perm_s[lane] : (uint32_t)lane;

@@ -244,6 +244,19 @@ class BatchedLexLSE:
         capi.check(capi.lib().lexls_lse_device_ptr(self._h, C.c_int(capi.ARRAY[name]), C.byref(p)))
         return int(p.value)
 
+    def set_prefix_reuse(self, enable: bool = True):
+        """lexls_lse_set_prefix_reuse: factor-keeping factorizations by the register-resident wave kernel leave what a later one needs to
+        read unchanged leading levels back instead of factorizing them (the reference has no such mechanism, README.md:14)"""
+        capi.check(capi.lib().lexls_lse_set_prefix_reuse(self._h, C.c_int(1 if enable else 0)))
+
+    def prefix_reuse_ready(self) -> bool:
+        return bool(capi.lib().lexls_lse_prefix_reuse_ready(self._h))
+
+    def set_resume_levels(self, levels):
+        """levels[b] = number of leading levels of problem b that are unchanged since its previous factorization (consumed by the next one)"""
+        lv = np.ascontiguousarray(np.broadcast_to(np.asarray(levels, np.int32), (self.batch,)))
+        capi.check(capi.lib().lexls_lse_set_resume_levels(self._h, lv.ctypes.data_as(C.c_void_p)))
+
     def set_kernel_policy(self, policy: int):
         """diagnostics (lexls_lse_set_kernel_policy): 0 automatic dispatch, 1 generic kernel only, 2 never the left-looking wave kernel,
         3 the left-looking wave kernel whenever the shape allows it"""
