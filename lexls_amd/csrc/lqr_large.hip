@@ -897,6 +897,10 @@ namespace lexls
             double norm;
             uint32_t pos, idx;
         };
+        /// records per mailbox row (a reader's row starts on a 256-byte boundary)
+        __host__ __device__ inline size_t persist_mailbox_stride(uint32_t G) { return ((size_t)G + 15u) & ~(size_t)15u; }
+        /// bytes of the two (pivot parity) sets of G mailbox rows
+        inline size_t persist_mailbox_bytes(uint32_t G) { return 2 * (size_t)G * persist_mailbox_stride(G) * sizeof(PersistCand); }
         __device__ __forceinline__ void st_sc1(double *p, double v)
         {
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -965,10 +969,11 @@ namespace lexls
         {
             constexpr int PTC      = NW * CPW; // columns per workgroup, CPW per wavefront
             constexpr uint32_t NT  = 64u * NW;
-            // records of neighbouring workgroups: PRS x 16 bytes apart when they are polled through memory (a line shared by sixteen records made its
-            // channel the bottleneck), side by side inside ONE L2 — there the G x G record reads of a poll are what costs, and a wavefront's
-            // load of 64 consecutive records is 8 lines instead of 64
-            constexpr size_t RS = ONEXCD ? 1 : PRS;
+            // Records travel by MAILBOX: a workgroup stores its record once per reader, into that reader's own row of G consecutive slots
+            // (lane = reader: three store instructions of wave 0), and a reader polls only its own row — 2 KB that nobody else reads, as
+            // coalesced loads.  Before (every workgroup's ONE record polled by all G: 129 x 129 scattered 16-byte reads of 129 hot lines per
+            // round) a poll round trip took 2200 cycles against 900 for a single line (scripts/ubench/xcd_pingpong.hip).
+            const size_t MBS = persist_mailbox_stride(G);
             extern __shared__ double smem[];
             __shared__ u32x4 slot[NW]; // the wavefronts' own candidates of the next pivot: {norm, position, column}
             __shared__ uint32_t flag;
@@ -1096,11 +1101,17 @@ namespace lexls
                 const uint32_t myk = kk[0];
                 const uint32_t myp = myk == 0xffffffffu ? 0xffffffffu : (myk >> 8), myj = t * PTC + (myk & 255u);
                 cand_p = myp, cand_j = myj;
-                if (tid == 0)
+                if (wave == 0)
                 {
                     u32x4 q;
                     q.x = (unsigned)__double2loint(myv), q.y = (unsigned)__double2hiint(myv), q.z = myp, q.w = ((cnt + 1u) << 8) | (myk & 255u); // (no candidate: pos says so, the index is not looked at)
-                    st16_x<ONEXCD>(cand + ((size_t)(cnt & 1u) * G + t) * RS, q);
+                    PersistCand *box = cand + (size_t)(cnt & 1u) * G * MBS + t; // slot t of every reader's row
+#pragma unroll
+                    for (int kq = 0; kq < 4; kq++)
+                    {
+                        const uint32_t reader = lane + 64u * kq;
+                        if (reader < G) st16_x<ONEXCD>(box + (size_t)reader * MBS, q);
+                    }
                 }
             };
             // the candidate's remaining rows, by the wavefront that owns (and has just updated) the column — and, behind them, the column's
@@ -1145,7 +1156,7 @@ namespace lexls
                 if (wave == 0)
                 {
                     // every lane keeps up to four records (G <= 256) in flight per poll: ONE round trip per poll, not one per record
-                    const PersistCand *base = cand + (size_t)par * G * RS;
+                    const PersistCand *base = cand + ((size_t)par * G + t) * MBS; // this workgroup's row
                     u32x4 q[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
                     uint32_t ok = 0;
                     for (uint32_t spin = 0; spin < (1u << 18); spin++)
@@ -1155,7 +1166,7 @@ namespace lexls
                         {
                             const uint32_t w = lane + 64u * kq;
                             if (kq == 0 || 64u * kq < G) // (wave-uniform)
-                                ld16_issue<ONEXCD>(q[kq], base + (size_t)(w < G ? w : 0) * RS);
+                                ld16_issue<ONEXCD>(q[kq], base + (w < G ? w : 0));
                         }
                         asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3])::"memory");
                         bool mine = true;
@@ -1796,7 +1807,7 @@ namespace lexls
         const size_t ps = (size_t)cap * (n + 1);
         const size_t G = (n + PTC_MIN) / PTC_MIN; // most workgroups of the one-launch-per-level forms
         return 8 * ((size_t)batch * ps + 3 * (size_t)batch * n + (size_t)batch * maxdim * maxdim) + 4 * 2 * (size_t)batch * (n + 1) + 2 * sizeof(LargeState) * (size_t)batch + 256 +
-               sizeof(PersistCtl) + 2 * G * PRS * sizeof(PersistCand) + 16 * 2 * G * (size_t)((maxdim + 3u) & ~1u) + 64;
+               sizeof(PersistCtl) + persist_mailbox_bytes((uint32_t)G) + 16 * 2 * G * (size_t)((maxdim + 3u) & ~1u) + 64;
     }
 
     /// the fast large path (see the comment above fast_level_begin); gemm_only_mfma: the bit-exact multi-launch path with its trailing update on the matrix cores
@@ -1839,7 +1850,7 @@ namespace lexls
         const uint32_t G     = pf.nw ? pf.G : 1u;
         if (std::getenv("LEXLS_LARGE_DEBUG")) std::fprintf(stderr, "lqr_large: in-launch form nw=%d cpw=%d xcds=%d G=%u lds=%zu\n", pf.nw, pf.cpw, pf.xcds, pf.G, pf.lds);
         PersistCand *cand    = reinterpret_cast<PersistCand *>(w);
-        w += 2 * ((size_t)(n + PTC_MIN) / PTC_MIN) * PRS * sizeof(PersistCand);
+        w += persist_mailbox_bytes((n + PTC_MIN) / PTC_MIN);
         double *colbuf           = reinterpret_cast<double *>(w);
         const size_t persist_lds = pf.lds;
         bool persist = B == 1 && pf.nw != 0 && a.skip == nullptr && !(std::getenv("LEXLS_LARGE_PERSIST") && std::atoi(std::getenv("LEXLS_LARGE_PERSIST")) == 0);
@@ -1864,7 +1875,7 @@ namespace lexls
             if (!all_exhausted && persist && h_level_max[level] > 0) // (an empty level has no pivot: nothing to launch, no state parity to flip)
             {
                 // the tags restart with every level (and every call): records and column granules of earlier pivots must not match them
-                e = hipMemsetAsync(ctl, 0, sizeof(PersistCtl) + 2 * ((size_t)(n + PTC_MIN) / PTC_MIN) * PRS * sizeof(PersistCand) + 16 * 2 * (size_t)G * persist_colld(maxdim), s);
+                e = hipMemsetAsync(ctl, 0, sizeof(PersistCtl) + persist_mailbox_bytes((n + PTC_MIN) / PTC_MIN) + 16 * 2 * (size_t)G * persist_colld(maxdim), s);
                 if (e != hipSuccess) return e;
                 if (persist_test_abort)
                 {
@@ -1878,6 +1889,7 @@ namespace lexls
                 if (e != hipSuccess) return e;
                 e = hipStreamSynchronize(s);
                 if (e != hipSuccess) return e;
+                if (hc.abort && std::getenv("LEXLS_LARGE_DEBUG")) std::fprintf(stderr, "lqr_large: level %u: the in-launch form gave up, a launch per pivot instead\n", level);
                 if (hc.abort) // a hand-off ran out of spins (workgroups not co-resident?): nothing of the level was committed — a launch per pivot instead
                     run_steps = true;
                 else
