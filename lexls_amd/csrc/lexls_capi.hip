@@ -748,7 +748,7 @@ extern "C"
                 HIP_TRY(launch_lqr_large_fast(a, h->level_max.data(), h->max_rows, h->d_large_ws, h->stream));
                 variant = "lqr_large<step-per-pivot,mfma>";
             }
-            if (do_solve) HIP_TRY(launch_solve_generic(a, h->stream));
+            if (do_solve) HIP_TRY(launch_solve_generic(a, h->stream, h->force_generic != 5)); // (the step-per-pivot path's contract allows reciprocals)
             solved       = do_solve;
             write_factor = true;
         }
@@ -784,7 +784,7 @@ extern "C"
         if (int rc = need_factor(h, "lexls_lse_solve")) return rc;
         if (h->x_epoch == h->factor_epoch) return LEXLS_OK; // the factorization kernel left the basic solution in place
         HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(launch_solve_generic(h->args(), h->stream));
+        HIP_TRY(launch_solve_generic(h->args(), h->stream, std::strstr(h->last_kernel, "step-per-pivot") != nullptr)); // (same x as that path's factorize_solve)
         h->x_epoch = h->factor_epoch;
         return LEXLS_OK;
     }

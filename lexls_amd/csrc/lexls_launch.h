@@ -12,7 +12,7 @@ namespace lexls
 
     // lqr_generic.hip — any shape, one workgroup per problem
     hipError_t launch_lqr_generic(LseArgs a, uint32_t max_rows, bool write_factor, bool do_solve, hipStream_t s, const char **variant);
-    hipError_t launch_solve_generic(const LseArgs &a, hipStream_t s);
+    hipError_t launch_solve_generic(const LseArgs &a, hipStream_t s, bool reciprocal_diagonal = false);
     hipError_t launch_residual(const LseArgs &a, hipStream_t s);
     hipError_t launch_sensitivity(const LseArgs &a, const int32_t *d_obj_index, int32_t obj_all, double tolW, double tolC, hipStream_t s, bool scan_up = false,
                                   uint32_t sweep_level_dim_hint = 0); // hint = largest level dimension of the batch (enables the single-sweep kernel)

@@ -775,16 +775,20 @@ namespace lexls
                     }
                     acc += rank;
                 }
-                if (tid == 0) // x = P x (lexlse.h:1044)
-                    for (uint32_t k = TotalRank; k--;)
+                // x = P x (lexlse.h:1044): variable i follows the transpositions, first to last, from position i to its final position
+                // (solve_generic_kernel explains); the entries of x by position are only read
+                __syncthreads();
+                for (uint32_t i = tid; i < n; i += NT)
+                {
+                    uint32_t p = i;
+#pragma unroll 8
+                    for (uint32_t k = 0; k < TotalRank; k++)
                     {
                         const uint32_t pk = perm_s[k];
-                        const double t    = xs[k];
-                        xs[k]             = xs[pk];
-                        xs[pk]            = t;
+                        p                 = (p == k) ? pk : ((p == pk) ? k : p);
                     }
-                __syncthreads();
-                for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
+                    a.x[(size_t)b * n + i] = xs[p];
+                }
             }
             GSTAMP(8)
             GSTAMP_WRITE
@@ -793,11 +797,19 @@ namespace lexls
         // -----------------------------------------------------------------------------------------
         // solve() alone, from the factor in HBM
         // -----------------------------------------------------------------------------------------
-        template <int NT>
+        /// RECIP (the large path's step-per-pivot form, whose contract is values within 1e-10): a diagonal block's 64 reciprocals are formed
+        /// at once, lane-parallel, and the chain multiplies — the division sequence (~400 cycles) sat on every one of the nVar dependent steps
+        template <int NT, bool RECIP = false>
         __global__ __launch_bounds__(NT) void solve_generic_kernel(LseArgs a)
         {
             extern __shared__ double smem[];
             const uint32_t b = blockIdx.x, tid = threadIdx.x;
+#ifdef LEXLS_SOLVE_STAMPS
+            long long sst[6] = {0, 0, 0, 0, 0, 0}, st0 = clock64();
+#define SSTAMP(i) { const long long t_ = clock64(); sst[i] += t_ - st0; st0 = t_; }
+#else
+#define SSTAMP(i)
+#endif
             const uint32_t n = a.nVar, cap = a.cap, nObj = a.nObj;
             const double *W  = a.fac + (size_t)b * cap * (n + 1);
             const size_t ld  = cap;
@@ -825,6 +837,16 @@ namespace lexls
                     uint32_t j = 0;
                     if constexpr (NT >= 256) // (large levels: sixteen entries of the row requested together; the chain itself stays in order)
                     {
+                        // (a batch = one trip to the stored factor, ~1.5 us: 64 entries per trip instead of 16 took the solve of configs[1] from
+                        // 150 to NN us)
+                        for (; j + 64 <= acc; j += 64)
+                        {
+                            double w64[64];
+#pragma unroll
+                            for (uint32_t u = 0; u < 64; u++) w64[u] = W[F + i + (c0 + j + u) * ld];
+#pragma unroll
+                            for (uint32_t u = 0; u < 64; u++) s = dfma(-w64[u], xs[c0 + j + u], s);
+                        }
                         for (; j + 16 <= acc; j += 16)
                         {
                             double w16[16];
@@ -837,6 +859,7 @@ namespace lexls
                     for (; j < acc; j++) s = dfma(-W[F + i + (c0 + j) * ld], xs[c0 + j], s);
                     xs[Fc + i] = s;
                 }
+                SSTAMP(0)
                 if constexpr (NT >= 256)
                 {
                     // Large levels: the triangular solve in blocks of 64 rows from the bottom.  ONE wavefront solves a diagonal block staged in
@@ -847,33 +870,68 @@ namespace lexls
                     for (uint32_t jb = ((rank - 1) / BS) * BS;; jb -= BS)
                     {
                         const uint32_t nb = rank - jb < BS ? rank - jb : BS;
-                        for (uint32_t e = tid; e < nb * nb; e += NT)
                         {
-                            const uint32_t i = e % nb, j = e / nb;
-                            Rb[i + j * BL] = W[F + jb + i + (Fc + jb + j) * ld];
+                            // thread = (row, column mod NT / 64) of the block: sixteen loads in flight per thread, no division per element
+                            // (one element at a time behind "e % nb, e / nb" the staging took 6 us per block)
+                            const uint32_t i = tid & 63u, j0 = tid >> 6;
+                            constexpr uint32_t JS = NT / 64;
+                            double st[BS / JS];
+#pragma unroll
+                            for (uint32_t u = 0; u < BS / JS; u++)
+                            {
+                                const uint32_t j = j0 + u * JS;
+                                st[u]            = (i < nb && j < nb) ? W[F + jb + i + (Fc + jb + j) * ld] : 0.0;
+                            }
+#pragma unroll
+                            for (uint32_t u = 0; u < BS / JS; u++)
+                            {
+                                const uint32_t j = j0 + u * JS;
+                                if (i < nb && j < nb) Rb[i + j * BL] = st[u];
+                            }
                         }
                         __syncthreads();
+                        SSTAMP(1)
                         if (tid < 64)
                         {
-                            double sv   = tid < nb ? xs[Fc + jb + tid] : 0.0;
-                            double rcur = Rb[tid + (nb - 1) * BL], dcur = Rb[(nb - 1) + (nb - 1) * BL]; // (column and diagonal one step ahead of their use)
-                            for (uint32_t j = nb; j--;)
-                            {
-                                const uint32_t jn  = j ? j - 1 : 0;
-                                const double rnext = Rb[tid + jn * BL], dnext = Rb[jn + jn * BL];
-                                const double xj    = rdlane(sv, (int)j) / dcur;
-                                if (tid == j) sv = xj;
-                                if (tid < j) sv = dfma(-rcur, xj, sv);
-                                rcur = rnext;
-                                dcur = dnext;
-                            }
+                            // lane = row of the block, its entries ABOVE the diagonal in registers (zero from the diagonal down: the update
+                            // below then needs no per-lane predicate — 64 of them, kept as 128 SGPRs, spilled), the chain fully unrolled: one
+                            // step = x_j from lane j (v_readlane, constant lane) times the reciprocal diagonal (or divided), one fma for the
+                            // rows above, lane j keeps x_j.  A lane's own entry is read before its step's fma can touch it.
+                            double sv = tid < nb ? xs[Fc + jb + tid] : 0.0;
+                            double rrow[BS];
+#pragma unroll
+                            for (uint32_t j = 0; j < BS; j++) rrow[j] = (tid < j && j < nb) ? Rb[tid + j * BL] : 0.0;
+                            double dg = tid < nb ? Rb[tid * (BL + 1)] : 1.0; // this lane's diagonal entry (RECIP: its reciprocal)
+                            if (RECIP) dg = 1.0 / dg;
+                            double xfin = 0.0;
+                            for_each_index<0, (int)BS>([&](auto jc) __attribute__((always_inline)) {
+                                constexpr int j = (int)BS - 1 - decltype(jc)::value;
+                                if ((uint32_t)j < nb) // (wave-uniform)
+                                {
+                                    const double xj = RECIP ? rdlane(sv, j) * rdlane(dg, j) : rdlane(sv, j) / rdlane(dg, j);
+                                    sv              = dfma(-rrow[j], xj, sv);
+                                    uint32_t tj = tid;
+                                    asm volatile("" : "+v"(tj) : "v"(xj)); // (ties the lane test to the chain: sixty-four of them hoisted = 128 SGPRs, spilled)
+                                    xfin = (tj == (uint32_t)j) ? xj : xfin;
+                                }
+                            });
+                            sv = xfin;
                             if (tid < nb) xs[Fc + jb + tid] = sv;
                         }
                         __syncthreads();
+                        SSTAMP(2)
                         for (uint32_t i = tid; i < jb; i += NT) // rows above the block: its columns, last first
                         {
                             double sv = xs[Fc + i];
                             uint32_t j = nb;
+                            for (; j >= 64; j -= 64) // (a full block: its 64 entries of the row in ONE trip)
+                            {
+                                double w64[64];
+#pragma unroll
+                                for (uint32_t u = 0; u < 64; u++) w64[u] = W[F + i + (Fc + jb + j - 1 - u) * ld];
+#pragma unroll
+                                for (uint32_t u = 0; u < 64; u++) sv = dfma(-w64[u], xs[Fc + jb + j - 1 - u], sv);
+                            }
                             for (; j >= 8; j -= 8)
                             {
                                 double w8[8];
@@ -886,6 +944,7 @@ namespace lexls
                             xs[Fc + i] = sv;
                         }
                         __syncthreads();
+                        SSTAMP(3)
                         if (jb == 0) break;
                     }
                 }
@@ -914,16 +973,55 @@ namespace lexls
                 }
                 acc += rank;
             }
-            if (tid == 0)
-                for (uint32_t k = a.totalrank[b]; k--;)
+            // x = P x (lexlse.h:1044): the transpositions k <-> perm[k], last first, on x by position — read the other way round: variable i
+            // follows them first to last from position i to its final position p, and x_i is what sits there.  Every thread for its own
+            // variables, on indices only (one thread swapping entries behind a load of perm[k] each was 128 of the 150 us of configs[1]'s solve)
+            {
+                const uint32_t T  = a.totalrank[b];
+                uint32_t *perm_l  = reinterpret_cast<uint32_t *>(xs + ((n + 1u) & ~1u)); // (the diagonal's place: free now; 16-byte aligned)
+                for (uint32_t k = tid; k < T; k += NT) perm_l[k] = perm[k];
+                __syncthreads();
+                // (UV variables per thread and pass: independent index chains side by side)
+                auto follow = [&](auto uv_c, uint32_t i0) __attribute__((always_inline)) {
+                    constexpr int UV = decltype(uv_c)::value;
+                    uint32_t p[UV];
+#pragma unroll
+                    for (int u = 0; u < UV; u++) p[u] = i0 + u * NT;
+                    for (uint32_t k = 0; k + 4 <= T; k += 4)
+                    {
+                        const uint4 pk4      = *reinterpret_cast<const uint4 *>(perm_l + k);
+                        const uint32_t pk[4] = {pk4.x, pk4.y, pk4.z, pk4.w};
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                            for (int u = 0; u < UV; u++) p[u] = (p[u] == k + kk) ? pk[kk] : ((p[u] == pk[kk]) ? k + kk : p[u]);
+                    }
+                    for (uint32_t k = T & ~3u; k < T; k++)
+                    {
+                        const uint32_t pk = perm_l[k];
+#pragma unroll
+                        for (int u = 0; u < UV; u++) p[u] = (p[u] == k) ? pk : ((p[u] == pk) ? k : p[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UV; u++)
+                        if (i0 + u * NT < n) a.x[(size_t)b * n + i0 + u * NT] = xs[p[u]];
+                };
+                const uint32_t rows = (n + NT - 1) / NT; // variables per thread (the last pass may reach beyond n: those are not stored)
+                uint32_t done       = 0;
+                for (; rows - done >= 4; done += 4) follow(std::integral_constant<int, 4>{}, tid + done * NT);
+                switch (rows - done)
                 {
-                    const uint32_t pk = perm[k];
-                    const double t    = xs[k];
-                    xs[k]             = xs[pk];
-                    xs[pk]            = t;
+                case 3: follow(std::integral_constant<int, 3>{}, tid + done * NT); break;
+                case 2: follow(std::integral_constant<int, 2>{}, tid + done * NT); break;
+                case 1: follow(std::integral_constant<int, 1>{}, tid + done * NT); break;
+                default: break;
                 }
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
+            }
+            SSTAMP(4)
+#ifdef LEXLS_SOLVE_STAMPS
+            if (tid == 0)
+                for (int i_ = 0; i_ < 5; i_++) a.lambda[(size_t)b * (n + cap) + 40 + i_] = (double)sst[i_];
+#endif
         }
 
         // -----------------------------------------------------------------------------------------
@@ -1647,16 +1745,49 @@ namespace lexls
             __syncthreads();
             for (uint32_t i = tid; i < nVarRank; i += NT) xs[nf + i] = out[i];
             __syncthreads();
-            if (tid == 0)
-                for (uint32_t k = a.totalrank[b]; k--;)
+            // x = P x (lexlse.h:1044): the transpositions k <-> perm[k], last first, on x by position — read the other way round: variable i
+            // follows them first to last from position i to its final position p, and x_i is what sits there.  Every thread for its own
+            // variables, on indices only (one thread swapping entries behind a load of perm[k] each was 128 of the 150 us of configs[1]'s solve)
+            {
+                const uint32_t T  = a.totalrank[b];
+                uint32_t *perm_l  = reinterpret_cast<uint32_t *>(xs + ((n + 1u) & ~1u)); // (the diagonal's place: free now; 16-byte aligned)
+                for (uint32_t k = tid; k < T; k += NT) perm_l[k] = perm[k];
+                __syncthreads();
+                // (UV variables per thread and pass: independent index chains side by side)
+                auto follow = [&](auto uv_c, uint32_t i0) __attribute__((always_inline)) {
+                    constexpr int UV = decltype(uv_c)::value;
+                    uint32_t p[UV];
+#pragma unroll
+                    for (int u = 0; u < UV; u++) p[u] = i0 + u * NT;
+                    for (uint32_t k = 0; k + 4 <= T; k += 4)
+                    {
+                        const uint4 pk4      = *reinterpret_cast<const uint4 *>(perm_l + k);
+                        const uint32_t pk[4] = {pk4.x, pk4.y, pk4.z, pk4.w};
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                            for (int u = 0; u < UV; u++) p[u] = (p[u] == k + kk) ? pk[kk] : ((p[u] == pk[kk]) ? k + kk : p[u]);
+                    }
+                    for (uint32_t k = T & ~3u; k < T; k++)
+                    {
+                        const uint32_t pk = perm_l[k];
+#pragma unroll
+                        for (int u = 0; u < UV; u++) p[u] = (p[u] == k) ? pk : ((p[u] == pk) ? k : p[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UV; u++)
+                        if (i0 + u * NT < n) a.x[(size_t)b * n + i0 + u * NT] = xs[p[u]];
+                };
+                uint32_t i0 = tid;
+                for (; i0 + 3 * NT < n + NT - 1 - ((n + NT - 1) % NT) + 0 && (n + NT - 1) / NT - (i0 - tid) / NT >= 4; i0 += 4 * NT) follow(std::integral_constant<int, 4>{}, i0);
+                switch (((n + NT - 1) / NT - (i0 - tid) / NT) & 3u)
                 {
-                    const uint32_t pk = perm[k];
-                    const double t    = xs[k];
-                    xs[k]             = xs[pk];
-                    xs[pk]            = t;
+                case 3: follow(std::integral_constant<int, 3>{}, i0); break;
+                case 2: follow(std::integral_constant<int, 2>{}, i0); break;
+                case 1: follow(std::integral_constant<int, 1>{}, i0); break;
+                default: break;
                 }
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += NT) a.x[(size_t)b * n + i] = xs[i];
+            }
         }
     } // namespace
 
@@ -1722,7 +1853,7 @@ namespace lexls
         return launch_lqr_t<1024, false>(a, true, do_solve, s);
     }
 
-    hipError_t launch_solve_generic(const LseArgs &a, hipStream_t s)
+    hipError_t launch_solve_generic(const LseArgs &a, hipStream_t s, bool reciprocal_diagonal)
     {
         const size_t lds = 16 * (size_t)a.nVar + 16 + (a.nVar + 1 <= 64 ? 0 : 8 * 64 * 65); // x by position + the diagonal of the level being solved (+ the 64 x 64 block of the blocked form)
         if (a.nVar + 1 <= 64)
@@ -1733,9 +1864,12 @@ namespace lexls
         }
         else
         {
-            hipError_t e = set_lds(solve_generic_kernel<256>, lds);
+            hipError_t e = reciprocal_diagonal ? set_lds(solve_generic_kernel<256, true>, lds) : set_lds(solve_generic_kernel<256>, lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((solve_generic_kernel<256>), dim3(a.batch), dim3(256), lds, s, a);
+            if (reciprocal_diagonal)
+                hipLaunchKernelGGL((solve_generic_kernel<256, true>), dim3(a.batch), dim3(256), lds, s, a);
+            else
+                hipLaunchKernelGGL((solve_generic_kernel<256>), dim3(a.batch), dim3(256), lds, s, a);
         }
         return hipGetLastError();
     }
