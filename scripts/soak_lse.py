@@ -9,7 +9,7 @@ import numpy as np
 import lexls_amd as hip
 from lexls_amd import problems as P
 from oracle import oracle_ctypes as oracle
-from test_gpu_random_sweep import _draw
+from test_gpu_random_sweep import _draw, assert_x_matches
 from test_gpu_parity import assert_factor_equal
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -104,7 +104,7 @@ while time.time() - t0 < budget:
             np.savez(os.path.join(ROOT, "gpurun_out", "soak_fail.npz"), lod=lod, dims=dims, cap_dims=cap_dims, n=n)
             sys.exit(1)
     else:
-        np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
+        assert_x_matches(s, ref["x"], ctx)
     np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"], err_msg=ctx)
     np.testing.assert_array_equal(s.getRanks()[0], ref["rank"], err_msg=ctx)
     if keep:

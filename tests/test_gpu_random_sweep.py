@@ -10,6 +10,17 @@ from test_gpu_parity import assert_factor_equal
 pytestmark = pytest.mark.gpu
 
 
+
+def assert_x_matches(s, x_ref, ctx):
+    """x against the oracle under the contract of the kernel that served the solve (include/lexls_hip.h, lexls_lse_set_kernel_policy):
+    the tolerance-contract kernel lqr_qtol — automatic dispatch of x-only solves whose levels all have 12 rows — within 1e-10 (relative to
+    max(1, |x|_inf)), pivots and ranks exact (checked by the callers); every other kernel bit for bit"""
+    if s.last_kernel().startswith("lqr_qtol"):
+        assert np.isfinite(s.get_x()).all(), ctx
+        assert np.abs(s.get_x() - x_ref).max() <= 1e-10 * max(1.0, float(np.abs(x_ref).max())), ctx
+    else:
+        np.testing.assert_array_equal(s.get_x(), x_ref, err_msg=ctx)
+
 def _draw(rng):
     n = int(rng.integers(1, 64))
     nobj = int(rng.integers(1, 7))
@@ -62,7 +73,7 @@ def test_random_sweep(hip, oracle, chunk):
         s.factorize_solve(keep_factor=keep)
         kernels.add(s.last_kernel().split("<")[0])
         ctx = f"chunk {chunk} case {case}: n={n} cap={cap_dims.tolist()} dims={dims.tolist()} policy={policy} keep={keep} fixed={bool(fixed)} kernel={s.last_kernel()}"
-        np.testing.assert_array_equal(s.get_x(), ref["x"], err_msg=ctx)
+        assert_x_matches(s, ref["x"], ctx)
         np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"], err_msg=ctx)
         np.testing.assert_array_equal(s.getRanks()[0], ref["rank"], err_msg=ctx)
         if keep:
