@@ -86,7 +86,7 @@ def main():
                 f"`VGPR_Count` = {kt['VGPR_Count']}, `Accum_VGPR_Count` = {kt['Accum_VGPR_Count']}, `SGPR_Count` = {kt['SGPR_Count']}, `LDS_Block_Size` = {kt['LDS_Block_Size']}.\n"
                 "rocprofv3 decodes the descriptor's VGPR granule count with a granule of 4 registers; the gfx950 granule is 8, so the ALLOCATED architectural VGPRs are "
                 "2 x `VGPR_Count` (the same factor explains round 1's `52` for a kernel the compiler reports at 102 and that is allocated 104). `LDS_Block_Size` is the STATIC "
-                "LDS of the code object; these kernels take their LDS dynamically at launch (lqr_qtol: 40,448 B per 64-thread workgroup for the IK shape = 4 x 10,112 B, one wavefront per SIMD), which the column does not show. "
+                "LDS of the code object; these kernels take their LDS dynamically at launch (lqr_qtol: 161,792 B per 256-thread workgroup for the IK shape = 4 wavefronts x 4 problems x 10,112 B, one wavefront per SIMD), which the column does not show. "
                 "lqr_qtol: 256 architectural VGPRs + 256 accumulation registers (a184..a255 hold the level-ahead pieces, managed by inline assembly; the compiler's own spill traffic uses a0..a28).\n\n")
         f.write(f"HBM traffic per launch: FETCH_SIZE = {f_raw:.1f} KB raw, WRITE_SIZE = {w_raw:.1f} KB raw. gfx950 tallies 16-B-per-lane loads at half "
                 f"(MI355X_MICROARCH.md, HBM): corrected fetch = {2*f_raw:.1f} KB -> **{hbm/1e6:.1f} MB per launch** (uncorrected: {(f_raw+w_raw)*1024/1e6:.1f} MB). "
@@ -106,6 +106,29 @@ def main():
         for r in st[:8]:
             f.write(f"{r['Name'][:90]:90s} calls={r['Calls']:>5s} avg_ns={r['AverageNs']:>14s} pct={r['Percentage']}\n")
         f.write("```\n")
+        # the large path (configs[1]) and the lock-step LexLSI batch (configs[4]): own traces of the same collection
+        lg = os.path.join(g, f"prof_large_{tag}", "large_kernel_stats.csv")
+        if os.path.exists(lg):
+            shutil.copy(lg, os.path.join(ROOT, "profiles", f"{tag}_large_kernel_stats.csv"))
+            f.write("\n## configs[1] (n = 512, 4 levels x 256 rows): `python3 scripts/time_large.py` (6 factorize+solve calls)\n\n```\n")
+            for r in rows(lg)[:10]:
+                f.write(f"{r['Name'][:90]:90s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:10.2f} pct={r['Percentage']}\n")
+            f.write("```\n")
+            mf = os.path.join(g, f"prof_large_mfma_{tag}", "mfma_counter_collection.csv")
+            if os.path.exists(mf):
+                c, nn = counters(mf, "large_gemm_mfma")
+                if c:
+                    f.write(f"\nMatrix-core counters of `large_gemm_mfma` (per launch, mean over {max(nn.values())} launches; `--pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES`): "
+                            + ", ".join(f"{k2} = {v2:.0f}" for k2, v2 in sorted(c.items())) + ". "
+                            "One `v_mfma_f64_16x16x4_f64` = 2048 flops per wavefront instruction: the instruction count x 2048 is the trailing update's flop count; the busy-cycle share says how little of "
+                            "the launch the matrix cores are occupied — the launch is bound by its LDS staging and barriers, not by the matrix cores.\n")
+        ls = os.path.join(g, f"prof_lsi_{tag}", "lsi_kernel_stats.csv")
+        if os.path.exists(ls):
+            shutil.copy(ls, os.path.join(ROOT, "profiles", f"{tag}_lsi_kernel_stats.csv"))
+            f.write("\n## configs[4] (1024 lock-step LexLSI instances): `python3 bench.py --workload lsi --steps 3 --warmup 1`\n\n```\n")
+            for r in rows(ls)[:8]:
+                f.write(f"{r['Name'][:90]:90s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:10.2f} pct={r['Percentage']}\n")
+            f.write("```\n")
     print(json.dumps(summary, indent=1))
 
 
