@@ -906,6 +906,46 @@ def test_large_path_with_an_empty_level(hip, oracle, empty, policy):
 
 
 @pytest.mark.gpu
+def test_large_path_row_that_repeats_an_earlier_level(hip, oracle):
+    """The documented caveat of the step-per-pivot path (include/lexls_hip.h, kernel policy): a row that exactly repeats a row of an earlier
+    level is rounding noise when its own level is reached; the sign of its reflector, beta = -sign(c0) |x|, follows the sign of that noise, and
+    tree sums and ordered chains may disagree on it.  What the contract still guarantees, and what this test pins: pivots, ranks and first
+    columns exact; x within 1e-10; every factor entry within 1e-10 (relative to the largest one) IN MAGNITUDE — a negated row of R with its
+    negated essential part is the only admissible difference; the bit-exact policy 5 gives the oracle's factor, signs included."""
+    n, dims = 150, [90, 90, 90]
+    lod = P.lse_batch(77, 1, n, dims)
+    lod[0, :, 90 + 7] = lod[0, :, 3]        # level 1, row 7 = level 0, row 3
+    lod[0, :, 180 + 11] = lod[0, :, 90 + 20]  # level 2, row 11 = level 1, row 20
+    ref = oracle.lse_run(lod, dims, n)
+    cap = sum(dims)
+    for policy in (0, 5):
+        s = hip.BatchedLexLSE(1, n, dims)
+        s.set_kernel_policy(policy)
+        s.setProblem(lod)
+        s.factorize_solve()
+        assert s.last_kernel().startswith("lqr_large<step-per-pivot" if policy == 0 else "lqr_large<multi-launch")
+        np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+        r, fc, tr = s.getRanks()
+        np.testing.assert_array_equal(r, ref["rank"])
+        np.testing.assert_array_equal(fc, ref["fcol"])
+        f, fr = s.get_lexqr()[0, :, :cap], ref["factor"][0, :, :cap]
+        if policy == 5:
+            np.testing.assert_array_equal(f, fr)
+            np.testing.assert_array_equal(s.get_x(), ref["x"])
+        else:
+            scale = max(1.0, float(np.abs(fr).max()))
+            assert np.abs(np.abs(f) - np.abs(fr)).max() <= 1e-10 * scale
+            assert np.abs(s.get_x() - ref["x"]).max() <= 1e-10 * max(1.0, float(np.abs(ref["x"]).max()))
+            # rows whose sign differs (if any) are whole rows of R: sign(f) = -sign(fr) on every entry of the row that is not noise
+            differs = (np.sign(f) != np.sign(fr)) & (np.abs(fr) > 1e-9 * scale)
+            rows = np.unique(np.nonzero(differs)[1])
+            for row in rows:
+                big = np.abs(fr[:, row]) > 1e-9 * scale
+                pivot_and_right = big & (np.arange(n + 1) >= np.argmax(big))
+                assert np.abs(f[pivot_and_right, row] + fr[pivot_and_right, row]).max() <= 1e-10 * scale, f"row {row}: not a negated row"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("keep", [False, True], ids=["x-only", "factor-kept"])
 def test_deep_hierarchies_on_the_left_looking_kernels(hip, oracle, keep):
     """More than 64 rows in all (six to eight levels of an IK-sized problem) do not fit the register-resident kernel's LDS image of the rows
