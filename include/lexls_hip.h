@@ -185,8 +185,13 @@ int lexls_lse_device_ptr(lexls_lse_t h, int which, void **d_ptr);
 const char *lexls_lse_last_kernel(lexls_lse_t h);
 /* Kernel policy — which CONTRACT a solve is held to, and which kernel family serves it.
  *   Contracts: (B) bit-identical to the arithmetic contract of oracle/lexlse_oracle.h (pivots, ranks, Householder scalars, factor, x, multipliers);
- *              (T) BASELINE north_star's: column permutation, ranks and first columns exact, x (and factor MAGNITUDES) within 1e-10.
- *   policy 0 = automatic dispatch.  (T) for x-only solves of the IK shape — n = 40, every level 12 rows, no fixed variables, no regularization:
+ *              (T) BASELINE north_star's: column permutation, ranks and first columns exact, x (and factor MAGNITUDES) within 1e-10
+ *                  (relative to max(1, |x|_inf)) — on problems whose own solution is determined that well.  An ill-conditioned problem
+ *                  (tiny pivots above the rank tolerance, rows / columns scaled over many decades), whose x moves by more than ~1e-11 when
+ *                  its DATA move by one ulp, is solved to a small multiple of that sensitivity instead (scripts/soak_qtol.py: 21 k
+ *                  random batches, 92 such problems beyond 1e-10, at most 20 x their one-ulp sensitivity; pivots and ranks exact in all).
+ *   policy 0 = automatic dispatch.  (T) for x-only solves whose levels ALL have 12 rows, no fixed variables, no regularization, n <= 40 (the IK shape of
+ *              BASELINE configs[2]/[3] and its smaller relatives):
  *              lqr_qtol, the bench kernel — and for problems beyond one CU's LDS (the step-per-pivot path with the trailing update on the matrix
  *              cores; there the reflector of a row that exactly repeats a row of an earlier level may come out with the opposite SIGN — that row of R
  *              and its essential part are negated, x and everything else agree: consumers of get_lexqr / hh scalars that need sign parity with the
