@@ -910,11 +910,6 @@ namespace lexls
             return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
         constexpr int PTC_MIN = 4; // fewest columns per workgroup (= wavefronts per workgroup) of the forms below: sizes the workspace
-#ifndef LEXLS_PERSIST_RSTRIDE
-#define LEXLS_PERSIST_RSTRIDE 16
-#endif
-        constexpr size_t PRS = LEXLS_PERSIST_RSTRIDE; // a workgroup's record sits PRS x 16 bytes from its neighbour's: G workgroups poll all G records
-                                                      // at once, and records in one line would make that line's memory channel the bottleneck
         /// 16-byte hand-off accesses: a record {norm, pos, tag | column} travels as ONE store and is read as ONE load (observed untorn on gfx950,
         /// MI355X_MICROARCH.md "R2's granule"); payload columns go one {value, tag} per lane.
         /// L2LOCAL = false: writers and readers on any XCD — system-scope store and load (sc0 sc1), served by memory.
