@@ -934,20 +934,92 @@ namespace lexls
             else
                 asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
         }
-        template <bool L2LOCAL> __device__ __forceinline__ void ld16_issue(u32x4 &v, const void *p)
-        {
-            if (L2LOCAL)
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
-            else
-                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory");
-        }
+        /// N loads in flight together, ONE wait — inside ONE asm statement: an output register of a load that is still in flight must not be
+        /// visible to the compiler (it may copy it — a phi of a conditional issue, a spill — before the data has arrived; the form with
+        /// separate issue and wait statements worked until the register allocation around it changed)
+#define LEXLS_LD16 "global_load_dwordx4 "
         template <bool L2LOCAL> __device__ __forceinline__ u32x4 ld16_x(const void *p)
         {
             u32x4 v;
-            ld16_issue<L2LOCAL>(v, p);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");
+            if (L2LOCAL)
+                asm volatile(LEXLS_LD16 "%0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+            else
+                asm volatile(LEXLS_LD16 "%0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
             return v;
         }
+        template <bool L2LOCAL> __device__ __forceinline__ void ld16_x2(u32x4 &a, u32x4 &b, const void *pa, const void *pb)
+        {
+            if (L2LOCAL)
+                asm volatile(LEXLS_LD16 "%0, %2, off sc1\n\t" LEXLS_LD16 "%1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(pa), "v"(pb) : "memory");
+            else
+                asm volatile(LEXLS_LD16 "%0, %2, off sc0 sc1\n\t" LEXLS_LD16 "%1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(pa), "v"(pb) : "memory");
+        }
+        template <bool L2LOCAL> __device__ __forceinline__ void ld16_x3(u32x4 &a, u32x4 &b, u32x4 &c, const void *pa, const void *pb, const void *pc)
+        {
+            if (L2LOCAL)
+                asm volatile(LEXLS_LD16 "%0, %3, off sc1\n\t" LEXLS_LD16 "%1, %4, off sc1\n\t" LEXLS_LD16 "%2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(pa), "v"(pb), "v"(pc) : "memory");
+            else
+                asm volatile(LEXLS_LD16 "%0, %3, off sc0 sc1\n\t" LEXLS_LD16 "%1, %4, off sc0 sc1\n\t" LEXLS_LD16 "%2, %5, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(pa), "v"(pb), "v"(pc) : "memory");
+        }
+        template <bool L2LOCAL> __device__ __forceinline__ void ld16_x4(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, const void *pa, const void *pb, const void *pc, const void *pd)
+        {
+            if (L2LOCAL)
+                asm volatile(LEXLS_LD16 "%0, %4, off sc1\n\t" LEXLS_LD16 "%1, %5, off sc1\n\t" LEXLS_LD16 "%2, %6, off sc1\n\t" LEXLS_LD16 "%3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(pa), "v"(pb), "v"(pc), "v"(pd) : "memory");
+            else
+                asm volatile(LEXLS_LD16 "%0, %4, off sc0 sc1\n\t" LEXLS_LD16 "%1, %5, off sc0 sc1\n\t" LEXLS_LD16 "%2, %6, off sc0 sc1\n\t" LEXLS_LD16 "%3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(pa), "v"(pb), "v"(pc), "v"(pd) : "memory");
+        }
+        /// Tear-proofing of the 16-byte granules.  An aligned global_store_dwordx4 / global_load_dwordx4 has been observed to travel as one piece
+        /// on gfx950 (MI355X_MICROARCH.md, "R2's granule"), but nothing in the ISA text promises it; so each granule's tag half also carries a
+        /// checksum of its payload half and of the tag: a reader that saw the new tag with an old payload (or the reverse) finds the checksum
+        /// wrong, treats the granule as "not there yet" and asks again (the bounded spins and the abort flag cover the rest).
+        /// (as few operations as possible: packing and checking sit on every pivot's critical path; a torn granule pairs halves of two DIFFERENT
+        /// publications, so any mixing of the payload's words will do.  Cost on configs[1]: 2.07 -> 2.20 ms; -DLEXLS_PERSIST_NOCHECK builds
+        /// without, for A/B.  scripts/persist_stamps.py counts granules whose tag is there and whose checksum is not: none seen so far)
+        /// record = {norm (8 bytes) | position (20 bits) + 12 checksum bits | tag (16 bits) + column inside the workgroup (8) + 8 checksum bits}
+        constexpr uint32_t kRecNoPos = 0xFFFFFu; // "no candidate"
+        __device__ __forceinline__ uint32_t record_check20(uint32_t lo, uint32_t hi, uint32_t p20, uint32_t tag)
+        {
+            const uint32_t h = lo ^ hi ^ (p20 << 7) ^ tag;
+            return (h ^ (h >> 20)) & 0xFFFFFu;
+        }
+        __device__ __forceinline__ u32x4 record_pack(double norm, uint32_t pos, uint32_t tag, uint32_t idx)
+        {
+            u32x4 q;
+            q.x = (unsigned)__double2loint(norm), q.y = (unsigned)__double2hiint(norm);
+            const uint32_t p20 = pos == 0xffffffffu ? kRecNoPos : pos;
+            const uint32_t c   = record_check20(q.x, q.y, p20, tag);
+            q.z = p20 | ((c >> 8) << 20);
+            q.w = (tag << 16) | ((idx & 255u) << 8) | (c & 255u);
+            return q;
+        }
+        __device__ __forceinline__ bool record_ok(const u32x4 &q, uint32_t tag)
+        {
+#ifdef LEXLS_PERSIST_NOCHECK
+            return (q.w >> 16) == tag; // (A/B builds: what the checksums cost)
+#endif
+            const uint32_t c = record_check20(q.x, q.y, q.z & kRecNoPos, tag);
+            return ((q.w >> 16) == tag) & ((q.z >> 20) == (c >> 8)) & ((q.w & 255u) == (c & 255u));
+        }
+        /// column granule = {value (8 bytes) | tag | low word ^ high word of the value}
+        __device__ __forceinline__ u32x4 value_pack(double v, uint32_t tag)
+        {
+            u32x4 q;
+            q.x = (unsigned)__double2loint(v), q.y = (unsigned)__double2hiint(v), q.z = tag;
+            q.w = q.x ^ q.y;
+            return q;
+        }
+        __device__ __forceinline__ bool value_ok(const u32x4 &q, uint32_t tag)
+        {
+#ifdef LEXLS_PERSIST_NOCHECK
+            return q.z == tag;
+#endif
+            return (q.z == tag) & ((q.x ^ q.y) == q.w);
+        }
+
         __device__ __forceinline__ unsigned persist_xcc_id()
         {
             unsigned v;
@@ -1021,7 +1093,7 @@ namespace lexls
 
             uint32_t c = s.ColIndex, rank = 0, stop = 0, exhausted = 0;
 #ifdef LEXLS_PERSIST_STAMPS
-            long long pst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = clock64();
+            long long pst[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = clock64();
 #define PSTAMP(i) { const long long t_ = clock64(); pst[i] += t_ - pt0; pt0 = t_; }
 #else
 #define PSTAMP(i)
@@ -1098,8 +1170,7 @@ namespace lexls
                 cand_p = myp, cand_j = myj;
                 if (wave == 0)
                 {
-                    u32x4 q;
-                    q.x = (unsigned)__double2loint(myv), q.y = (unsigned)__double2hiint(myv), q.z = myp, q.w = ((cnt + 1u) << 8) | (myk & 255u); // (no candidate: pos says so, the index is not looked at)
+                    const u32x4 q = record_pack(myv, myp, cnt + 1u, myk & 255u); // (no candidate: the position says so, the index is not looked at)
                     PersistCand *box = cand + (size_t)(cnt & 1u) * G * MBS + t; // slot t of every reader's row
 #pragma unroll
                     for (int kq = 0; kq < 4; kq++)
@@ -1121,9 +1192,7 @@ namespace lexls
                 for (uint32_t i = lane; i < Rn; i += 64)
                 {
                     const double v0 = srcc[i];
-                    u32x4 q;
-                    q.x = (unsigned)__double2loint(v0), q.y = (unsigned)__double2hiint(v0), q.z = cnt + 1u, q.w = 0u;
-                    st16_x<ONEXCD>(mycol + i, q);
+                    st16_x<ONEXCD>(mycol + i, value_pack(v0, cnt + 1u));
                     fr = dfma(v0, v0, fr);
                     if (i > 0) tl = dfma(v0, v0, tl);
                 }
@@ -1132,9 +1201,7 @@ namespace lexls
                 if (lane < 2)
                 {
                     const double v0 = lane == 0 ? fr : tl;
-                    u32x4 q;
-                    q.x = (unsigned)__double2loint(v0), q.y = (unsigned)__double2hiint(v0), q.z = cnt + 1u, q.w = 0u;
-                    st16_x<ONEXCD>(mycol + Rn + lane, q);
+                    st16_x<ONEXCD>(mycol + Rn + lane, value_pack(v0, cnt + 1u));
                 }
             };
             publish_record(0, c);
@@ -1156,19 +1223,34 @@ namespace lexls
                     uint32_t ok = 0;
                     for (uint32_t spin = 0; spin < (1u << 18); spin++)
                     {
-#pragma unroll
-                        for (int kq = 0; kq < 4; kq++)
                         {
-                            const uint32_t w = lane + 64u * kq;
-                            if (kq == 0 || 64u * kq < G) // (wave-uniform)
-                                ld16_issue<ONEXCD>(q[kq], base + (w < G ? w : 0));
+                            const PersistCand *a0 = base + lane, *a1 = base + (lane + 64u < G ? lane + 64u : 0u), *a2 = base + (lane + 128u < G ? lane + 128u : 0u),
+                                              *a3 = base + (lane + 192u < G ? lane + 192u : 0u);
+                            if (G <= 64u) // (wave-uniform: as many loads as the row has records)
+                                q[0] = ld16_x<ONEXCD>(base + (lane < G ? lane : 0u));
+                            else if (G <= 128u)
+                                ld16_x2<ONEXCD>(q[0], q[1], a0, a1);
+                            else if (G <= 192u)
+                                ld16_x3<ONEXCD>(q[0], q[1], q[2], a0, a1, a2);
+                            else
+                                ld16_x4<ONEXCD>(q[0], q[1], q[2], q[3], a0, a1, a2, a3);
                         }
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3])::"memory");
                         bool mine = true;
 #pragma unroll
-                        for (int kq = 0; kq < 4; kq++) mine = mine && (lane + 64u * kq >= G || (q[kq].w >> 8) == tag);
+                        for (int kq = 0; kq < 4; kq++) mine = mine && (lane + 64u * kq >= G || (q[kq].w >> 16) == tag);
+                        if (__ballot(!mine) == 0ull) // every tag is there: now the checksums (once per pivot, not once per poll)
+                        {
+#pragma unroll
+                            for (int kq = 0; kq < 4; kq++) mine = mine && (lane + 64u * kq >= G || record_ok(q[kq], tag));
+                        }
 #ifdef LEXLS_PERSIST_STAMPS
                         pst[2] += 1; // polls
+                        {
+                            bool torn = false; // the tag is there, the checksum is not: halves of two publications
+#pragma unroll
+                            for (int kq = 0; kq < 4; kq++) torn = torn || (lane + 64u * kq < G && (q[kq].w >> 16) == tag && !record_ok(q[kq], tag));
+                            if (__ballot(torn) != 0ull) pst[12] += 1;
+                        }
 #endif
                         if (__ballot(!mine) == 0ull)
                         {
@@ -1185,12 +1267,12 @@ namespace lexls
                     {
                         const uint32_t w = lane + 64u * kq;
                         const double v   = __hiloint2double((int)q[kq].y, (int)q[kq].x);
-                        const uint32_t p = q[kq].z;
+                        const uint32_t p = (q[kq].z & kRecNoPos) == kRecNoPos ? 0xffffffffu : (q[kq].z & kRecNoPos);
                         if (ok && w < G && p != 0xffffffffu && (v > bv || (v == bv && p < bp)))
                         {
                             bv = v;
                             bp = p;
-                            bi = w * PTC + (q[kq].w & 255u);
+                            bi = w * PTC + ((q[kq].w >> 8) & 255u);
                             bw = w;
                         }
                     }
@@ -1235,23 +1317,14 @@ namespace lexls
                     uint32_t good = 0;
                     for (uint32_t spin = 0; spin < (1u << 18); spin++)
                     {
-#pragma unroll
-                        for (uint32_t r = 0; r < CR; r++)
-                        {
-                            const uint32_t i = tid + r * NT;
-                            ld16_issue<ONEXCD>(g[r], pcol + (i < R ? i : R));
-                        }
-                        ld16_issue<ONEXCD>(g[CR], pcol + R);
-                        ld16_issue<ONEXCD>(g[CR + 1], pcol + R + 1u);
+                        static_assert(CR == 1, "one row of the column per thread in the batch");
+                        ld16_x3<ONEXCD>(g[0], g[1], g[2], pcol + (tid < R ? tid : R), pcol + R, pcol + R + 1u);
                         bool all = true;
 #pragma unroll
-                        for (uint32_t r = 0; r < CR + 2; r++)
-                        {
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[r])::"memory");
-                            all = all & (g[r].z == tag);
-                        }
+                        for (uint32_t r = 0; r < CR + 2; r++) all = all & value_ok(g[r], tag);
 #ifdef LEXLS_PERSIST_STAMPS
                         pst[11] += 1; // column read rounds
+                        if ((g[0].z == tag && !value_ok(g[0], tag)) || (g[1].z == tag && !value_ok(g[1], tag)) || (g[2].z == tag && !value_ok(g[2], tag))) pst[13] += 1; // torn value granules seen by this thread
 #endif
                         if (all)
                         {
@@ -1281,7 +1354,7 @@ namespace lexls
                     for (uint32_t spin = 0; spin < (1u << 18); spin++)
                     {
                         q = ld16_x<ONEXCD>(pcol + i);
-                        if (q.z == tag)
+                        if (value_ok(q, tag))
                         {
                             good = 1;
                             break;
@@ -1428,7 +1501,7 @@ namespace lexls
             }
 #ifdef LEXLS_PERSIST_STAMPS
             if (t == 1 && tid == 0)
-                for (int i_ = 0; i_ < 12; i_++) a.lambda[16 * level + i_] = (double)pst[i_];
+                for (int i_ = 0; i_ < 14; i_++) a.lambda[16 * level + i_] = (double)pst[i_];
             if (tid == 0 && level == 0 && 64u + 2u * G < a.cap) // where the workgroups ran and how long each waited for the records
             {
                 unsigned hw;
@@ -1757,6 +1830,7 @@ namespace lexls
             static const int want_one = std::getenv("LEXLS_LARGE_ONE_XCD") ? std::atoi(std::getenv("LEXLS_LARGE_ONE_XCD")) : 0; // (measured: no gain, see the kernel's comment)
             const int xcds            = want_one ? persist_xcds() : 0;
             PersistForm f{0, 0, 0, 0, 0};
+            if (n + 1u >= 0xFFFFFu || maxdim >= 0xFFFFu) return f; // (the record's 20-bit position and 16-bit tag fields)
             auto try_form = [&](int nw, int cpw, bool one) {
                 if (f.nw) return;
                 const uint32_t ptc = (uint32_t)(nw * cpw), G = (n + ptc) / ptc;

@@ -11,6 +11,7 @@ w = s.getWorkspace()[0]
 names = ["flush pending", "wait for the records", "POLLS x1000", "read column + norms", "publish column", "dot + wave sums", "scalars", "maps + pivot row + norms", "barrier C", "publish record", "column update", "COLUMN READS x1000"]
 for lvl in range(2):
     v = w[16 * lvl: 16 * lvl + 12]
+    print("level", lvl, "torn records / torn value granules seen by workgroup 1 (tag present, checksum wrong):", int(w[16 * lvl + 12]), int(w[16 * lvl + 13]))
     print("level", lvl, "cycles per pivot:", {nm: round(x / 256 * (1000 if "x1000" in nm else 1)) for nm, x in zip(names, v)}, "total/pivot", round((v.sum() - v[2] - v[11]) / 256))
 # placement of the workgroups (HW_ID: cu_id bits 11:8, sh 12, se 15:13) and each one's wait for the records, level 0
 import collections
