@@ -1245,12 +1245,14 @@ namespace lexls
                         }
 #ifdef LEXLS_PERSIST_STAMPS
                         pst[2] += 1; // polls
+#ifdef LEXLS_PERSIST_TORN_COUNT
                         {
                             bool torn = false; // the tag is there, the checksum is not: halves of two publications
 #pragma unroll
                             for (int kq = 0; kq < 4; kq++) torn = torn || (lane + 64u * kq < G && (q[kq].w >> 16) == tag && !record_ok(q[kq], tag));
                             if (__ballot(torn) != 0ull) pst[12] += 1;
                         }
+#endif
 #endif
                         if (__ballot(!mine) == 0ull)
                         {
@@ -1324,7 +1326,9 @@ namespace lexls
                         for (uint32_t r = 0; r < CR + 2; r++) all = all & value_ok(g[r], tag);
 #ifdef LEXLS_PERSIST_STAMPS
                         pst[11] += 1; // column read rounds
+#ifdef LEXLS_PERSIST_TORN_COUNT
                         if ((g[0].z == tag && !value_ok(g[0], tag)) || (g[1].z == tag && !value_ok(g[1], tag)) || (g[2].z == tag && !value_ok(g[2], tag))) pst[13] += 1; // torn value granules seen by this thread
+#endif
 #endif
                         if (all)
                         {
