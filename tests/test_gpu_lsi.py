@@ -372,6 +372,39 @@ def test_resident_iterations_match_host_driver(hip, oracle, monkeypatch, simple_
         np.testing.assert_array_equal(res["active"][b], np.concatenate(o["active"]))
 
 
+@pytest.mark.parametrize("simple_bounds", [True, False])
+def test_resident_iterations_with_and_without_prefix_reuse(hip, oracle, monkeypatch, simple_bounds):
+    """the resident iterations tell every factorization which leading levels are unchanged since the previous one (the level of
+    the constraint that was activated / removed), and those levels are read back instead of factorized (lexls_lse_set_prefix_reuse).  The
+    reference refactorizes everything (README.md:14).  Same trajectories, x, v and working sets, bit for bit, with the reuse on (default)
+    and off (LEXLS_LSI_PREFIX_REUSE=0), IK-sized problems with several general levels, cold and warm-started; and as the oracle-backed driver."""
+    n, dims, batch = 40, [12, 12, 12, 12, 12], 24
+    problems = [P.lsi_problem(4100 + b, n, dims, simple_bounds=simple_bounds) for b in range(batch)]
+    pk = lexlsi.pack_batch(n, problems)
+    pert = lexlsi.pack_batch(n, [P.lsi_problem(4100 + b, n, dims, simple_bounds=simple_bounds, perturb=0.9) for b in range(batch)])
+    runs = {}
+    for reuse in ("1", "0"):
+        monkeypatch.setenv("LEXLS_LSI_PREFIX_REUSE", reuse)
+        srv = lexlsi.LsiBatch(n, pk.dims, pk.types, batch)  # (the switch is read when the batch object is created)
+        cold = srv.run(pk)
+        guess = np.where(cold["active"] == 3, 0, cold["active"]).astype(np.uint8)
+        warm = srv.run(pert, active_guess=guess, x0=cold["x"])
+        assert srv.stats()["device_step"] > 0
+        srv.close()
+        runs[reuse] = (cold, warm)
+    for a, b2 in zip(runs["1"], runs["0"]):
+        assert a["info"] == b2["info"]
+        np.testing.assert_array_equal(a["x"], b2["x"])
+        np.testing.assert_array_equal(a["v"], b2["v"])
+        np.testing.assert_array_equal(a["active"], b2["active"])
+    assert max(i["factorizations"] for i in runs["1"][0]["info"]) > 5  # (the reuse had factorizations to act on)
+    for b in range(0, batch, 5):
+        o = oracle.lsi_run(n, problems[b])
+        assert runs["1"][0]["info"][b] == o["info"]
+        np.testing.assert_array_equal(runs["1"][0]["x"][b], o["x"])
+        np.testing.assert_array_equal(runs["1"][0]["active"][b], np.concatenate(o["active"]))
+
+
 def test_resident_iterations_beyond_the_wave_kernel_shapes(hip, oracle):
     """resident iterations with equality problems the register-resident wave kernel does not take (nVar + 1 > 64: the generic kernel, which
     reads the assembled problem — the row gather is then its own launch again) and with more than 64 constraints per instance."""
