@@ -695,6 +695,18 @@ extern "C"
         return LEXLS_OK;
     }
 
+    /// Which tolerance-contract kernels a factorization of this handle may take (launch_lqr_wave's `tolerance`): policies 6 / 7 / 8 name one;
+    /// automatic dispatch (policy 0) takes them wherever they serve unless the process runs under LEXLS_QTOL=0 (read at every call, so that a
+    /// caller may change it between solves); every other policy stays on the bit-exact kernels
+    static int tolerance_mode(lexls_lse_t h)
+    {
+        if (h->fused_gather) return 0;
+        if (h->force_generic == 6 || h->force_generic == 7 || h->force_generic == 8) return h->force_generic;
+        if (h->force_generic != 0) return 0;
+        const char *e = std::getenv("LEXLS_QTOL");
+        return (e && std::atoi(e) == 0) ? 0 : 1;
+    }
+
     /// opportunistic_solve: the caller only asked for the factor; kernels that produce x on the way at no extra launch do (the wave kernels
     /// always, the generic kernel on request), so that a later lexls_lse_solve of the same factor has nothing left to do
     static int run_lqr(lexls_lse_t h, bool write_factor, bool do_solve, bool opportunistic_solve = false)
@@ -711,18 +723,14 @@ extern "C"
         {
             const int ll = h->fused_gather ? -1 : (h->force_generic == 2 ? -1 : (h->force_generic == 3 ? 1 : (h->force_generic == 4 ? 2 : 0)));
             // the tolerance-contract kernel (lqr_qtol_impl.h): automatic dispatch and policy 6; LEXLS_QTOL=0 keeps every solve bit-exact
-            static const bool qtol_env = !(std::getenv("LEXLS_QTOL") && std::atoi(std::getenv("LEXLS_QTOL")) == 0);
-            const bool tol_ok = !h->fused_gather && (h->force_generic == 6 || (h->force_generic == 0 && qtol_env));
-            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, ll, h->stream, &variant, tol_ok)); // always solves as well
+            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, ll, h->stream, &variant, tolerance_mode(h))); // always solves as well
         }
         else if (shape_kernels && h->force_generic != 2 && h->max_rows > 64 && h->max_level_dim <= 16 && a.nObj <= 16 &&
                  deep_kernel_supports(a, h->max_level_dim, write_factor, h->has_fixed))
         {
             // deep hierarchies (more than 64 rows in all): the left-looking kernels, whose LDS holds pivot rows only (x-only solves of the IK
             // shape: the tolerance-contract kernel under the same rules as above — it reads a level's rows when the level starts, too)
-            static const bool qtol_env2 = !(std::getenv("LEXLS_QTOL") && std::atoi(std::getenv("LEXLS_QTOL")) == 0);
-            const bool tol_ok2 = !h->fused_gather && (h->force_generic == 6 || (h->force_generic == 0 && qtol_env2));
-            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, 2, h->stream, &variant, tol_ok2));
+            HIP_TRY(launch_lqr_wave(a, h->max_level_dim, write_factor, h->has_fixed, 2, h->stream, &variant, tolerance_mode(h)));
         }
         else if (shape_kernels && h->reg_type == 0 && !generic_fits_lds(a, h->max_rows) && large_kernel_supports(a, h->max_level_dim, h->has_fixed))
         {

@@ -26,10 +26,11 @@ namespace lexls
     bool wave_kernel_supports(const LseArgs &a, uint32_t max_rows, uint32_t max_level_dim, bool has_fixed);
     bool deep_kernel_supports(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed);
     bool wave_dispatch_is_register_resident(const LseArgs &a, uint32_t max_level_dim, bool has_fixed, int left_looking);
-    /// allow_tolerance: x-only solves of the shapes lqr_qtol_impl.h serves may take that kernel (pivots / ranks exact, x within 1e-10 instead of
-    /// bit-identical to the oracle); false = bit-exact kernels only
+    /// tolerance: x-only solves of the shapes lqr_mfma_impl.h / lqr_qtol_impl.h serve may take those kernels (pivots / ranks exact, x within 1e-10
+    /// instead of bit-identical to the oracle).  0 = bit-exact kernels only; 1 = automatic (lqr_mfma where it serves, else lqr_qtol); 6 = lqr_qtol
+    /// only; 7 / 8 = lqr_mfma with two / one problem per wavefront, else lqr_qtol
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
-                               const char **variant, bool allow_tolerance = false);
+                               const char **variant, int tolerance = 0);
 
     // lqr_large.hip — problems too large for one CU's LDS: one launch per stage, the whole chip per problem
     bool generic_fits_lds(const LseArgs &a, uint32_t max_rows);

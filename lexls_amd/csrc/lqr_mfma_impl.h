@@ -1,0 +1,712 @@
+// TWO (or one) PROBLEMS PER WAVEFRONT, TWO (or four) WAVEFRONTS PER SIMD, Gauss step on the matrix cores: x-only, tolerance-contract
+// lexicographic-QR kernel for IK-sized batches — the bench kernel since round 4 (lexlse.h:117-506 factorize() + :1015-1045 solve()).
+//
+// Contract (T) of include/lexls_hip.h (BASELINE north_star): column permutation, ranks and first columns EXACTLY those of the reference
+// algorithm (first-maximum column pivoting on down-dated norms — compared BY VALUE, ties by position —, rank test on the fresh squared norm
+// against tol_linear_dependence), x within 1e-10.
+//
+// Why another mapping.  lqr_qtol (four problems per wavefront, ONE wavefront per SIMD) spends half of its cycles exposed to latencies that
+// nothing hides, and four in five of its vector instructions are not fma's.  4096 problems on 1024 SIMDs are four problems per SIMD however
+// they are cut; here they are cut as 2 wavefronts x 2 problems (LP = 32 lanes per problem; LP = 64: 4 wavefronts x 1 problem), so that
+//   * a second wavefront issues while the first waits for its pivot chain (LDS broadcast, 1/sqrt, butterfly);
+//   * 32-bit vector instructions (selects, DPP moves, index work) issue every 2 cycles instead of every 4 (MI355X_MICROARCH.md, constants);
+//   * the Gauss elimination of a level's rows by the finished levels (lexlse.h:431-471: two thirds of the model's flops) leaves the vector
+//     unit: C[12 x 48] -= L[12 x 12] N_e[12 x 48] per finished level e is 3 k-steps x (1..3) column tiles of v_mfma_f64_16x16x4_f64 with one
+//     problem spread over the whole wavefront.  No DPP row broadcasts, no multiplier chain: the finished levels are kept REDUCED
+//     (N_e = R_e^-1 [T_e | rhs_e], identity in the pivot columns), so a row's multipliers are its own entries in the pivot columns.
+// The wavefront alternates between two modes that exchange data through LDS:
+//   "LP mode"     lane l of a problem's LP lanes, slot s  <->  the column whose position in the reference's permuted order (lexlse.h:222-232)
+//                 was Fc + LP s + l when the level started (free columns are contiguous from Fc on: compaction for free).  Householder QR with
+//                 column pivoting of the level, all MD rows of a column in the lane's registers.
+//   "serial mode" the wavefront works on ONE problem at a time in the matrix-core layout (lane = (column c of a 16-position tile, row group g),
+//                 register v = row g + 4 v): level loads, Gauss step.
+//
+// Level k of a problem:
+//   1. its rows were requested one level ahead by LDS-DMA (global_load_lds_dwordx4: 16-byte pieces of columns straight into LDS, [column][MD]);
+//   2. serial mode: C <- rows by POSITION; for every finished level e (ascending): multipliers = C's entries at e's pivot positions (through
+//      an LDS scratch: C layout -> A-operand layout), C -= L_e N_e on the matrix cores; C -> LDS by position;
+//   3. LP mode: 12 pivot steps.  Per step: decision (max butterfly over the down-dated norms, then a min butterfly over the positions of the
+//      lanes that hold the maximum), the winner's lane stores its column to the problem's broadcast slot, every lane reads it back, fresh norm
+//      / rank test / 1/sqrt in every lane, reflector in raw form H a = a + q (w.a) w, row j normalised by 1/R_jj, and a JORDAN step on the
+//      rows above (a[i] -= U_i[p] U_j): after the last pivot the level block IS N_k — no triangular solve, no image of R;
+//   4. N_k goes to LDS, indexed by a per-level local column index (byte k of a column's index word, as in lqr_quad).
+// solve(): x_pivots(k) = rhs'_k - N_k x_later, k descending (lexlse.h:1015-1045 on the reduced rows), x kept by physical column.
+//
+// Shapes: every level of every problem has exactly MD rows (LseArgs::uniform_dim), no fixed variables, no regularization, n + 1 <= 48,
+// cap even, 16-byte aligned input, n <= 47.  Anything else takes the other kernels.
+#pragma once
+#include "lqr_wave_common.h"
+
+#include <cstdlib>
+
+namespace lexls
+{
+    namespace
+    {
+        typedef double mf_d2 __attribute__((ext_vector_type(2)));
+        typedef double mf_d4 __attribute__((ext_vector_type(4)));
+        typedef unsigned mf_u2 __attribute__((ext_vector_type(2)));
+        typedef unsigned mf_u4 __attribute__((ext_vector_type(4)));
+
+        __device__ __forceinline__ void mf_lds_fence()
+        {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            asm volatile("" ::: "memory");
+        }
+
+        /// 1 / x to ~2^-50 (v_rcp_f64 + one Newton step): the factor of a rank-one update, whose own rounding is of that size
+        __device__ __forceinline__ double mf_rcp1(double x)
+        {
+            const double y = __builtin_amdgcn_rcp(x);
+            return dfma(y, dfma(-x, y, 1.0), y);
+        }
+
+        /// maximum over the LP lanes of a problem, in every lane: butterfly inside the 16-lane DPP rows, then v_permlane16_swap / v_permlane32_swap
+        /// (both operands the same value: whichever rows the instruction exchanges, the two results hold the two partners of every lane)
+        template <int LP>
+        __device__ __forceinline__ double mf_grp_max(double v)
+        {
+            v = dpp_max<0xB1>(v);  // quad_perm [1,0,3,2]
+            v = dpp_max<0x4E>(v);  // quad_perm [2,3,0,1]
+            v = dpp_max<0x141>(v); // row_half_mirror
+            v = dpp_max<0x140>(v); // row_mirror
+            if constexpr (LP >= 32)
+            {
+                const mf_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+                const mf_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+                v              = vmax(__hiloint2double((int)hi.x, (int)lo.x), __hiloint2double((int)hi.y, (int)lo.y));
+            }
+            if constexpr (LP >= 64)
+            {
+                const mf_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+                const mf_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+                v              = vmax(__hiloint2double((int)hi.x, (int)lo.x), __hiloint2double((int)hi.y, (int)lo.y));
+            }
+            return v;
+        }
+        template <int LP>
+        __device__ __forceinline__ unsigned mf_grp_minu(unsigned v)
+        {
+            v = dpp_minu<0xB1>(v);
+            v = dpp_minu<0x4E>(v);
+            v = dpp_minu<0x141>(v);
+            v = dpp_minu<0x140>(v);
+            if constexpr (LP >= 32)
+            {
+                const mf_u2 r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+                v             = r.x < r.y ? r.x : r.y;
+            }
+            if constexpr (LP >= 64)
+            {
+                const mf_u2 r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+                v             = r.x < r.y ? r.x : r.y;
+            }
+            return v;
+        }
+
+        /// f(integral_constant<int, I>) for I = B, B+1, ... while pred(I) holds
+        template <int B, int E, class P, class F>
+        __device__ __forceinline__ void mf_for_each_while(P &&pred, F &&f)
+        {
+            if constexpr (B < E)
+            {
+                if (pred(std::integral_constant<int, B>{}))
+                {
+                    f(std::integral_constant<int, B>{});
+                    mf_for_each_while<B + 1, E>(pred, f);
+                }
+            }
+        }
+
+        constexpr double kMfSentinel = -1.0e300; // below every down-dated norm; stays there under further down-dates
+        constexpr int kMfMaxObj      = 8;
+
+        // per-level phase stamps of the diagnostic build (-DLEXLS_WAVE_STAMPS): lambda[11 + 4 k + {0 Gauss step, 1 level start, 2 Householder, 3 level end}]
+#ifdef LEXLS_WAVE_STAMPS
+#define MF_LSTAMP(ph)                                                                                     \
+    {                                                                                                     \
+        const unsigned long long t_ = clock64();                                                          \
+        if (gl == 0 && live) a.lambda[(size_t)b * (n + cap) + 11 + 4 * k + (ph)] = (double)(t_ - lst_t0); \
+        lst_t0 = t_;                                                                                      \
+    }
+#else
+#define MF_LSTAMP(ph)
+#endif
+
+        /// LP lanes per problem (32: two problems per wavefront, two wavefronts per SIMD; 64: one problem, four wavefronts per SIMD);
+        /// NV: the number of variables when the instantiation serves ONE n (0: taken from the arguments)
+        template <int LP, int MD, int NV>
+        __global__ __launch_bounds__(256, (LP == 64 ? 4 : 2)) void lqr_mfma_kernel(LseArgs a, uint32_t nd_doubles, uint32_t group_bytes)
+        {
+            static_assert((LP == 32 || LP == 64) && (MD == 12 || MD == 16), "mappings / level sizes served");
+            constexpr int G   = 64 / LP;            // problems per wavefront
+            constexpr int NSM = (48 + LP - 1) / LP; // slots of a lane
+            constexpr int NT  = 3;                  // 16-position tiles of the matrix-core layout (n + 1 <= 48)
+            constexpr int HP  = MD / 2;             // 16-byte pieces per column of a level
+            constexpr int CB  = 8 * MD;             // bytes per column of a level
+            constexpr int NV4 = MD / 4;             // accumulator registers that hold rows of the level
+            extern __shared__ double smem[];
+            typedef __attribute__((address_space(3))) char lds_char;
+            const int lds0 = (int)(unsigned)(size_t)(lds_char *)smem;
+            auto D   = [&](int off) -> __attribute__((address_space(3))) double & { return *(__attribute__((address_space(3))) double *)(size_t)(unsigned)off; };
+            auto D2  = [&](int off) -> __attribute__((address_space(3))) mf_d2 & { return *(__attribute__((address_space(3))) mf_d2 *)(size_t)(unsigned)off; };
+            auto B8  = [&](int off) -> __attribute__((address_space(3))) uint8_t & { return *(__attribute__((address_space(3))) uint8_t *)(size_t)(unsigned)off; };
+            auto U64 = [&](int off) -> __attribute__((address_space(3))) unsigned long long & { return *(__attribute__((address_space(3))) unsigned long long *)(size_t)(unsigned)off; };
+            auto U4  = [&](int off) -> __attribute__((address_space(3))) mf_u4 & { return *(__attribute__((address_space(3))) mf_u4 *)(size_t)(unsigned)off; };
+
+            const int lane    = threadIdx.x & 63;
+            const int wv      = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const uint32_t wq = blockIdx.x * 4u + (uint32_t)wv; // this wavefront's group of G problems
+            if (wq * (uint32_t)G >= a.batch) return;
+            const int g    = lane / LP; // problem inside the wavefront (LP mode)
+            const int gl   = lane % LP;
+            const int c16  = lane & 15; // serial mode: column inside a 16-position tile
+            const int gg   = lane >> 4; //              row group (register v holds row gg + 4 v)
+            const int n    = NV ? NV : (int)a.nVar;
+            const int cap  = (int)a.cap;
+            const int nObj = (int)a.nObj;
+            const uint32_t b  = wq * (uint32_t)G + (uint32_t)g;
+            const uint32_t bb = b < a.batch ? b : a.batch - 1u;
+            const bool live   = b < a.batch && !(a.skip && a.skip[bb]);
+            const uint32_t pstride = (uint32_t)cap * (uint32_t)(n + 1);
+            const double *inw      = a.in + (size_t)wq * (uint32_t)G * pstride; // wave-uniform base
+            const uint32_t poff    = (bb - wq * (uint32_t)G) * pstride;
+
+            // ---- level 0: lane = column (its position layout is the identity), straight from HBM ----
+            double blk[NSM][MD];
+#pragma unroll
+            for (int s = 0; s < NSM; s++)
+            {
+                const int P       = LP * s + gl;
+                const int c       = P <= n ? P : n;
+                const mf_d2 *src2 = reinterpret_cast<const mf_d2 *>(inw + (poff + (uint32_t)(c * cap)));
+#pragma unroll
+                for (int r = 0; r < MD / 2; r++)
+                {
+                    const mf_d2 v     = src2[r];
+                    blk[s][2 * r]     = v.x;
+                    blk[s][2 * r + 1] = v.y;
+                }
+            }
+
+            // ---- LDS carve-up of a problem's slice (byte offsets; launch_mfma_t computes group_bytes) ----
+            //   [0, o_pf)   the reduced rows N_e of the finished levels (row q of level e: S_e doubles at noff_e + q S_e), each followed by its
+            //               inverse map (S_e bytes: column index in N_e -> physical column)
+            //   o_pf        [column][MD]: the level loaded ahead / scratch of the Gauss step ([pivot][16 rows], then [position][MD]) / x by physical column
+            //   o_bc        MD doubles: broadcast slot of the pivot steps
+            //   o_phys      48 B: physical column at each position (column_permutations go straight to HBM: one byte-sized store per pivot)
+            //   o_meta      per level {Fc | rank << 8 | S << 16, offset of N_e (doubles), -, -}
+            //   o_emap      per physical column: byte k = its column index in N_k
+            const int pfb    = CB * (n + 1) > 128 * MD ? CB * (n + 1) : 128 * MD;
+            const int o_pf   = 8 * (int)nd_doubles;
+            const int o_bc   = o_pf + pfb;
+            const int o_phys = o_bc + CB;
+            const int o_meta = o_phys + 48;
+            const int o_emap = o_meta + 16 * nObj;
+            const int my = lds0 + (wv * G + g) * (int)group_bytes; // LP mode: this lane's problem
+
+            for (int i = gl; i < 48; i += LP) B8(my + o_phys + i) = (uint8_t)i;
+            for (int i = gl; i <= n; i += LP) D(my + o_emap + 8 * i) = 0.0;
+            for (int i = gl; i < MD; i += LP) D(my + o_bc + 8 * i) = 0.0;
+            mf_lds_fence();
+
+            // ---- a level's rows by LDS-DMA: 16-byte pieces, piece t = 64 i + lane -> column t / HP, rows 2 (t % HP) .. +1; LDS image [column][MD] ----
+            const int CH = (n + 1) * HP;
+            uint32_t pieceoff[5];
+            bool piecein[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+            {
+                const int t   = 64 * i + lane;
+                const int tc  = t < CH ? t : CH - 1;
+                const int col = tc / HP, m = tc - col * HP;
+                pieceoff[i]   = (uint32_t)(col * cap + 2 * m);
+                piecein[i]    = t < CH;
+            }
+            // The requests are inline assembly (cdna_hip_programming.md 5.7: M0 written in the statement that reads it): the compiler does not
+            // count them, so no s_waitcnt of its own waits for a level that is still on its way; the kernel waits itself (vmcnt(0)) before the
+            // Gauss step reads the buffer.  `tie`: a value that must be complete before the requests are issued (operand dependency)
+            auto prefetch_level = [&](auto pp, int Frow, int tie) __attribute__((always_inline)) {
+                constexpr int p   = decltype(pp)::value;
+                const uint32_t pb = wq * (uint32_t)G + (uint32_t)p;
+                const double *src = inw + (size_t)((pb < a.batch ? pb : a.batch - 1u) - wq * (uint32_t)G) * pstride + Frow; // wave-uniform
+                const int dst     = lds0 + (wv * G + p) * (int)group_bytes + o_pf;
+#pragma unroll
+                for (int i = 0; i < 5; i++)
+                    if (64 * i < CH) // wave-uniform
+                    {
+                        uint32_t po = 8u * pieceoff[i];
+                        asm volatile("" : "+v"(po) : "v"(tie));
+                        if (piecein[i])
+                        {
+                            unsigned keep;
+                            asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                                         : "=&s"(keep)
+                                         : "v"(po), "s"(dst + 1024 * i), "s"(src)
+                                         : "memory");
+                        }
+                    }
+            };
+
+            int pos[NSM]; // current position of the column held in slot s
+            int pc[NSM];  // its physical column
+#pragma unroll
+            for (int s = 0; s < NSM; s++)
+            {
+                pos[s] = LP * s + gl;
+                pc[s]  = LP * s + gl <= n ? LP * s + gl : n;
+            }
+
+            int ColIndex  = 0; // per problem (uniform inside its LP lanes), like everything below
+            int TotalRank = 0;
+            int noff      = 0; // doubles
+            bool exh      = false;
+            bool have_next = false; // the rows of the level about to start are in flight / in LDS (per problem)
+#ifdef LEXLS_WAVE_STAMPS
+            unsigned long long lst_t0 = clock64();
+#endif
+
+            for (int k = 0; k < nObj; k++)
+            {
+                const bool work = live && !exh; // x only: once the columns are exhausted nothing below matters
+                const int Fc    = ColIndex;
+                int rank        = 0;
+                if (__ballot(work) == 0ull)
+                {
+                    if (gl == 0) U4(my + o_meta + 16 * k) = mf_u4{(unsigned)Fc | ((unsigned)(n + 1 - Fc) << 16), (unsigned)noff, 0u, 0u};
+                    continue;
+                }
+                const int F = k * MD;
+
+                // =====================================================================================
+                // serial mode: Gauss elimination of this level's rows by the finished levels (lexlse.h:431-471) on the matrix cores
+                // =====================================================================================
+                if (k > 0)
+                {
+                    // a level whose predecessor could have exhausted the columns was not requested ahead
+                    for_each_index<0, G>([&](auto pp) __attribute__((always_inline)) {
+                        constexpr int p = decltype(pp)::value;
+                        const int need  = __builtin_amdgcn_readlane((int)(work && !have_next), p * LP);
+                        if (need) prefetch_level(pp, F, 0);
+                    });
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for_each_index<0, G>([&](auto pp) __attribute__((always_inline)) {
+                        constexpr int p = decltype(pp)::value;
+                        if (!__builtin_amdgcn_readlane((int)work, p * LP)) return;
+                        const int Fck = __builtin_amdgcn_readlane(ColIndex, p * LP);
+                        const int sp  = lds0 + (wv * G + p) * (int)group_bytes;
+                        mf_d4 C[NT];
+                        unsigned long long emw[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                        {
+                            const int P   = 16 * t + c16;
+                            const int ph  = P < n ? (int)B8(sp + o_phys + P) : n;
+                            emw[t]        = U64(sp + o_emap + 8 * ph);
+#pragma unroll
+                            for (int v = 0; v < 4; v++) C[t][v] = (v < NV4 && P <= n) ? D(sp + o_pf + ph * CB + 8 * (gg + 4 * v)) : 0.0;
+                        }
+                        mf_lds_fence();
+                        for (int e = 0; e < k; e++)
+                        {
+                            const mf_u4 mt  = U4(sp + o_meta + 16 * e);
+                            const int mx    = __builtin_amdgcn_readfirstlane((int)mt.x);
+                            const int Noffe = __builtin_amdgcn_readfirstlane((int)mt.y);
+                            const int Fce = mx & 0xff, re = (mx >> 8) & 0xff, Se = (mx >> 16) & 0xff;
+                            if (re == 0) continue;
+                            // this row block's entries at e's pivot positions -> scratch [pivot q][16 rows]
+#pragma unroll
+                            for (int t = 0; t < NT; t++)
+                            {
+                                const int q = 16 * t + c16 - Fce;
+                                if (q >= 0 && q < re)
+                                {
+#pragma unroll
+                                    for (int v = 0; v < NV4; v++) D(sp + o_pf + q * 128 + 8 * (gg + 4 * v)) = C[t][v];
+                                }
+                            }
+                            mf_lds_fence();
+                            const int ksn = (re + 3) >> 2;
+#pragma unroll
+                            for (int ks = 0; ks < 4; ks++)
+                                if (ks < ksn && 4 * ks < MD) // wave-uniform
+                                {
+                                    const int q     = 4 * ks + gg; // A operand: lane (row c16, k = gg); B operand: lane (column c16, k = gg)
+                                    const double Aq = (q < re && c16 < MD) ? -D(sp + o_pf + q * 128 + 8 * c16) : 0.0;
+#pragma unroll
+                                    for (int t = 0; t < NT; t++)
+                                        if (16 * t + 15 >= Fce + re && 16 * t <= n) // wave-uniform: the tile holds columns behind e's pivots
+                                        {
+                                            const int P      = 16 * t + c16;
+                                            const int j      = (int)((emw[t] >> (8 * e)) & 0xffull);
+                                            const bool valid = P >= Fce + re && P <= n && q < re;
+                                            const double Bv  = valid ? D(sp + 8 * (Noffe + q * Se + j)) : 0.0;
+                                            C[t]             = __builtin_amdgcn_mfma_f64_16x16x4f64(Aq, Bv, C[t], 0, 0, 0);
+                                        }
+                                }
+                            mf_lds_fence();
+                        }
+                        // the eliminated rows, by position: [position][MD]
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                        {
+                            const int P = 16 * t + c16;
+                            if (P >= Fck && P <= n)
+                            {
+#pragma unroll
+                                for (int v = 0; v < NV4; v++) D(sp + o_pf + P * CB + 8 * (gg + 4 * v)) = C[t][v];
+                            }
+                        }
+                    });
+                    mf_lds_fence();
+                }
+                MF_LSTAMP(0)
+
+                // =====================================================================================
+                // LP mode: position layout of the level
+                // =====================================================================================
+                const int fcmin = [&]() {
+                    int m = 0x7fff;
+                    for_each_index<0, G>([&](auto pp) __attribute__((always_inline)) {
+                        constexpr int p = decltype(pp)::value;
+                        const int w = __builtin_amdgcn_readlane((int)work, p * LP), f = __builtin_amdgcn_readlane(ColIndex, p * LP);
+                        m           = (w && f < m) ? f : m;
+                    });
+                    return m;
+                }();
+                const int ns = (n + 1 - fcmin + LP - 1) / LP; // live slots (wave-uniform)
+                if (k > 0)
+                {
+#pragma unroll
+                    for (int s = 0; s < NSM; s++)
+                        if (s < ns)
+                        {
+                            const int P      = Fc + LP * s + gl;
+                            const bool valid = work && P <= n;
+                            const int Pc     = valid ? P : n;
+                            pc[s]            = Pc < n ? (int)B8(my + o_phys + Pc) : n;
+                            pos[s]           = valid ? P : 0x3fff;
+#pragma unroll
+                            for (int r = 0; r < MD; r += 2)
+                            {
+                                const mf_d2 v = D2(my + o_pf + Pc * CB + 8 * r);
+                                blk[s][r]     = valid ? v.x : 0.0;
+                                blk[s][r + 1] = valid ? v.y : 0.0;
+                            }
+                        }
+                }
+                else
+                {
+#pragma unroll
+                    for (int s = 0; s < NSM; s++)
+                    {
+                        const bool valid = work && LP * s + gl <= n;
+                        pos[s]           = valid ? LP * s + gl : 0x3fff;
+#pragma unroll
+                        for (int r = 0; r < MD; r++) blk[s][r] = valid ? blk[s][r] : 0.0;
+                    }
+                }
+                // down-dated norms start as the squared column norms of the eliminated rows (lexlse.h:193-196)
+                double nrm[NSM];
+#pragma unroll
+                for (int s = 0; s < NSM; s++)
+                {
+                    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                    for (int r = 0; r < MD; r += 2)
+                    {
+                        t0 = dfma(blk[s][r], blk[s][r], t0);
+                        t1 = dfma(blk[s][r + 1], blk[s][r + 1], t1);
+                    }
+                    nrm[s] = (s < ns && pos[s] < n) ? t0 + t1 : kMfSentinel;
+                }
+                // the next level's rows: requested now (the block is in registers, the scratch is free again), unless this level can exhaust the
+                // columns
+                {
+                    const bool pf = work && (k + 1 < nObj) && (Fc + MD < n);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the DMA writes what the reads above read)
+                    int tie = __double2hiint(nrm[0]);
+#pragma unroll
+                    for (int s = 1; s < NSM; s++) tie ^= __double2hiint(nrm[s]);
+                    for_each_index<0, G>([&](auto pp) __attribute__((always_inline)) {
+                        constexpr int p = decltype(pp)::value;
+                        if (__builtin_amdgcn_readlane((int)pf, p * LP)) prefetch_level(pp, F + MD, tie);
+                    });
+                    have_next = pf;
+                }
+                MF_LSTAMP(1)
+
+                // =====================================================================================
+                // Householder QR with column pivoting of the level (lexlse.h:182-268) + Jordan step: the block ends as N_k
+                // =====================================================================================
+                auto factor_level = [&](auto nsc) __attribute__((always_inline)) {
+                    constexpr int NS = decltype(nsc)::value;
+                    bool go = work;
+                    mf_for_each_while<0, MD>(
+                        [&](auto jc) __attribute__((always_inline)) { return (decltype(jc)::value % 4 != 0) || __ballot(go) != 0ull; },
+                        [&](auto jc) __attribute__((always_inline)) {
+                            constexpr int j = decltype(jc)::value;
+                            const bool act  = go;
+                            // ---- decision: maximum of the down-dated norms by VALUE, first by position among equals (lexlse.h:205-206) ----
+                            double m = nrm[0];
+#pragma unroll
+                            for (int s = 1; s < NS; s++) m = vmax(m, nrm[s]);
+                            m = mf_grp_max<LP>(m);
+                            bool ismax[NS];
+                            unsigned pk = 0xffffu;
+#pragma unroll
+                            for (int s = 0; s < NS; s++)
+                            {
+                                ismax[s]         = nrm[s] == m;
+                                const unsigned c = ismax[s] ? (unsigned)pos[s] : 0xffffu;
+                                pk               = c < pk ? c : pk;
+                            }
+                            const int ppos = (int)mf_grp_minu<LP>(pk); // the winner's position
+                            bool iswin[NS];
+#pragma unroll
+                            for (int s = 0; s < NS; s++) iswin[s] = ismax[s] && pos[s] == ppos;
+                            // ---- the winner's column to every lane of the problem ----
+#pragma unroll
+                            for (int s = 0; s < NS; s++)
+                                if (iswin[s] && act)
+                                {
+#pragma unroll
+                                    for (int r = 0; r < MD; r += 2) D2(my + o_bc + 8 * r) = mf_d2{blk[s][r], blk[s][r + 1]};
+                                }
+                            mf_lds_fence();
+                            double w[MD];
+#pragma unroll
+                            for (int r = 0; r < MD; r += 2)
+                            {
+                                const mf_d2 v = D2(my + o_bc + 8 * r);
+                                w[r]          = v.x;
+                                w[r + 1]      = v.y;
+                            }
+                            mf_lds_fence();
+                            const double c0 = w[j];
+                            // tail norm in three partial sums, fresh norm = c0^2 + tail (lexlse.h:210-211, :241)
+                            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                            for (int r = j + 1; r < MD; r++)
+                            {
+                                if ((r - j) % 3 == 1) t0 = dfma(w[r], w[r], t0);
+                                if ((r - j) % 3 == 2) t1 = dfma(w[r], w[r], t1);
+                                if ((r - j) % 3 == 0) t2 = dfma(w[r], w[r], t2);
+                            }
+                            const double fresh = dfma(c0, c0, (t0 + t1) + t2);
+                            const bool cont    = act && !(fresh < a.tol); // rank test on the squared norm (lexlse.h:214)
+                            // 1 / sqrt(fresh): v_rsq_f64 and two coupled iterations (g -> sqrt, h -> 1 / (2 sqrt))
+                            double gq, hq;
+                            {
+                                const double y = __builtin_amdgcn_rsq(fresh);
+                                gq             = fresh * y;
+                                hq             = 0.5 * y;
+                                double r       = dfma(-hq, gq, 0.5);
+                                gq             = dfma(gq, r, gq);
+                                hq             = dfma(hq, r, hq);
+                                r              = dfma(-hq, gq, 0.5);
+                                gq             = dfma(gq, r, gq);
+                                hq             = dfma(hq, r, hq);
+                            }
+                            const bool neg    = c0 >= 0.0; // beta = -sign(c0) sqrt(fresh)
+                            const double beta = neg ? -gq : gq;
+                            const double ibet = (neg ? -2.0 : 2.0) * hq; // 1 / beta
+                            const double rden = mf_rcp1(c0 - beta);
+                            // ---- every column: R_js = (w . a_s) / beta, rows below a_s += gs w, row j normalised, Jordan step on the rows above ----
+#pragma unroll
+                            for (int s = 0; s < NS; s++)
+                            {
+                                double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+                                for (int r = j + 1; r < MD; r++)
+                                {
+                                    if ((r - j) & 1)
+                                        d0 = dfma(w[r], blk[s][r], d0);
+                                    else
+                                        d1 = dfma(w[r], blk[s][r], d1);
+                                }
+                                const double dw = dfma(c0, blk[s][j], d0 + d1);
+                                const double t  = dw * ibet;                // R_js
+                                const double gs = (t - blk[s][j]) * rden;   // a_s[r] += gs w[r] (= a_s - tau v v.a_s, lexlse.h:243-246)
+                                const double u  = cont ? t * ibet : 0.0;    // R_js / R_jj; a level that has stopped leaves its rows alone
+                                nrm[s]          = dfma(-t, t, nrm[s]);      // lexlse.h:262-266
+                                nrm[s]          = (cont && iswin[s]) ? kMfSentinel : nrm[s];
+#pragma unroll
+                                for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs, w[r], blk[s][r]);
+                                blk[s][j] = cont ? t * ibet : blk[s][j];
+#pragma unroll
+                                for (int i = 0; i < j; i++) blk[s][i] = dfma(-w[i], u, blk[s][i]);
+                            }
+                            // ---- column "swap": the position map (lexlse.h:222-232) ----
+#pragma unroll
+                            for (int s = 0; s < NS; s++)
+                            {
+                                const bool front = cont && pos[s] == ColIndex;
+                                pos[s]           = front ? ppos : pos[s];
+                                pos[s]           = (cont && iswin[s]) ? ColIndex : pos[s];
+                                if (cont && iswin[s]) a.perm[(size_t)b * n + ColIndex] = (uint32_t)ppos;
+                            }
+                            ColIndex += cont ? 1 : 0;
+                            rank += cont ? 1 : 0;
+                            const bool full = cont && ColIndex == n;
+                            exh             = exh || full;
+                            go              = cont && !full;
+                        });
+                };
+                if (NSM > 1 && ns > 1)
+                    factor_level(std::integral_constant<int, NSM>{});
+                else
+                    factor_level(std::integral_constant<int, 1>{});
+                MF_LSTAMP(2)
+
+                // =====================================================================================
+                // level end: N_k = the first `rank` rows of the columns behind the pivots, by local column index; maps
+                // =====================================================================================
+                {
+                    const int S = n + 1 - Fc - rank;
+#pragma unroll
+                    for (int s = 0; s < NSM; s++)
+                        if (s < ns)
+                        {
+                            const int P0     = Fc + LP * s + gl;
+                            const bool mv    = work && P0 <= n;
+                            const int j      = pos[s] - (Fc + rank);
+                            const bool free_ = mv && j >= 0;
+                            if (free_)
+                            {
+#pragma unroll
+                                for (int q = 0; q < MD; q++)
+                                    if (q < rank) D(my + 8 * (noff + q * S + j)) = blk[s][q];
+                                B8(my + o_emap + 8 * pc[s] + k) = (uint8_t)j;
+                                if (rank > 0) B8(my + 8 * (noff + rank * S) + j) = (uint8_t)pc[s];
+                            }
+                            if (mv && P0 < n) B8(my + o_phys + pos[s]) = (uint8_t)pc[s];
+                        }
+                    if (gl == 0) U4(my + o_meta + 16 * k) = mf_u4{(unsigned)Fc | ((unsigned)rank << 8) | ((unsigned)S << 16), (unsigned)noff, 0u, 0u};
+                    noff += (work && rank > 0) ? rank * S + ((S + 7) >> 3) : 0;
+                    TotalRank += rank;
+                }
+                mf_lds_fence();
+                MF_LSTAMP(3)
+            }
+
+            // ---- solve(): x_pivots(k) = rhs'_k - N_k x_later, k descending (lexlse.h:1015-1045); lane q <-> row q of a level; x by physical column
+            //      in the (idle) level buffer.  A DMA request that nobody consumed (the columns ran out under it) must have landed first ----
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int o_x = o_pf;
+            for (int i = gl; i <= n; i += LP) D(my + o_x + 8 * i) = 0.0;
+            mf_lds_fence();
+            for (int k = nObj; k--;)
+            {
+                const mf_u4 mt = U4(my + o_meta + 16 * k);
+                const int Fck = (int)(mt.x & 0xffu), rk = live ? (int)((mt.x >> 8) & 0xffu) : 0, Sk = (int)((mt.x >> 16) & 0xffu);
+                const int nofk = (int)mt.y, invk = 8 * (nofk + rk * Sk);
+                int rmax = 0, smax = 0;
+                for_each_index<0, G>([&](auto pp) __attribute__((always_inline)) {
+                    constexpr int p = decltype(pp)::value;
+                    const int r_ = __builtin_amdgcn_readlane(rk, p * LP), s_ = __builtin_amdgcn_readlane(rk > 0 ? Sk : 0, p * LP);
+                    rmax = r_ > rmax ? r_ : rmax;
+                    smax = s_ > smax ? s_ : smax;
+                });
+                if (rmax == 0) continue;
+                const bool row = gl < rk;
+                const int rowa = my + 8 * (nofk + (row ? gl : 0) * Sk);
+                double s0 = row ? D(rowa + 8 * (Sk - 1)) : 0.0, s1 = 0.0; // the right-hand side is the last column of N_k
+                for (int j = 0; j + 1 < smax; j += 2)
+                {
+                    const bool in0 = row && j < Sk - 1, in1 = row && j + 1 < Sk - 1;
+                    const int p0 = in0 ? (int)B8(my + invk + j) : 0, p1 = in1 ? (int)B8(my + invk + j + 1) : 0;
+                    const double n0 = D(rowa + 8 * (in0 ? j : 0)), n1 = D(rowa + 8 * (in1 ? j + 1 : 0));
+                    const double x0 = D(my + o_x + 8 * p0), x1 = D(my + o_x + 8 * p1);
+                    s0 = dfma(in0 ? -n0 : 0.0, x0, s0);
+                    s1 = dfma(in1 ? -n1 : 0.0, x1, s1);
+                }
+                mf_lds_fence();
+                if (row) D(my + o_x + 8 * (int)B8(my + o_phys + Fck + gl)) = s0 + s1;
+                mf_lds_fence();
+            }
+            // ---- results ----
+            if (live)
+            {
+                for (int P = gl; P < n; P += LP)
+                {
+                    a.x[(size_t)b * n + P]    = D(my + o_x + 8 * P); // x of the variable (physical column) P: x = P x already applied (lexlse.h:1044)
+                    if (P >= TotalRank) a.perm[(size_t)b * n + P] = (uint32_t)P; // (the pivots' entries were stored as they were chosen)
+                }
+                if (gl < nObj)
+                {
+                    const mf_u4 mt                = U4(my + o_meta + 16 * gl);
+                    a.fcol[(size_t)b * nObj + gl] = mt.x & 0xffu;
+                    a.rank[(size_t)b * nObj + gl] = (mt.x >> 8) & 0xffu;
+                }
+                if (gl == 0) a.totalrank[b] = (uint32_t)TotalRank;
+            }
+        }
+
+        /// exact worst case of the reduced rows and their inverse maps: max over rank distributions (rank_k <= md, sum <= n) of
+        /// sum_k rank_k S_k + ceil(S_k / 8), S_k = n + 1 - Fc_k - rank_k
+        inline uint32_t mfma_nd_doubles(uint32_t n, uint32_t nObj, uint32_t md)
+        {
+            // best[fc]: the most doubles the levels from the current one on can need when the current one starts at column fc
+            uint32_t best[65], next[65];
+            for (uint32_t fc = 0; fc <= n; fc++) next[fc] = 0;
+            for (uint32_t k = nObj; k--;)
+            {
+                for (uint32_t fc = 0; fc <= n; fc++)
+                {
+                    uint32_t m = 0;
+                    for (uint32_t r = 0; r <= md && fc + r <= n; r++)
+                    {
+                        const uint32_t S = n + 1 - fc - r;
+                        const uint32_t v = r * S + (r ? (S + 7) / 8 : 0) + next[fc + r]; // the rows and their inverse map
+                        m                = v > m ? v : m;
+                    }
+                    best[fc] = m;
+                }
+                for (uint32_t fc = 0; fc <= n; fc++) next[fc] = best[fc];
+            }
+            return (next[0] + 1) & ~1u;
+        }
+
+        template <int MD>
+        inline size_t mfma_group_bytes(uint32_t n, uint32_t nObj)
+        {
+            const size_t pfb = 8u * MD * (size_t)(n + 1) > 128u * MD ? 8u * MD * (size_t)(n + 1) : 128u * MD;
+            const size_t raw = 8 * (size_t)mfma_nd_doubles(n, nObj, MD) + pfb + 8 * MD + 48 + 16 * (size_t)nObj + 8 * (size_t)(n + 1);
+            // (no padding against bank conflicts between the problems of a wavefront: the LDS serves a wave's 8- and 16-byte accesses in lane groups
+            // that never mix the two halves of the wavefront, MI355X_MICROARCH.md LDS table)
+            return (raw + 15) & ~(size_t)15;
+        }
+
+        template <int LP, int MD, int NV>
+        hipError_t launch_mfma_t(const LseArgs &a, hipStream_t s)
+        {
+            constexpr uint32_t G = 64 / LP;
+            const uint32_t nd    = mfma_nd_doubles(a.nVar, a.nObj, MD);
+            const size_t gbytes  = mfma_group_bytes<MD>(a.nVar, a.nObj);
+            const size_t lds     = 4 * G * gbytes;
+            // (two / four wavefronts per SIMD are the point of the mapping: the workgroups of a CU must fit its LDS together)
+            if (lds * (LP == 64 ? 4 : 2) > kMaxLdsBytes || a.nObj > (uint32_t)kMfMaxObj || a.nVar + 1 > 48u || a.nVar < 1u || (NV && a.nVar != (uint32_t)NV)) return hipErrorInvalidValue;
+            if (a.uniform_dim != (uint32_t)MD || (a.cap & 1u) || (reinterpret_cast<uintptr_t>(a.in) & 15u) || a.nfixed || a.reg_type != 0) return hipErrorInvalidValue;
+            if (lds > 64 * 1024)
+            {
+                static size_t granted[64] = {0}; // per device: the attribute is set once, not per launch
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+                if (dev < 0 || granted[dev] < lds)
+                {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lqr_mfma_kernel<LP, MD, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) return e;
+                    if (dev >= 0) granted[dev] = lds;
+                }
+            }
+            const uint32_t blocks = (a.batch + 4u * G - 1u) / (4u * G);
+            hipLaunchKernelGGL((lqr_mfma_kernel<LP, MD, NV>), dim3(blocks), dim3(256), lds, s, a, nd, (uint32_t)gbytes);
+            return hipGetLastError();
+        }
+    } // namespace
+} // namespace lexls
+
+#define LEXLS_MFMA_INSTANCE(NAME, LP, MD, NV) \
+    namespace lexls { hipError_t NAME(const LseArgs &a, hipStream_t s) { return launch_mfma_t<LP, MD, NV>(a, s); } \
+                      size_t NAME##_lds(uint32_t nVar, uint32_t nObj) { return 4 * (64 / LP) * mfma_group_bytes<MD>(nVar, nObj); } }

@@ -42,6 +42,25 @@ namespace lexls
     size_t launch_qtol_3x12_lds(uint32_t nVar, uint32_t nObj);
     hipError_t launch_qtol_2x12(const LseArgs &a, hipStream_t s);
     size_t launch_qtol_2x12_lds(uint32_t nVar, uint32_t nObj);
+    hipError_t launch_mfma_32x12n40(const LseArgs &a, hipStream_t s);
+    size_t launch_mfma_32x12n40_lds(uint32_t nVar, uint32_t nObj);
+    hipError_t launch_mfma_32x12(const LseArgs &a, hipStream_t s);
+    size_t launch_mfma_32x12_lds(uint32_t nVar, uint32_t nObj);
+    hipError_t launch_mfma_64x12(const LseArgs &a, hipStream_t s);
+    size_t launch_mfma_64x12_lds(uint32_t nVar, uint32_t nObj);
+
+    /// which instantiation of the matrix-core tolerance-contract kernel (lqr_mfma_impl.h) serves these arguments (0: none): x-only solves of
+    /// batches in which every level of every problem has exactly 12 rows, no fixed variables, no regularization, n + 1 <= 48 —
+    /// 1: two problems per wavefront, n = 40 (the IK shape of BASELINE configs[2]/[3]); 2: two problems per wavefront, other n;
+    /// 3: one problem per wavefront (asked for by policy 8)
+    static int mfma_choice(const LseArgs &a, bool write_factor, bool has_fixed, bool one_per_wave)
+    {
+        if (write_factor || has_fixed || a.reg_type != 0 || a.uniform_dim != 12 || a.nObj > 8 || (a.cap & 1u) != 0 || (reinterpret_cast<uintptr_t>(a.in) & 15u) != 0 || a.g_cdata) return 0;
+        if (a.nVar < 1 || a.nVar + 1 > 48) return 0;
+        if (one_per_wave) return 4 * launch_mfma_64x12_lds(a.nVar, a.nObj) <= kMaxLdsBytes ? 3 : 0;
+        if (2 * launch_mfma_32x12_lds(a.nVar, a.nObj) > kMaxLdsBytes) return 0;
+        return a.nVar == 40 ? 1 : 2;
+    }
 
     /// which instantiation of the tolerance-contract four-per-wavefront kernel (lqr_qtol_impl.h) serves these arguments (0: none): x-only
     /// solves of batches in which every level of every problem has exactly 12 rows, no fixed variables, no regularization, n + 1 <= 48 —
@@ -133,10 +152,20 @@ namespace lexls
     }
 
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
-                               const char **variant, bool allow_tolerance)
+                               const char **variant, int tolerance)
     {
         const uint32_t nc = a.nVar + 1;
-        if (allow_tolerance)
+        // tolerance: 0 bit-exact kernels only; 1 automatic (the matrix-core kernel where it serves, else lqr_qtol); 6 lqr_qtol; 7 / 8 lqr_mfma with
+        // two / one problem per wavefront
+        if (tolerance == 1 || tolerance == 7 || tolerance == 8)
+            switch (mfma_choice(a, write_factor, has_fixed, tolerance == 8))
+            {
+            case 1: *variant = "lqr_mfma<32,12,n40>"; return launch_mfma_32x12n40(a, s);
+            case 2: *variant = "lqr_mfma<32,12>"; return launch_mfma_32x12(a, s);
+            case 3: *variant = "lqr_mfma<64,12>"; return launch_mfma_64x12(a, s);
+            default: break;
+            }
+        if (tolerance != 0)
             switch (qtol_choice(a, write_factor, has_fixed))
             {
             case 1: *variant = "lqr_qtol<3,12,shift 7>"; return launch_qtol_3x12s7(a, s);
