@@ -104,6 +104,33 @@ namespace lexls
             return v;
         }
 
+        template <int CTRL>
+        __device__ __forceinline__ int mf_dpp_maxi(int v)
+        {
+            const int o = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); // folds into v_max_i32_dpp
+            return o > v ? o : v;
+        }
+        /// signed maximum over the LP lanes of a problem, in every lane
+        template <int LP>
+        __device__ __forceinline__ int mf_grp_maxi(int v)
+        {
+            v = mf_dpp_maxi<0xB1>(v);
+            v = mf_dpp_maxi<0x4E>(v);
+            v = mf_dpp_maxi<0x141>(v);
+            v = mf_dpp_maxi<0x140>(v);
+            if constexpr (LP >= 32)
+            {
+                const mf_u2 r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+                v             = (int)r.x > (int)r.y ? (int)r.x : (int)r.y;
+            }
+            if constexpr (LP >= 64)
+            {
+                const mf_u2 r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+                v             = (int)r.x > (int)r.y ? (int)r.x : (int)r.y;
+            }
+            return v;
+        }
+
         /// f(integral_constant<int, I>) for I = B, B+1, ... while pred(I) holds
         template <int B, int E, class P, class F>
         __device__ __forceinline__ void mf_for_each_while(P &&pred, F &&f)
@@ -129,8 +156,15 @@ namespace lexls
         if (gl == 0 && live) a.lambda[(size_t)b * (n + cap) + 11 + 4 * k + (ph)] = (double)(t_ - lst_t0); \
         lst_t0 = t_;                                                                                      \
     }
+#define MF_GSTAMP(i)                                     \
+    {                                                    \
+        const unsigned long long t_ = clock64();         \
+        gst[i] += t_ - gst_t0;                           \
+        gst_t0 = t_;                                     \
+    }
 #else
 #define MF_LSTAMP(ph)
+#define MF_GSTAMP(i)
 #endif
 
         /// LP lanes per problem (32: two problems per wavefront, two wavefronts per SIMD; 64: one problem, four wavefronts per SIMD);
@@ -144,7 +178,7 @@ namespace lexls
             constexpr int NT  = 3;                  // 16-position tiles of the matrix-core layout (n + 1 <= 48)
             constexpr int HP  = MD / 2;             // 16-byte pieces per column of a level
             constexpr int CB  = 8 * MD;             // bytes per column of a level
-            constexpr int NV4 = MD / 4;             // accumulator registers that hold rows of the level
+            constexpr int NV4 = MD / 4;             // accumulator registers that hold rows of the level = k-steps of a finished level
             extern __shared__ double smem[];
             typedef __attribute__((address_space(3))) char lds_char;
             const int lds0 = (int)(unsigned)(size_t)(lds_char *)smem;
@@ -152,7 +186,6 @@ namespace lexls
             auto D2  = [&](int off) -> __attribute__((address_space(3))) mf_d2 & { return *(__attribute__((address_space(3))) mf_d2 *)(size_t)(unsigned)off; };
             auto B8  = [&](int off) -> __attribute__((address_space(3))) uint8_t & { return *(__attribute__((address_space(3))) uint8_t *)(size_t)(unsigned)off; };
             auto U64 = [&](int off) -> __attribute__((address_space(3))) unsigned long long & { return *(__attribute__((address_space(3))) unsigned long long *)(size_t)(unsigned)off; };
-            auto U4  = [&](int off) -> __attribute__((address_space(3))) mf_u4 & { return *(__attribute__((address_space(3))) mf_u4 *)(size_t)(unsigned)off; };
 
             const int lane    = threadIdx.x & 63;
             const int wv      = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -192,22 +225,25 @@ namespace lexls
             // ---- LDS carve-up of a problem's slice (byte offsets; launch_mfma_t computes group_bytes) ----
             //   [0, o_pf)   the reduced rows N_e of the finished levels (row q of level e: S_e doubles at noff_e + q S_e), each followed by its
             //               inverse map (S_e bytes: column index in N_e -> physical column)
-            //   o_pf        [column][MD]: the level loaded ahead / scratch of the Gauss step ([pivot][16 rows], then [position][MD]) / x by physical column
+            //   o_pf        [column][MD]: the level loaded ahead / scratch of the Gauss step ([pivot][16 rows], then [position][MD]) / x by physical
+            //               column and by column index during solve()
             //   o_bc        MD doubles: broadcast slot of the pivot steps
-            //   o_phys      48 B: physical column at each position (column_permutations go straight to HBM: one byte-sized store per pivot)
-            //   o_meta      per level {Fc | rank << 8 | S << 16, offset of N_e (doubles), -, -}
+            //   o_mx        2 doubles: the maximum of the down-dated norms (LDS atomic), even / odd pivot steps
+            //   o_phys      48 B: physical column at each position (column_permutations go straight to HBM)
+            //   o_meta      per level {Fc | rank << 8 | S << 16, offset of N_e (doubles)}
             //   o_emap      per physical column: byte k = its column index in N_k
             const int pfb    = CB * (n + 1) > 128 * MD ? CB * (n + 1) : 128 * MD;
             const int o_pf   = 8 * (int)nd_doubles;
             const int o_bc   = o_pf + pfb;
-            const int o_phys = o_bc + CB;
+            const int o_mx   = o_bc + CB;
+            const int o_phys = o_mx + 16;
             const int o_meta = o_phys + 48;
-            const int o_emap = o_meta + 16 * nObj;
+            const int o_emap = o_meta + 8 * nObj;
             const int my = lds0 + (wv * G + g) * (int)group_bytes; // LP mode: this lane's problem
 
             for (int i = gl; i < 48; i += LP) B8(my + o_phys + i) = (uint8_t)i;
             for (int i = gl; i <= n; i += LP) D(my + o_emap + 8 * i) = 0.0;
-            for (int i = gl; i < MD; i += LP) D(my + o_bc + 8 * i) = 0.0;
+            for (int i = gl; i < MD + 2; i += LP) D(my + o_bc + 8 * i) = i < MD ? 0.0 : kMfSentinel;
             mf_lds_fence();
 
             // ---- a level's rows by LDS-DMA: 16-byte pieces, piece t = 64 i + lane -> column t / HP, rows 2 (t % HP) .. +1; LDS image [column][MD] ----
@@ -264,6 +300,8 @@ namespace lexls
             bool have_next = false; // the rows of the level about to start are in flight / in LDS (per problem)
 #ifdef LEXLS_WAVE_STAMPS
             unsigned long long lst_t0 = clock64();
+            const unsigned long long lst_t00 = lst_t0;
+            unsigned long long gst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gst_t0 = 0;
 #endif
 
             for (int k = 0; k < nObj; k++)
@@ -273,91 +311,136 @@ namespace lexls
                 int rank        = 0;
                 if (__ballot(work) == 0ull)
                 {
-                    if (gl == 0) U4(my + o_meta + 16 * k) = mf_u4{(unsigned)Fc | ((unsigned)(n + 1 - Fc) << 16), (unsigned)noff, 0u, 0u};
+                    if (gl == 0) U64(my + o_meta + 8 * k) = (unsigned long long)((unsigned)Fc | ((unsigned)(n + 1 - Fc) << 16)) | ((unsigned long long)(unsigned)noff << 32);
                     continue;
                 }
                 const int F = k * MD;
 
                 // =====================================================================================
-                // serial mode: Gauss elimination of this level's rows by the finished levels (lexlse.h:431-471) on the matrix cores
+                // serial mode: Gauss elimination of this level's rows by the finished levels (lexlse.h:431-471) on the matrix cores.
+                // The problems of the wavefront go through every stage together (straight-line code: their LDS round trips and matrix
+                // instructions overlap); what does not apply is a zero operand, never a branch around a matrix instruction
                 // =====================================================================================
                 if (k > 0)
                 {
-                    // a level whose predecessor could have exhausted the columns was not requested ahead
+                    int wk[G], Fck[G], sp[G];
                     for_each_index<0, G>([&](auto pp) __attribute__((always_inline)) {
                         constexpr int p = decltype(pp)::value;
-                        const int need  = __builtin_amdgcn_readlane((int)(work && !have_next), p * LP);
-                        if (need) prefetch_level(pp, F, 0);
+                        wk[p]           = __builtin_amdgcn_readlane((int)work, p * LP);
+                        Fck[p]          = __builtin_amdgcn_readlane(ColIndex, p * LP);
+                        sp[p]           = lds0 + (wv * G + p) * (int)group_bytes;
+                        // a level whose predecessor could have exhausted the columns was not requested ahead
+                        if (__builtin_amdgcn_readlane((int)(work && !have_next), p * LP)) prefetch_level(pp, F, 0);
                     });
+#ifdef LEXLS_WAVE_STAMPS
+                    gst_t0 = clock64();
+#endif
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    for_each_index<0, G>([&](auto pp) __attribute__((always_inline)) {
-                        constexpr int p = decltype(pp)::value;
-                        if (!__builtin_amdgcn_readlane((int)work, p * LP)) return;
-                        const int Fck = __builtin_amdgcn_readlane(ColIndex, p * LP);
-                        const int sp  = lds0 + (wv * G + p) * (int)group_bytes;
-                        mf_d4 C[NT];
-                        unsigned long long emw[NT];
+                    MF_GSTAMP(0)
+                    mf_d4 C[G][NT];
+                    unsigned long long emw[G][NT];
+#pragma unroll
+                    for (int p = 0; p < G; p++)
 #pragma unroll
                         for (int t = 0; t < NT; t++)
                         {
-                            const int P   = 16 * t + c16;
-                            const int ph  = P < n ? (int)B8(sp + o_phys + P) : n;
-                            emw[t]        = U64(sp + o_emap + 8 * ph);
+                            const int P  = 16 * t + c16;
+                            const int ph = P < n ? (int)B8(sp[p] + o_phys + P) : n;
+                            emw[p][t]    = U64(sp[p] + o_emap + 8 * ph);
 #pragma unroll
-                            for (int v = 0; v < 4; v++) C[t][v] = (v < NV4 && P <= n) ? D(sp + o_pf + ph * CB + 8 * (gg + 4 * v)) : 0.0;
+                            for (int v = 0; v < 4; v++)
+                            {
+                                const double rd = D(sp[p] + o_pf + ph * CB + 8 * (v < NV4 ? gg + 4 * v : 0));
+                                C[p][t][v]      = (v < NV4 && P <= n && wk[p]) ? rd : 0.0;
+                            }
                         }
-                        mf_lds_fence();
-                        for (int e = 0; e < k; e++)
+                    mf_lds_fence();
+                    MF_GSTAMP(1)
+                    for (int e = 0; e < k; e++)
+                    {
+                        int Fce[G], re[G], Se[G], Noffe[G];
+                        int tmin = NT;
+#pragma unroll
+                        for (int p = 0; p < G; p++)
                         {
-                            const mf_u4 mt  = U4(sp + o_meta + 16 * e);
-                            const int mx    = __builtin_amdgcn_readfirstlane((int)mt.x);
-                            const int Noffe = __builtin_amdgcn_readfirstlane((int)mt.y);
-                            const int Fce = mx & 0xff, re = (mx >> 8) & 0xff, Se = (mx >> 16) & 0xff;
-                            if (re == 0) continue;
-                            // this row block's entries at e's pivot positions -> scratch [pivot q][16 rows]
+                            const unsigned long long mt = U64(sp[p] + o_meta + 8 * e);
+                            const int mx                = __builtin_amdgcn_readfirstlane((int)(unsigned)mt);
+                            Noffe[p]                    = __builtin_amdgcn_readfirstlane((int)(unsigned)(mt >> 32));
+                            Fce[p]                      = mx & 0xff;
+                            re[p]                       = wk[p] ? (mx >> 8) & 0xff : 0;
+                            Se[p]                       = (mx >> 16) & 0xff;
+                            const int tm                = (Fce[p] + re[p]) >> 4;
+                            tmin                        = (re[p] > 0 && tm < tmin) ? tm : tmin;
+                        }
+                        if (tmin >= NT) continue; // nobody has pivots at this level (wave-uniform)
+                        // this row block's entries at e's pivot positions -> scratch [pivot q][16 rows]
+#pragma unroll
+                        for (int p = 0; p < G; p++)
 #pragma unroll
                             for (int t = 0; t < NT; t++)
                             {
-                                const int q = 16 * t + c16 - Fce;
-                                if (q >= 0 && q < re)
+                                const int q = 16 * t + c16 - Fce[p];
+                                if (q >= 0 && q < re[p])
                                 {
 #pragma unroll
-                                    for (int v = 0; v < NV4; v++) D(sp + o_pf + q * 128 + 8 * (gg + 4 * v)) = C[t][v];
+                                    for (int v = 0; v < NV4; v++) D(sp[p] + o_pf + q * 128 + 8 * (gg + 4 * v)) = C[p][t][v];
                                 }
                             }
-                            mf_lds_fence();
-                            const int ksn = (re + 3) >> 2;
+                        mf_lds_fence();
+                        MF_GSTAMP(2)
+                        // operands: A = -multipliers, lane (row c16, k = gg); B = N_e, lane (column c16, k = gg); k-step ks <-> pivots 4 ks .. 4 ks + 3
+                        double Aop[G][NV4], Bop[G][NV4][NT];
 #pragma unroll
-                            for (int ks = 0; ks < 4; ks++)
-                                if (ks < ksn && 4 * ks < MD) // wave-uniform
+                        for (int p = 0; p < G; p++)
+#pragma unroll
+                            for (int ks = 0; ks < NV4; ks++)
+                            {
+                                const int q     = 4 * ks + gg;
+                                const double rd = D(sp[p] + o_pf + q * 128 + 8 * c16);
+                                Aop[p][ks]      = (q < re[p] && c16 < MD) ? -rd : 0.0;
+#pragma unroll
+                                for (int t = 0; t < NT; t++)
                                 {
-                                    const int q     = 4 * ks + gg; // A operand: lane (row c16, k = gg); B operand: lane (column c16, k = gg)
-                                    const double Aq = (q < re && c16 < MD) ? -D(sp + o_pf + q * 128 + 8 * c16) : 0.0;
-#pragma unroll
-                                    for (int t = 0; t < NT; t++)
-                                        if (16 * t + 15 >= Fce + re && 16 * t <= n) // wave-uniform: the tile holds columns behind e's pivots
-                                        {
-                                            const int P      = 16 * t + c16;
-                                            const int j      = (int)((emw[t] >> (8 * e)) & 0xffull);
-                                            const bool valid = P >= Fce + re && P <= n && q < re;
-                                            const double Bv  = valid ? D(sp + 8 * (Noffe + q * Se + j)) : 0.0;
-                                            C[t]             = __builtin_amdgcn_mfma_f64_16x16x4f64(Aq, Bv, C[t], 0, 0, 0);
-                                        }
+                                    const int P      = 16 * t + c16;
+                                    const int j      = (int)((emw[p][t] >> (8 * e)) & 0xffull);
+                                    const bool valid = P >= Fce[p] + re[p] && P <= n && q < re[p];
+                                    const double rb  = D(sp[p] + 8 * (valid ? Noffe[p] + q * Se[p] + j : 0));
+                                    Bop[p][ks][t]    = valid ? rb : 0.0;
                                 }
-                            mf_lds_fence();
-                        }
-                        // the eliminated rows, by position: [position][MD]
+                            }
+                        // tiles in front of every problem's pivots of this level are not touched (wave-uniform choice of the first tile)
+                        auto run_tiles = [&](auto t0c) __attribute__((always_inline)) {
+                            constexpr int T0 = decltype(t0c)::value;
+#pragma unroll
+                            for (int ks = 0; ks < NV4; ks++)
+#pragma unroll
+                                for (int t = T0; t < NT; t++)
+#pragma unroll
+                                    for (int p = 0; p < G; p++) C[p][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[p][ks], Bop[p][ks][t], C[p][t], 0, 0, 0);
+                        };
+                        if (tmin == 0)
+                            run_tiles(std::integral_constant<int, 0>{});
+                        else if (tmin == 1)
+                            run_tiles(std::integral_constant<int, 1>{});
+                        else
+                            run_tiles(std::integral_constant<int, 2>{});
+                        mf_lds_fence();
+                        MF_GSTAMP(3)
+                    }
+                    // the eliminated rows, by position: [position][MD]
+#pragma unroll
+                    for (int p = 0; p < G; p++)
 #pragma unroll
                         for (int t = 0; t < NT; t++)
                         {
                             const int P = 16 * t + c16;
-                            if (P >= Fck && P <= n)
+                            if (wk[p] && P >= Fck[p] && P <= n)
                             {
 #pragma unroll
-                                for (int v = 0; v < NV4; v++) D(sp + o_pf + P * CB + 8 * (gg + 4 * v)) = C[t][v];
+                                for (int v = 0; v < NV4; v++) D(sp[p] + o_pf + P * CB + 8 * (gg + 4 * v)) = C[p][t][v];
                             }
                         }
-                    });
+                    MF_GSTAMP(4)
                     mf_lds_fence();
                 }
                 MF_LSTAMP(0)
@@ -437,8 +520,15 @@ namespace lexls
                 MF_LSTAMP(1)
 
                 // =====================================================================================
-                // Householder QR with column pivoting of the level (lexlse.h:182-268) + Jordan step: the block ends as N_k
+                // Householder QR with column pivoting of the level (lexlse.h:182-268) + Jordan step: the block ends as N_k.
+                // What is uniform per problem lives in scalar registers as lane masks / readlane results: the decision costs the vector unit one
+                // maximum, one LDS atomic and one compare; everything a stopped level must not do is skipped under its lanes' exec bits.
                 // =====================================================================================
+                unsigned permw[G][(MD + 3) / 4]; // column_permutations of this level's pivots, four per word (scalar registers)
+#pragma unroll
+                for (int p = 0; p < G; p++)
+#pragma unroll
+                    for (int i = 0; i < (MD + 3) / 4; i++) permw[p][i] = 0u;
                 auto factor_level = [&](auto nsc) __attribute__((always_inline)) {
                     constexpr int NS = decltype(nsc)::value;
                     bool go = work;
@@ -447,24 +537,64 @@ namespace lexls
                         [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
                             const bool act  = go;
-                            // ---- decision: maximum of the down-dated norms by VALUE, first by position among equals (lexlse.h:205-206) ----
-                            double m = nrm[0];
+                            // ---- decision: first maximum of the down-dated norms (lexlse.h:205-206).  Fast path on the norms' HIGH WORDS (sign, exponent,
+                            //      20 mantissa bits; signed integer order = the order of non-negative doubles): one v_max_i32_dpp per butterfly
+                            //      stage.  A unique lane with the largest high word holds the largest norm.  Anything else — two lanes with that
+                            //      high word, or no non-negative norm at all — takes the exact path below: maximum by VALUE over the whole
+                            //      double, the smallest position among equals ----
+                            int hl = __double2hiint(nrm[0]);
 #pragma unroll
-                            for (int s = 1; s < NS; s++) m = vmax(m, nrm[s]);
-                            m = mf_grp_max<LP>(m);
-                            bool ismax[NS];
-                            unsigned pk = 0xffffu;
+                            for (int s = 1; s < NS; s++) hl = __double2hiint(nrm[s]) > hl ? __double2hiint(nrm[s]) : hl;
+                            const int mh = mf_grp_maxi<LP>(hl);
+                            bool iswin[NS];
+                            bool any = false, two = false;
 #pragma unroll
                             for (int s = 0; s < NS; s++)
                             {
-                                ismax[s]         = nrm[s] == m;
-                                const unsigned c = ismax[s] ? (unsigned)pos[s] : 0xffffu;
-                                pk               = c < pk ? c : pk;
+                                iswin[s] = act && __double2hiint(nrm[s]) == mh;
+                                two      = two || (any && iswin[s]);
+                                any      = any || iswin[s];
                             }
-                            const int ppos = (int)mf_grp_minu<LP>(pk); // the winner's position
-                            bool iswin[NS];
+                            const unsigned long long mk = __ballot(any);
+                            bool tie = __ballot(two || (act && mh < 0)) != 0ull;
 #pragma unroll
-                            for (int s = 0; s < NS; s++) iswin[s] = ismax[s] && pos[s] == ppos;
+                            for (int p = 0; p < G; p++) tie = tie || __builtin_popcountll(LP == 64 ? mk : (mk >> (32 * p)) & 0xffffffffull) > 1;
+                            if (tie) // (wave-uniform, rare)
+                            {
+                                double mv = kMfSentinel;
+#pragma unroll
+                                for (int s = 0; s < NS; s++) mv = vmax(mv, nrm[s]);
+                                mv          = mf_grp_max<LP>(mv);
+                                unsigned pk = 0xffffu;
+#pragma unroll
+                                for (int s = 0; s < NS; s++)
+                                {
+                                    iswin[s]         = act && nrm[s] == mv && nrm[s] > 0.5 * kMfSentinel;
+                                    const unsigned c = iswin[s] ? (unsigned)pos[s] : 0xffffu;
+                                    pk               = c < pk ? c : pk;
+                                }
+                                const unsigned wp = mf_grp_minu<LP>(pk);
+#pragma unroll
+                                for (int s = 0; s < NS; s++) iswin[s] = iswin[s] && (unsigned)pos[s] == wp;
+                            }
+                            // the winner's position, per problem in a scalar register
+                            int wposl = pos[0];
+#pragma unroll
+                            for (int s = 1; s < NS; s++) wposl = iswin[s] ? pos[s] : wposl;
+                            bool anyw = false;
+#pragma unroll
+                            for (int s = 0; s < NS; s++) anyw = anyw || iswin[s];
+                            const unsigned long long wm = __ballot(anyw);
+                            int pps[G];
+#pragma unroll
+                            for (int p = 0; p < G; p++)
+                            {
+                                const unsigned long long h = LP == 64 ? wm : (wm >> (32 * p)) & 0xffffffffull;
+                                const int wl               = h ? (int)__builtin_ctzll(h) + LP * p : LP * p;
+                                pps[p]                     = __builtin_amdgcn_readlane(wposl, wl);
+                            }
+                            int ppos = pps[0];
+                            if constexpr (G > 1) ppos = g ? pps[G - 1] : pps[0];
                             // ---- the winner's column to every lane of the problem ----
 #pragma unroll
                             for (int s = 0; s < NS; s++)
@@ -495,59 +625,72 @@ namespace lexls
                             }
                             const double fresh = dfma(c0, c0, (t0 + t1) + t2);
                             const bool cont    = act && !(fresh < a.tol); // rank test on the squared norm (lexlse.h:214)
-                            // 1 / sqrt(fresh): v_rsq_f64 and two coupled iterations (g -> sqrt, h -> 1 / (2 sqrt))
-                            double gq, hq;
+                            // column_permutations: scalar bookkeeping (the winners' positions and the problems' `cont` bits are scalar values)
                             {
-                                const double y = __builtin_amdgcn_rsq(fresh);
-                                gq             = fresh * y;
-                                hq             = 0.5 * y;
-                                double r       = dfma(-hq, gq, 0.5);
-                                gq             = dfma(gq, r, gq);
-                                hq             = dfma(hq, r, hq);
-                                r              = dfma(-hq, gq, 0.5);
-                                gq             = dfma(gq, r, gq);
-                                hq             = dfma(hq, r, hq);
-                            }
-                            const bool neg    = c0 >= 0.0; // beta = -sign(c0) sqrt(fresh)
-                            const double beta = neg ? -gq : gq;
-                            const double ibet = (neg ? -2.0 : 2.0) * hq; // 1 / beta
-                            const double rden = mf_rcp1(c0 - beta);
-                            // ---- every column: R_js = (w . a_s) / beta, rows below a_s += gs w, row j normalised, Jordan step on the rows above ----
+                                const unsigned long long cm = __ballot(cont);
 #pragma unroll
-                            for (int s = 0; s < NS; s++)
-                            {
-                                double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-                                for (int r = j + 1; r < MD; r++)
+                                for (int p = 0; p < G; p++)
                                 {
-                                    if ((r - j) & 1)
-                                        d0 = dfma(w[r], blk[s][r], d0);
-                                    else
-                                        d1 = dfma(w[r], blk[s][r], d1);
+                                    const unsigned cb = (unsigned)((cm >> (LP * p)) & 1ull);
+                                    permw[p][j / 4] |= (cb ? (unsigned)pps[p] : 0u) << (8 * (j % 4));
                                 }
-                                const double dw = dfma(c0, blk[s][j], d0 + d1);
-                                const double t  = dw * ibet;                // R_js
-                                const double gs = (t - blk[s][j]) * rden;   // a_s[r] += gs w[r] (= a_s - tau v v.a_s, lexlse.h:243-246)
-                                const double u  = cont ? t * ibet : 0.0;    // R_js / R_jj; a level that has stopped leaves its rows alone
-                                nrm[s]          = dfma(-t, t, nrm[s]);      // lexlse.h:262-266
-                                nrm[s]          = (cont && iswin[s]) ? kMfSentinel : nrm[s];
-#pragma unroll
-                                for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs, w[r], blk[s][r]);
-                                blk[s][j] = cont ? t * ibet : blk[s][j];
-#pragma unroll
-                                for (int i = 0; i < j; i++) blk[s][i] = dfma(-w[i], u, blk[s][i]);
                             }
-                            // ---- column "swap": the position map (lexlse.h:222-232) ----
-#pragma unroll
-                            for (int s = 0; s < NS; s++)
+                            if (cont) // a level that has stopped leaves its block, norms and maps alone (its lanes sit out)
                             {
-                                const bool front = cont && pos[s] == ColIndex;
-                                pos[s]           = front ? ppos : pos[s];
-                                pos[s]           = (cont && iswin[s]) ? ColIndex : pos[s];
-                                if (cont && iswin[s]) a.perm[(size_t)b * n + ColIndex] = (uint32_t)ppos;
+                                // 1 / sqrt(fresh): v_rsq_f64 and one coupled iteration (g -> sqrt, h -> 1 / (2 sqrt)).  ~2^-45: the reflector need not be
+                                // orthogonal to rounding — N_k = (G A_P)^-1 G A_rest for ANY row transformation G applied to all columns alike; what
+                                // matters is that the pivot column's image is (beta, 0, ..) to a relative 1e-13, and the norms' down-date to 1e-13
+                                double gq, hq;
+                                {
+                                    const double y = __builtin_amdgcn_rsq(fresh);
+                                    gq             = fresh * y;
+                                    hq             = 0.5 * y;
+                                    const double r = dfma(-hq, gq, 0.5);
+                                    gq             = dfma(gq, r, gq);
+                                    hq             = dfma(hq, r, hq);
+                                }
+                                const bool neg    = c0 >= 0.0; // beta = -sign(c0) sqrt(fresh)
+                                const double beta = neg ? -gq : gq;
+                                const double ibet = (neg ? -2.0 : 2.0) * hq; // 1 / beta
+                                const double rden = mf_rcp1(c0 - beta);
+                                // every column: R_js = (w . a_s) / beta, rows below a_s += gs w, row j normalised, Jordan step on the rows above
+#pragma unroll
+                                for (int s = 0; s < NS; s++)
+                                {
+                                    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+                                    for (int r = j + 1; r < MD; r++)
+                                    {
+                                        if ((r - j) & 1)
+                                            d0 = dfma(w[r], blk[s][r], d0);
+                                        else
+                                            d1 = dfma(w[r], blk[s][r], d1);
+                                    }
+                                    const double dw = dfma(c0, blk[s][j], d0 + d1);
+                                    const double t  = dw * ibet;              // R_js
+                                    const double gs = (t - blk[s][j]) * rden; // a_s[r] += gs w[r] (= a_s - tau v v.a_s, lexlse.h:243-246)
+                                    const double u  = t * ibet;               // R_js / R_jj
+                                    nrm[s]          = dfma(-t, t, nrm[s]);    // lexlse.h:262-266
+#pragma unroll
+                                    for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs, w[r], blk[s][r]);
+                                    blk[s][j] = u;
+#pragma unroll
+                                    for (int i = 0; i < j; i++) blk[s][i] = dfma(-w[i], u, blk[s][i]);
+                                }
+                                // column "swap": the position map (lexlse.h:222-232); the pivot column leaves the candidates
+#pragma unroll
+                                for (int s = 0; s < NS; s++)
+                                {
+                                    pos[s] = pos[s] == ColIndex ? ppos : pos[s];
+                                    if (iswin[s])
+                                    {
+                                        pos[s] = ColIndex;
+                                        nrm[s] = kMfSentinel;
+                                    }
+                                }
+                                ColIndex += 1;
+                                rank += 1;
                             }
-                            ColIndex += cont ? 1 : 0;
-                            rank += cont ? 1 : 0;
                             const bool full = cont && ColIndex == n;
                             exh             = exh || full;
                             go              = cont && !full;
@@ -560,7 +703,7 @@ namespace lexls
                 MF_LSTAMP(2)
 
                 // =====================================================================================
-                // level end: N_k = the first `rank` rows of the columns behind the pivots, by local column index; maps
+                // level end: N_k = the first `rank` rows of the columns behind the pivots, by local column index; maps; column_permutations
                 // =====================================================================================
                 {
                     const int S = n + 1 - Fc - rank;
@@ -582,7 +725,16 @@ namespace lexls
                             }
                             if (mv && P0 < n) B8(my + o_phys + pos[s]) = (uint8_t)pc[s];
                         }
-                    if (gl == 0) U4(my + o_meta + 16 * k) = mf_u4{(unsigned)Fc | ((unsigned)rank << 8) | ((unsigned)S << 16), (unsigned)noff, 0u, 0u};
+                    if (gl < rank)
+                    {
+                        unsigned wsel = permw[0][0];
+#pragma unroll
+                        for (int p = 0; p < G; p++)
+#pragma unroll
+                            for (int i = 0; i < (MD + 3) / 4; i++) wsel = (g == p && (gl >> 2) == i) ? permw[p][i] : wsel;
+                        a.perm[(size_t)b * n + Fc + gl] = (wsel >> (8 * (gl & 3))) & 0xffu;
+                    }
+                    if (gl == 0) U64(my + o_meta + 8 * k) = (unsigned long long)((unsigned)Fc | ((unsigned)rank << 8) | ((unsigned)S << 16)) | ((unsigned long long)(unsigned)noff << 32);
                     noff += (work && rank > 0) ? rank * S + ((S + 7) >> 3) : 0;
                     TotalRank += rank;
                 }
@@ -593,14 +745,22 @@ namespace lexls
             // ---- solve(): x_pivots(k) = rhs'_k - N_k x_later, k descending (lexlse.h:1015-1045); lane q <-> row q of a level; x by physical column
             //      in the (idle) level buffer.  A DMA request that nobody consumed (the columns ran out under it) must have landed first ----
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int o_x = o_pf;
-            for (int i = gl; i <= n; i += LP) D(my + o_x + 8 * i) = 0.0;
+#ifdef LEXLS_WAVE_STAMPS
+            {
+                const unsigned long long t_ = clock64();
+                if (gl == 0 && live) a.lambda[(size_t)b * (n + cap) + 8] = (double)(t_ - lst_t00);
+                lst_t0 = t_;
+            }
+#endif
+            const int o_x  = o_pf;       // x by physical column
+            const int o_xl = o_pf + 512; // x by column index in N_k (the operand of a level's product)
+            for (int i = gl; i < 64 + 56; i += LP) D(my + o_x + 8 * i) = 0.0; // (x by physical column and, from o_xl on, by column index: finite everywhere)
             mf_lds_fence();
             for (int k = nObj; k--;)
             {
-                const mf_u4 mt = U4(my + o_meta + 16 * k);
-                const int Fck = (int)(mt.x & 0xffu), rk = live ? (int)((mt.x >> 8) & 0xffu) : 0, Sk = (int)((mt.x >> 16) & 0xffu);
-                const int nofk = (int)mt.y, invk = 8 * (nofk + rk * Sk);
+                const unsigned long long mt = U64(my + o_meta + 8 * k);
+                const int Fck = (int)(mt & 0xffu), rk = live ? (int)((mt >> 8) & 0xffu) : 0, Sk = (int)((mt >> 16) & 0xffu);
+                const int nofk = (int)(unsigned)(mt >> 32), invk = 8 * (nofk + rk * Sk);
                 int rmax = 0, smax = 0;
                 for_each_index<0, G>([&](auto pp) __attribute__((always_inline)) {
                     constexpr int p = decltype(pp)::value;
@@ -609,35 +769,53 @@ namespace lexls
                     smax = s_ > smax ? s_ : smax;
                 });
                 if (rmax == 0) continue;
-                const bool row = gl < rk;
-                const int rowa = my + 8 * (nofk + (row ? gl : 0) * Sk);
-                double s0 = row ? D(rowa + 8 * (Sk - 1)) : 0.0, s1 = 0.0; // the right-hand side is the last column of N_k
-                for (int j = 0; j + 1 < smax; j += 2)
+                // x of the columns behind this level's pivots, by their column index in N_k (zero beyond a problem's own count)
+                for (int j = gl; j < smax - 1; j += LP)
                 {
-                    const bool in0 = row && j < Sk - 1, in1 = row && j + 1 < Sk - 1;
-                    const int p0 = in0 ? (int)B8(my + invk + j) : 0, p1 = in1 ? (int)B8(my + invk + j + 1) : 0;
-                    const double n0 = D(rowa + 8 * (in0 ? j : 0)), n1 = D(rowa + 8 * (in1 ? j + 1 : 0));
-                    const double x0 = D(my + o_x + 8 * p0), x1 = D(my + o_x + 8 * p1);
-                    s0 = dfma(in0 ? -n0 : 0.0, x0, s0);
-                    s1 = dfma(in1 ? -n1 : 0.0, x1, s1);
+                    const bool in = rk > 0 && j < Sk - 1;
+                    const int ph  = in ? (int)B8(my + invk + j) : 0;
+                    const double xv = D(my + o_x + 8 * ph);
+                    D(my + o_xl + 8 * j) = in ? xv : 0.0;
                 }
                 mf_lds_fence();
-                if (row) D(my + o_x + 8 * (int)B8(my + o_phys + Fck + gl)) = s0 + s1;
+                const bool row = gl < rk;
+                const int rowa = my + 8 * (nofk + (row ? gl : 0) * Sk);
+                double s0 = row ? D(rowa + 8 * (Sk - 1)) : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0; // the right-hand side is the last column of N_k
+                for (int j = 0; j < smax - 1; j += 4)
+                {
+                    // (reads beyond a row's own columns stay inside the slice and meet zeros of x)
+                    const double n0 = D(rowa + 8 * j), n1 = D(rowa + 8 * j + 8), n2 = D(rowa + 8 * j + 16), n3 = D(rowa + 8 * j + 24);
+                    const mf_d2 xa = D2(my + o_xl + 8 * j), xb = D2(my + o_xl + 8 * j + 16);
+                    s0 = dfma(-(row && j < Sk - 1 ? n0 : 0.0), xa.x, s0);
+                    s1 = dfma(-(row && j + 1 < Sk - 1 ? n1 : 0.0), xa.y, s1);
+                    s2 = dfma(-(row && j + 2 < Sk - 1 ? n2 : 0.0), xb.x, s2);
+                    s3 = dfma(-(row && j + 3 < Sk - 1 ? n3 : 0.0), xb.y, s3);
+                }
+                if (row) D(my + o_x + 8 * (int)B8(my + o_phys + Fck + gl)) = (s0 + s1) + (s2 + s3);
                 mf_lds_fence();
             }
+#ifdef LEXLS_WAVE_STAMPS
+            {
+                const unsigned long long t_ = clock64();
+                if (gl == 0 && live) a.lambda[(size_t)b * (n + cap) + 9] = (double)(t_ - lst_t0);
+                lst_t0 = t_;
+                if (gl == 0 && live)
+                    for (int i_ = 0; i_ < 8; i_++) a.lambda[(size_t)b * (n + cap) + 32 + i_] = (double)gst[i_];
+            }
+#endif
             // ---- results ----
             if (live)
             {
                 for (int P = gl; P < n; P += LP)
                 {
-                    a.x[(size_t)b * n + P]    = D(my + o_x + 8 * P); // x of the variable (physical column) P: x = P x already applied (lexlse.h:1044)
-                    if (P >= TotalRank) a.perm[(size_t)b * n + P] = (uint32_t)P; // (the pivots' entries were stored as they were chosen)
+                    a.x[(size_t)b * n + P] = D(my + o_x + 8 * P); // x of the variable (physical column) P: x = P x already applied (lexlse.h:1044)
+                    if (P >= TotalRank) a.perm[(size_t)b * n + P] = (uint32_t)P; // (the pivots' entries were stored level by level)
                 }
                 if (gl < nObj)
                 {
-                    const mf_u4 mt                = U4(my + o_meta + 16 * gl);
-                    a.fcol[(size_t)b * nObj + gl] = mt.x & 0xffu;
-                    a.rank[(size_t)b * nObj + gl] = (mt.x >> 8) & 0xffu;
+                    const unsigned long long mt   = U64(my + o_meta + 8 * gl);
+                    a.fcol[(size_t)b * nObj + gl] = (uint32_t)(mt & 0xffu);
+                    a.rank[(size_t)b * nObj + gl] = (uint32_t)((mt >> 8) & 0xffu);
                 }
                 if (gl == 0) a.totalrank[b] = (uint32_t)TotalRank;
             }
@@ -672,7 +850,7 @@ namespace lexls
         inline size_t mfma_group_bytes(uint32_t n, uint32_t nObj)
         {
             const size_t pfb = 8u * MD * (size_t)(n + 1) > 128u * MD ? 8u * MD * (size_t)(n + 1) : 128u * MD;
-            const size_t raw = 8 * (size_t)mfma_nd_doubles(n, nObj, MD) + pfb + 8 * MD + 48 + 16 * (size_t)nObj + 8 * (size_t)(n + 1);
+            const size_t raw = 8 * (size_t)mfma_nd_doubles(n, nObj, MD) + pfb + 8 * MD + 16 + 48 + 8 * (size_t)nObj + 8 * (size_t)(n + 1);
             // (no padding against bank conflicts between the problems of a wavefront: the LDS serves a wave's 8- and 16-byte accesses in lane groups
             // that never mix the two halves of the wavefront, MI355X_MICROARCH.md LDS table)
             return (raw + 15) & ~(size_t)15;
