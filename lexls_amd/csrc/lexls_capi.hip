@@ -701,7 +701,7 @@ extern "C"
     static int tolerance_mode(lexls_lse_t h)
     {
         if (h->fused_gather) return 0;
-        if (h->force_generic == 6 || h->force_generic == 7 || h->force_generic == 8) return h->force_generic;
+        if (h->force_generic >= 6 && h->force_generic <= 9) return h->force_generic;
         if (h->force_generic != 0) return 0;
         const char *e = std::getenv("LEXLS_QTOL");
         return (e && std::atoi(e) == 0) ? 0 : 1;

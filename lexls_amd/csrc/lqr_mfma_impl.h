@@ -170,9 +170,9 @@ namespace lexls
         /// LP lanes per problem (32: two problems per wavefront, two wavefronts per SIMD; 64: one problem, four wavefronts per SIMD);
         /// NV: the number of variables when the instantiation serves ONE n (0: taken from the arguments)
         template <int LP, int MD, int NV>
-        __global__ __launch_bounds__(256, (LP == 64 ? 4 : 2)) void lqr_mfma_kernel(LseArgs a, uint32_t nd_doubles, uint32_t group_bytes)
+        __global__ __launch_bounds__(256, (LP == 64 ? 4 : (LP == 32 ? 2 : 1))) void lqr_mfma_kernel(LseArgs a, uint32_t nd_doubles, uint32_t group_bytes, uint32_t stagger)
         {
-            static_assert((LP == 32 || LP == 64) && (MD == 12 || MD == 16), "mappings / level sizes served");
+            static_assert((LP == 16 || LP == 32 || LP == 64) && (MD == 12 || MD == 16), "mappings / level sizes served");
             constexpr int G   = 64 / LP;            // problems per wavefront
             constexpr int NSM = (48 + LP - 1) / LP; // slots of a lane
             constexpr int NT  = 3;                  // 16-position tiles of the matrix-core layout (n + 1 <= 48)
@@ -228,7 +228,7 @@ namespace lexls
             //   o_pf        [column][MD]: the level loaded ahead / scratch of the Gauss step ([pivot][16 rows], then [position][MD]) / x by physical
             //               column and by column index during solve()
             //   o_bc        MD doubles: broadcast slot of the pivot steps
-            //   o_mx        2 doubles: the maximum of the down-dated norms (LDS atomic), even / odd pivot steps
+            //   o_mx        2 doubles, always zero: what an operand that does not apply reads
             //   o_phys      48 B: physical column at each position (column_permutations go straight to HBM)
             //   o_meta      per level {Fc | rank << 8 | S << 16, offset of N_e (doubles)}
             //   o_emap      per physical column: byte k = its column index in N_k
@@ -243,7 +243,7 @@ namespace lexls
 
             for (int i = gl; i < 48; i += LP) B8(my + o_phys + i) = (uint8_t)i;
             for (int i = gl; i <= n; i += LP) D(my + o_emap + 8 * i) = 0.0;
-            for (int i = gl; i < MD + 2; i += LP) D(my + o_bc + 8 * i) = i < MD ? 0.0 : kMfSentinel;
+            for (int i = gl; i < MD + 2; i += LP) D(my + o_bc + 8 * i) = 0.0; // (o_mx: the slice's zero words)
             mf_lds_fence();
 
             // ---- a level's rows by LDS-DMA: 16-byte pieces, piece t = 64 i + lane -> column t / HP, rows 2 (t % HP) .. +1; LDS image [column][MD] ----
@@ -284,6 +284,15 @@ namespace lexls
                     }
             };
 
+            // The wavefronts that share a SIMD run the same program on the same schedule: left alone they reach every LDS round trip of the pivot
+            // chain together and wait together.  Every second wavefront slot starts `stagger` x 64 cycles late
+            if (stagger)
+            {
+                const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11)); // HW_REG_HW_ID, bits [3:0] = wave slot of the SIMD
+                if (hwid & 1u)
+                    for (unsigned i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(1);
+            }
+
             int pos[NSM]; // current position of the column held in slot s
             int pc[NSM];  // its physical column
 #pragma unroll
@@ -319,7 +328,8 @@ namespace lexls
                 // =====================================================================================
                 // serial mode: Gauss elimination of this level's rows by the finished levels (lexlse.h:431-471) on the matrix cores.
                 // The problems of the wavefront go through every stage together (straight-line code: their LDS round trips and matrix
-                // instructions overlap); what does not apply is a zero operand, never a branch around a matrix instruction
+                // instructions overlap); what does not apply reads a zero (the slice's zero word), never a branch around a matrix instruction.
+                // N_e is stored NEGATED: C += M N'_e with the multipliers M taken as they stand.
                 // =====================================================================================
                 if (k > 0)
                 {
@@ -339,6 +349,22 @@ namespace lexls
                     MF_GSTAMP(0)
                     mf_d4 C[G][NT];
                     unsigned long long emw[G][NT];
+                    int mxs[G][kMfMaxObj - 1], nos[G][kMfMaxObj - 1]; // the finished levels' records (scalar registers): read together, ahead of their use
+                    {
+                        unsigned long long mtv[G][kMfMaxObj - 1];
+#pragma unroll
+                        for (int p = 0; p < G; p++)
+#pragma unroll
+                            for (int e = 0; e < kMfMaxObj - 1; e++) mtv[p][e] = e < k ? U64(sp[p] + o_meta + 8 * e) : 0ull;
+#pragma unroll
+                        for (int p = 0; p < G; p++)
+#pragma unroll
+                            for (int e = 0; e < kMfMaxObj - 1; e++)
+                            {
+                                mxs[p][e] = __builtin_amdgcn_readfirstlane((int)(unsigned)mtv[p][e]);
+                                nos[p][e] = __builtin_amdgcn_readfirstlane((int)(unsigned)(mtv[p][e] >> 32));
+                            }
+                    }
 #pragma unroll
                     for (int p = 0; p < G; p++)
 #pragma unroll
@@ -350,30 +376,51 @@ namespace lexls
 #pragma unroll
                             for (int v = 0; v < 4; v++)
                             {
-                                const double rd = D(sp[p] + o_pf + ph * CB + 8 * (v < NV4 ? gg + 4 * v : 0));
-                                C[p][t][v]      = (v < NV4 && P <= n && wk[p]) ? rd : 0.0;
+                                const double rd = D((v < NV4 && P <= n && wk[p]) ? sp[p] + o_pf + ph * CB + 8 * (gg + 4 * v) : sp[p] + o_mx);
+                                C[p][t][v]      = rd;
                             }
                         }
-                    mf_lds_fence();
                     MF_GSTAMP(1)
-                    for (int e = 0; e < k; e++)
-                    {
+                    for_each_index<0, kMfMaxObj - 1>([&](auto ec) __attribute__((always_inline)) {
+                        constexpr int e = decltype(ec)::value;
+                        if (e >= k) return; // wave-uniform
                         int Fce[G], re[G], Se[G], Noffe[G];
                         int tmin = NT;
 #pragma unroll
                         for (int p = 0; p < G; p++)
                         {
-                            const unsigned long long mt = U64(sp[p] + o_meta + 8 * e);
-                            const int mx                = __builtin_amdgcn_readfirstlane((int)(unsigned)mt);
-                            Noffe[p]                    = __builtin_amdgcn_readfirstlane((int)(unsigned)(mt >> 32));
-                            Fce[p]                      = mx & 0xff;
-                            re[p]                       = wk[p] ? (mx >> 8) & 0xff : 0;
-                            Se[p]                       = (mx >> 16) & 0xff;
-                            const int tm                = (Fce[p] + re[p]) >> 4;
-                            tmin                        = (re[p] > 0 && tm < tmin) ? tm : tmin;
+                            const int mx = mxs[p][e];
+                            Noffe[p]     = nos[p][e];
+                            Fce[p]       = mx & 0xff;
+                            re[p]        = wk[p] ? (mx >> 8) & 0xff : 0;
+                            Se[p]        = (mx >> 16) & 0xff;
+                            const int tm = (Fce[p] + re[p]) >> 4;
+                            tmin         = (re[p] > 0 && tm < tmin) ? tm : tmin;
                         }
-                        if (tmin >= NT) continue; // nobody has pivots at this level (wave-uniform)
-                        // this row block's entries at e's pivot positions -> scratch [pivot q][16 rows]
+                        if (tmin >= NT) return; // nobody has pivots at this level (wave-uniform)
+                        // B operand = N'_e, lane (column c16, k = gg): its reads do not depend on C — issued first, they run beside the previous
+                        // level's matrix instructions.  k-step ks <-> pivots 4 ks .. 4 ks + 3
+                        double Bop[G][NV4][NT];
+#pragma unroll
+                        for (int p = 0; p < G; p++)
+                        {
+                            const int vb = sp[p] + 8 * Noffe[p] + gg * (8 * Se[p]);
+#pragma unroll
+                            for (int t = 0; t < NT; t++)
+                            {
+                                const int P     = 16 * t + c16;
+                                const int j     = (int)(((unsigned)(emw[p][t] >> (8 * (e & 3) + 32 * (e >> 2)))) & 0xffu);
+                                const bool vt   = P >= Fce[p] + re[p] && P <= n;
+                                const int jaddr = vb + 8 * j;
+#pragma unroll
+                                for (int ks = 0; ks < NV4; ks++)
+                                {
+                                    const bool valid = vt && 4 * ks + gg < re[p];
+                                    Bop[p][ks][t]    = D(valid ? jaddr + ks * (32 * Se[p]) : sp[p] + o_mx);
+                                }
+                            }
+                        }
+                        // this row block's entries at e's pivot positions -> scratch [pivot q][16 rows] (waits for the previous level's products)
 #pragma unroll
                         for (int p = 0; p < G; p++)
 #pragma unroll
@@ -386,27 +433,17 @@ namespace lexls
                                     for (int v = 0; v < NV4; v++) D(sp[p] + o_pf + q * 128 + 8 * (gg + 4 * v)) = C[p][t][v];
                                 }
                             }
-                        mf_lds_fence();
+                        mf_lds_fence(); // (lanes read what OTHER lanes stored: without the fence the compiler may move a lane's load above the store)
                         MF_GSTAMP(2)
-                        // operands: A = -multipliers, lane (row c16, k = gg); B = N_e, lane (column c16, k = gg); k-step ks <-> pivots 4 ks .. 4 ks + 3
-                        double Aop[G][NV4], Bop[G][NV4][NT];
+                        // A operand = multipliers, lane (row c16, k = gg)
+                        double Aop[G][NV4];
 #pragma unroll
                         for (int p = 0; p < G; p++)
 #pragma unroll
                             for (int ks = 0; ks < NV4; ks++)
                             {
-                                const int q     = 4 * ks + gg;
-                                const double rd = D(sp[p] + o_pf + q * 128 + 8 * c16);
-                                Aop[p][ks]      = (q < re[p] && c16 < MD) ? -rd : 0.0;
-#pragma unroll
-                                for (int t = 0; t < NT; t++)
-                                {
-                                    const int P      = 16 * t + c16;
-                                    const int j      = (int)((emw[p][t] >> (8 * e)) & 0xffull);
-                                    const bool valid = P >= Fce[p] + re[p] && P <= n && q < re[p];
-                                    const double rb  = D(sp[p] + 8 * (valid ? Noffe[p] + q * Se[p] + j : 0));
-                                    Bop[p][ks][t]    = valid ? rb : 0.0;
-                                }
+                                const int q = 4 * ks + gg;
+                                Aop[p][ks]  = D((q < re[p] && c16 < MD) ? sp[p] + o_pf + q * 128 + 8 * c16 : sp[p] + o_mx);
                             }
                         // tiles in front of every problem's pivots of this level are not touched (wave-uniform choice of the first tile)
                         auto run_tiles = [&](auto t0c) __attribute__((always_inline)) {
@@ -424,9 +461,8 @@ namespace lexls
                             run_tiles(std::integral_constant<int, 1>{});
                         else
                             run_tiles(std::integral_constant<int, 2>{});
-                        mf_lds_fence();
                         MF_GSTAMP(3)
-                    }
+                    });
                     // the eliminated rows, by position: [position][MD]
 #pragma unroll
                     for (int p = 0; p < G; p++)
@@ -524,16 +560,32 @@ namespace lexls
                 // What is uniform per problem lives in scalar registers as lane masks / readlane results: the decision costs the vector unit one
                 // maximum, one LDS atomic and one compare; everything a stopped level must not do is skipped under its lanes' exec bits.
                 // =====================================================================================
-                unsigned permw[G][(MD + 3) / 4]; // column_permutations of this level's pivots, four per word (scalar registers)
+                // What is uniform per problem is ALSO kept in scalar registers (act_s, col_s, rank_s, the winners' positions): scalar instructions
+                // issue beside the other wavefront's vector instructions, and turning a lane mask into an integer costs vector instructions
+                unsigned permw[G][(MD + 3) / 4]; // column_permutations of this level's pivots, four per word
+                int act_s[G], col_s[G], rank_s[G];
 #pragma unroll
                 for (int p = 0; p < G; p++)
+                {
 #pragma unroll
                     for (int i = 0; i < (MD + 3) / 4; i++) permw[p][i] = 0u;
+                    act_s[p]  = __builtin_amdgcn_readlane((int)work, p * LP);
+                    col_s[p]  = __builtin_amdgcn_readlane(ColIndex, p * LP);
+                    rank_s[p] = 0;
+                }
+                // (a problem without work has no candidates: one lane with a zero norm keeps its "maximum" unique, so that it never asks for
+                // the tie path below)
+                if (!work) nrm[0] = gl == 0 ? 0.0 : kMfSentinel;
                 auto factor_level = [&](auto nsc) __attribute__((always_inline)) {
                     constexpr int NS = decltype(nsc)::value;
                     bool go = work;
                     mf_for_each_while<0, MD>(
-                        [&](auto jc) __attribute__((always_inline)) { return (decltype(jc)::value % 4 != 0) || __ballot(go) != 0ull; },
+                        [&](auto jc) __attribute__((always_inline)) {
+                            int any = 0;
+#pragma unroll
+                            for (int p = 0; p < G; p++) any |= act_s[p];
+                            return (decltype(jc)::value % 4 != 0) || any != 0;
+                        },
                         [&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
                             const bool act  = go;
@@ -547,18 +599,25 @@ namespace lexls
                             for (int s = 1; s < NS; s++) hl = __double2hiint(nrm[s]) > hl ? __double2hiint(nrm[s]) : hl;
                             const int mh = mf_grp_maxi<LP>(hl);
                             bool iswin[NS];
-                            bool any = false, two = false;
+                            unsigned long long mk = 0ull, two = 0ull;
 #pragma unroll
                             for (int s = 0; s < NS; s++)
                             {
-                                iswin[s] = act && __double2hiint(nrm[s]) == mh;
-                                two      = two || (any && iswin[s]);
-                                any      = any || iswin[s];
+                                iswin[s]                     = __double2hiint(nrm[s]) == mh;
+                                const unsigned long long ms = __builtin_amdgcn_uicmp((unsigned)__double2hiint(nrm[s]), (unsigned)mh, 32 /* == */);
+                                two |= mk & ms;
+                                mk |= ms;
                             }
-                            const unsigned long long mk = __ballot(any);
-                            bool tie = __ballot(two || (act && mh < 0)) != 0ull;
+                            const unsigned long long negm = __builtin_amdgcn_sicmp(mh, 0, 40 /* signed < */);
+                            bool tie                      = two != 0ull;
+                            int wl[G];
 #pragma unroll
-                            for (int p = 0; p < G; p++) tie = tie || __builtin_popcountll(LP == 64 ? mk : (mk >> (32 * p)) & 0xffffffffull) > 1;
+                            for (int p = 0; p < G; p++)
+                            {
+                                const unsigned long long h = LP == 64 ? mk : (mk >> (LP * p)) & ((1ull << (LP & 63)) - 1ull);
+                                tie                        = tie || (act_s[p] && (__builtin_popcountll(h) > 1 || ((negm >> (LP * p)) & 1ull)));
+                                wl[p]                      = h ? (int)__builtin_ctzll(h) + LP * p : LP * p;
+                            }
                             if (tie) // (wave-uniform, rare)
                             {
                                 double mv = kMfSentinel;
@@ -569,41 +628,44 @@ namespace lexls
 #pragma unroll
                                 for (int s = 0; s < NS; s++)
                                 {
-                                    iswin[s]         = act && nrm[s] == mv && nrm[s] > 0.5 * kMfSentinel;
+                                    iswin[s]         = nrm[s] == mv && nrm[s] > 0.5 * kMfSentinel;
                                     const unsigned c = iswin[s] ? (unsigned)pos[s] : 0xffffu;
                                     pk               = c < pk ? c : pk;
                                 }
                                 const unsigned wp = mf_grp_minu<LP>(pk);
+                                unsigned long long wm = 0ull;
 #pragma unroll
-                                for (int s = 0; s < NS; s++) iswin[s] = iswin[s] && (unsigned)pos[s] == wp;
+                                for (int s = 0; s < NS; s++)
+                                {
+                                    iswin[s] = iswin[s] && (unsigned)pos[s] == wp;
+                                    wm |= __ballot(iswin[s]);
+                                }
+#pragma unroll
+                                for (int p = 0; p < G; p++)
+                                {
+                                    const unsigned long long h = LP == 64 ? wm : (wm >> (LP * p)) & ((1ull << (LP & 63)) - 1ull);
+                                    wl[p]                      = h ? (int)__builtin_ctzll(h) + LP * p : LP * p;
+                                }
                             }
                             // the winner's position, per problem in a scalar register
                             int wposl = pos[0];
 #pragma unroll
                             for (int s = 1; s < NS; s++) wposl = iswin[s] ? pos[s] : wposl;
-                            bool anyw = false;
-#pragma unroll
-                            for (int s = 0; s < NS; s++) anyw = anyw || iswin[s];
-                            const unsigned long long wm = __ballot(anyw);
                             int pps[G];
 #pragma unroll
-                            for (int p = 0; p < G; p++)
-                            {
-                                const unsigned long long h = LP == 64 ? wm : (wm >> (32 * p)) & 0xffffffffull;
-                                const int wl               = h ? (int)__builtin_ctzll(h) + LP * p : LP * p;
-                                pps[p]                     = __builtin_amdgcn_readlane(wposl, wl);
-                            }
+                            for (int p = 0; p < G; p++) pps[p] = __builtin_amdgcn_readlane(wposl, wl[p]);
                             int ppos = pps[0];
-                            if constexpr (G > 1) ppos = g ? pps[G - 1] : pps[0];
-                            // ---- the winner's column to every lane of the problem ----
+#pragma unroll
+                            for (int p = 1; p < G; p++) ppos = g == p ? pps[p] : ppos;
+                            // ---- the winner's column to every lane of the problem (a problem that has stopped may write: nobody uses it) ----
 #pragma unroll
                             for (int s = 0; s < NS; s++)
-                                if (iswin[s] && act)
+                                if (iswin[s])
                                 {
 #pragma unroll
                                     for (int r = 0; r < MD; r += 2) D2(my + o_bc + 8 * r) = mf_d2{blk[s][r], blk[s][r + 1]};
                                 }
-                            mf_lds_fence();
+                            mf_lds_fence(); // (lanes read what another lane stored: without the fence the compiler may move a lane's load above the store)
                             double w[MD];
 #pragma unroll
                             for (int r = 0; r < MD; r += 2)
@@ -612,7 +674,6 @@ namespace lexls
                                 w[r]          = v.x;
                                 w[r + 1]      = v.y;
                             }
-                            mf_lds_fence();
                             const double c0 = w[j];
                             // tail norm in three partial sums, fresh norm = c0^2 + tail (lexlse.h:210-211, :241)
                             double t0 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -624,15 +685,19 @@ namespace lexls
                                 if ((r - j) % 3 == 0) t2 = dfma(w[r], w[r], t2);
                             }
                             const double fresh = dfma(c0, c0, (t0 + t1) + t2);
-                            const bool cont    = act && !(fresh < a.tol); // rank test on the squared norm (lexlse.h:214)
-                            // column_permutations: scalar bookkeeping (the winners' positions and the problems' `cont` bits are scalar values)
+                            const bool okf     = !(fresh < a.tol); // rank test on the squared norm (lexlse.h:214)
+                            const bool cont    = act && okf;
+                            // scalar bookkeeping: which problems go on, their column counters, column_permutations
                             {
-                                const unsigned long long cm = __ballot(cont);
+                                const unsigned long long om = __builtin_amdgcn_fcmp(fresh, a.tol, 11 /* unordered or >= : !(fresh < tol) */);
 #pragma unroll
                                 for (int p = 0; p < G; p++)
                                 {
-                                    const unsigned cb = (unsigned)((cm >> (LP * p)) & 1ull);
-                                    permw[p][j / 4] |= (cb ? (unsigned)pps[p] : 0u) << (8 * (j % 4));
+                                    const int cs = act_s[p] & (int)((om >> (LP * p)) & 1ull);
+                                    permw[p][j / 4] |= (cs ? (unsigned)pps[p] : 0u) << (8 * (j % 4));
+                                    col_s[p] += cs;
+                                    rank_s[p] += cs;
+                                    act_s[p] = cs && col_s[p] != n;
                                 }
                             }
                             if (cont) // a level that has stopped leaves its block, norms and maps alone (its lanes sit out)
@@ -696,17 +761,31 @@ namespace lexls
                             go              = cont && !full;
                         });
                 };
-                if (NSM > 1 && ns > 1)
-                    factor_level(std::integral_constant<int, NSM>{});
+                if (NSM > 2 && ns > 2)
+                    factor_level(std::integral_constant<int, (NSM > 2 ? 3 : 1)>{});
+                else if (NSM > 1 && ns > 1)
+                    factor_level(std::integral_constant<int, (NSM > 1 ? 2 : 1)>{});
                 else
                     factor_level(std::integral_constant<int, 1>{});
                 MF_LSTAMP(2)
 
                 // =====================================================================================
-                // level end: N_k = the first `rank` rows of the columns behind the pivots, by local column index; maps; column_permutations
+                // level end: N'_k = minus the first `rank` rows of the columns behind the pivots, by local column index; maps; column_permutations
                 // =====================================================================================
                 {
                     const int S = n + 1 - Fc - rank;
+                    bool same = true; // every working problem of the wavefront has the same rank (the usual case): the row loop is scalar
+                    int rk0   = 0;
+#pragma unroll
+                    for (int p = 0; p < G; p++)
+                    {
+                        const int w_ = __builtin_amdgcn_readlane((int)work, p * LP);
+                        if (w_)
+                        {
+                            same = same && (rk0 == 0 || rank_s[p] == rk0 || rank_s[p] == 0);
+                            rk0  = rank_s[p] > rk0 ? rank_s[p] : rk0;
+                        }
+                    }
 #pragma unroll
                     for (int s = 0; s < NSM; s++)
                         if (s < ns)
@@ -714,15 +793,25 @@ namespace lexls
                             const int P0     = Fc + LP * s + gl;
                             const bool mv    = work && P0 <= n;
                             const int j      = pos[s] - (Fc + rank);
-                            const bool free_ = mv && j >= 0;
+                            const bool free_ = mv && j >= 0 && rank > 0;
                             if (free_)
                             {
+                                const int na = my + 8 * (noff + j);
+                                if (same)
+                                {
 #pragma unroll
-                                for (int q = 0; q < MD; q++)
-                                    if (q < rank) D(my + 8 * (noff + q * S + j)) = blk[s][q];
-                                B8(my + o_emap + 8 * pc[s] + k) = (uint8_t)j;
-                                if (rank > 0) B8(my + 8 * (noff + rank * S) + j) = (uint8_t)pc[s];
+                                    for (int q = 0; q < MD; q++)
+                                        if (q < rk0) D(na + 8 * q * S) = -blk[s][q]; // (wave-uniform bound)
+                                }
+                                else
+                                {
+#pragma unroll
+                                    for (int q = 0; q < MD; q++)
+                                        if (q < rank) D(na + 8 * q * S) = -blk[s][q];
+                                }
+                                B8(my + 8 * (noff + rank * S) + j) = (uint8_t)pc[s];
                             }
+                            if (mv && j >= 0) B8(my + o_emap + 8 * pc[s] + k) = (uint8_t)j;
                             if (mv && P0 < n) B8(my + o_phys + pos[s]) = (uint8_t)pc[s];
                         }
                     if (gl < rank)
@@ -780,16 +869,16 @@ namespace lexls
                 mf_lds_fence();
                 const bool row = gl < rk;
                 const int rowa = my + 8 * (nofk + (row ? gl : 0) * Sk);
-                double s0 = row ? D(rowa + 8 * (Sk - 1)) : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0; // the right-hand side is the last column of N_k
+                double s0 = row ? -D(rowa + 8 * (Sk - 1)) : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0; // the right-hand side is the last column of N_k (rows stored negated)
                 for (int j = 0; j < smax - 1; j += 4)
                 {
                     // (reads beyond a row's own columns stay inside the slice and meet zeros of x)
                     const double n0 = D(rowa + 8 * j), n1 = D(rowa + 8 * j + 8), n2 = D(rowa + 8 * j + 16), n3 = D(rowa + 8 * j + 24);
                     const mf_d2 xa = D2(my + o_xl + 8 * j), xb = D2(my + o_xl + 8 * j + 16);
-                    s0 = dfma(-(row && j < Sk - 1 ? n0 : 0.0), xa.x, s0);
-                    s1 = dfma(-(row && j + 1 < Sk - 1 ? n1 : 0.0), xa.y, s1);
-                    s2 = dfma(-(row && j + 2 < Sk - 1 ? n2 : 0.0), xb.x, s2);
-                    s3 = dfma(-(row && j + 3 < Sk - 1 ? n3 : 0.0), xb.y, s3);
+                    s0 = dfma((row && j < Sk - 1 ? n0 : 0.0), xa.x, s0);
+                    s1 = dfma((row && j + 1 < Sk - 1 ? n1 : 0.0), xa.y, s1);
+                    s2 = dfma((row && j + 2 < Sk - 1 ? n2 : 0.0), xb.x, s2);
+                    s3 = dfma((row && j + 3 < Sk - 1 ? n3 : 0.0), xb.y, s3);
                 }
                 if (row) D(my + o_x + 8 * (int)B8(my + o_phys + Fck + gl)) = (s0 + s1) + (s2 + s3);
                 mf_lds_fence();
@@ -864,7 +953,7 @@ namespace lexls
             const size_t gbytes  = mfma_group_bytes<MD>(a.nVar, a.nObj);
             const size_t lds     = 4 * G * gbytes;
             // (two / four wavefronts per SIMD are the point of the mapping: the workgroups of a CU must fit its LDS together)
-            if (lds * (LP == 64 ? 4 : 2) > kMaxLdsBytes || a.nObj > (uint32_t)kMfMaxObj || a.nVar + 1 > 48u || a.nVar < 1u || (NV && a.nVar != (uint32_t)NV)) return hipErrorInvalidValue;
+            if (lds * (LP == 64 ? 4 : (LP == 32 ? 2 : 1)) > kMaxLdsBytes || a.nObj > (uint32_t)kMfMaxObj || a.nVar + 1 > 48u || a.nVar < 1u || (NV && a.nVar != (uint32_t)NV)) return hipErrorInvalidValue;
             if (a.uniform_dim != (uint32_t)MD || (a.cap & 1u) || (reinterpret_cast<uintptr_t>(a.in) & 15u) || a.nfixed || a.reg_type != 0) return hipErrorInvalidValue;
             if (lds > 64 * 1024)
             {
@@ -879,7 +968,9 @@ namespace lexls
                 }
             }
             const uint32_t blocks = (a.batch + 4u * G - 1u) / (4u * G);
-            hipLaunchKernelGGL((lqr_mfma_kernel<LP, MD, NV>), dim3(blocks), dim3(256), lds, s, a, nd, (uint32_t)gbytes);
+            const char *st_env     = std::getenv("LEXLS_MFMA_STAGGER"); // x 64 cycles; diagnostic knob
+            const uint32_t stagger = st_env ? (uint32_t)std::atoi(st_env) : (LP == 32 ? 8u : 0u);
+            hipLaunchKernelGGL((lqr_mfma_kernel<LP, MD, NV>), dim3(blocks), dim3(256), lds, s, a, nd, (uint32_t)gbytes, stagger);
             return hipGetLastError();
         }
     } // namespace

@@ -46,6 +46,7 @@ namespace lexls
     size_t launch_mfma_32x12n40_lds(uint32_t nVar, uint32_t nObj);
     hipError_t launch_mfma_32x12(const LseArgs &a, hipStream_t s);
     size_t launch_mfma_32x12_lds(uint32_t nVar, uint32_t nObj);
+    hipError_t launch_mfma_16x12n40(const LseArgs &a, hipStream_t s);
     hipError_t launch_mfma_64x12(const LseArgs &a, hipStream_t s);
     size_t launch_mfma_64x12_lds(uint32_t nVar, uint32_t nObj);
 
@@ -157,6 +158,11 @@ namespace lexls
         const uint32_t nc = a.nVar + 1;
         // tolerance: 0 bit-exact kernels only; 1 automatic (the matrix-core kernel where it serves, else lqr_qtol); 6 lqr_qtol; 7 / 8 lqr_mfma with
         // two / one problem per wavefront
+        if (tolerance == 9 && mfma_choice(a, write_factor, has_fixed, false) == 1)
+        {
+            *variant = "lqr_mfma<16,12,n40>";
+            return launch_mfma_16x12n40(a, s);
+        }
         if (tolerance == 1 || tolerance == 7 || tolerance == 8)
             switch (mfma_choice(a, write_factor, has_fixed, tolerance == 8))
             {
