@@ -64,6 +64,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("LEXLS_BENCH_FAIL_RANK") == str(rank) and world > 1:  # test hook of the launcher's failure path (tests/test_bench_launcher.py)
+        sys.stderr.write("bench.py: failing on request (LEXLS_BENCH_FAIL_RANK)\n")
+        raise SystemExit(7)
     if args.dry_run:
         return dry_run(args, world, rank)
 
@@ -77,10 +80,11 @@ def main():
     coll_device = "cuda" if args.dist_backend == "nccl" else "cpu"  # where the few collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        rdv = {"init_method": os.environ["LEXLS_BENCH_RDV"], "rank": rank, "world_size": world} if os.environ.get("LEXLS_BENCH_RDV") else {}
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(minutes=5))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(minutes=5), **rdv)
         else:
-            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=5))
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=5), **rdv)
 
     import lexls_amd
     from lexls_amd import problems as P
@@ -147,8 +151,10 @@ def main():
         gathered = [torch.zeros_like(checksum) for _ in range(world)]
         dist.all_gather(gathered, checksum)
         all_ok = all(bool(g[1].item()) and np.isfinite(g[0].item()) for g in gathered)
+        shard_checksums = [float(g[0].item()) for g in gathered]
     else:
         all_ok = ranks_ok and np.isfinite(checksum[0].item())
+        shard_checksums = [float(checksum[0].item())]
     if not all_ok:
         raise SystemExit("bench: wrong ranks / non-finite solution — refusing to report a number")
 
@@ -248,7 +254,11 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per * batch, "kernel_ms": kernel_ms, "resident_batches": nres,
                          "resident_bytes": int(nres * lod_host.nbytes),
                          "bytes_touched_per_launch": touched * batch, "frac_on_bytes_touched": touched * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "contract": "pivots / ranks exact, x within 1e-10 (lqr_qtol)" if solver.last_kernel().startswith("lqr_qtol") else "bit-identical to the oracle"},
+                         "note": "frac = SURVEY 8(d)'s algorithmic bytes (20,000 B/problem) / time / peak, as bench.py's contract defines it; the x-only kernel never reads "
+                                 "level 4 (its columns are exhausted): frac_on_bytes_touched is the share of the bytes it moves",
+                         "contract": ("pivots / ranks exact (norms within 2^-40 of each other ordered by position), x within 1e-10 (lqr_qtol)" if solver.last_kernel().startswith("lqr_qtol")
+                                      else "pivots / ranks exact (norms compared by value), x within 1e-10 (lqr_mfma)" if solver.last_kernel().startswith("lqr_mfma")
+                                      else "bit-identical to the oracle")},
             # the same launch against the fp64 vector peak (the path is issue-bound, not byte-bound: DESIGN.md section 5)
             "roofline_fp64": {"bound": "fp64 vector", "achieved": flops_per * batch / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": flops_per * batch / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
@@ -259,6 +269,7 @@ def main():
             line["factor_kept"] = side_factor_kept(solver, stream, ptrs, nres, batch, torch)
             line["config1_large"] = side_config1_large(device_index, not args.no_cpu_baseline)
             line["config4_lsi"] = side_config4_lsi(device_index, not args.no_cpu_baseline)
+        line["shard_checksums"] = shard_checksums  # sum |x| of every rank's shard (all ranks' ranks were verified before this line is printed)
         if scatter_gather is not None:
             line["scatter_gather"] = scatter_gather
             line["scatter_gather_ok"] = bool("error" not in scatter_gather and scatter_gather.get("blocks_verified"))
@@ -354,24 +365,57 @@ def host_cpu_share():
 
 
 def self_launch(n):
-    """python bench.py --gpus N without a launcher: N child processes (one rank per GPU), 127.0.0.1 rendezvous, rank 0's stdout is ours."""
-    import socket
+    """python bench.py --gpus N without a launcher: N child processes (one rank per GPU), 127.0.0.1 rendezvous, rank 0's stdout is ours.
+    Every child is watched: the first one that exits with an error takes the others down with it (a rank that dies before the rendezvous
+    would otherwise leave the rest in init_process_group until its timeout) and its stderr tail is shown; the launcher exits with that code."""
     import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    procs = []
+    import tempfile
+    rdv = tempfile.NamedTemporaryFile(prefix="lexls_bench_rdv_", delete=False)  # file:// rendezvous: no probed port that another process could take
+    rdv.close()
+    os.unlink(rdv.name)
+    procs, errs = [], []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", LEXLS_BENCH_RDV="file://" + rdv.name)
+        env.setdefault("MASTER_PORT", "29531")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        err = tempfile.TemporaryFile()
+        errs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err))
+    import threading
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)  # (rank 0's pipe must be drained while we poll)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, pr in enumerate(procs):
+            if pr.poll() not in (None, 0):
+                failed = r
+                break
+        time.sleep(0.05)
+    if failed is None:
+        failed = next((r for r, pr in enumerate(procs) if pr.returncode != 0), None)
+    if failed is not None:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except Exception:  # noqa: BLE001
+                pr.kill()
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(out_chunks).decode())
     sys.stdout.flush()
-    if any(codes):
-        raise SystemExit(f"bench.py: rank exit codes {codes}")
+    try:
+        os.unlink(rdv.name)
+    except OSError:
+        pass
+    if failed is not None:
+        errs[failed].seek(0)
+        tail = errs[failed].read().decode(errors="replace")[-2000:]
+        sys.stderr.write(f"bench.py: rank {failed} exited with code {procs[failed].returncode}; the other ranks were stopped\n{tail}\n")
+        raise SystemExit(procs[failed].returncode or 1)
 
 
 def dry_run(args, world, rank):
@@ -380,7 +424,8 @@ def dry_run(args, world, rank):
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=2))
+        rdv = {"init_method": os.environ["LEXLS_BENCH_RDV"], "rank": rank, "world_size": world} if os.environ.get("LEXLS_BENCH_RDV") else {}
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=2), **rdv)
         dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))  # ranks finish at different times: the reported time is the slowest rank's

@@ -156,15 +156,17 @@ namespace lexls
                                const char **variant, int tolerance)
     {
         const uint32_t nc = a.nVar + 1;
-        // tolerance: 0 bit-exact kernels only; 1 automatic (the matrix-core kernel where it serves, else lqr_qtol); 6 lqr_qtol; 7 / 8 lqr_mfma with
-        // two / one problem per wavefront
-        if (tolerance == 9 && mfma_choice(a, write_factor, has_fixed, false) == 1)
+        // tolerance: 0 bit-exact kernels only; 1 automatic (lqr_qtol where it serves — the faster of the two on MI355X: 41 us against 57 us per
+        // 4096 IK problems — else the matrix-core kernel); 6 lqr_qtol only; 7 / 8 / 9 lqr_mfma with two / one / four problems per wavefront
+        // (9: the IK shape only), else lqr_qtol
+        auto try_mfma = [&](bool one_per_wave) -> int { return mfma_choice(a, write_factor, has_fixed, one_per_wave); };
+        if (tolerance == 9 && try_mfma(false) == 1)
         {
             *variant = "lqr_mfma<16,12,n40>";
             return launch_mfma_16x12n40(a, s);
         }
-        if (tolerance == 1 || tolerance == 7 || tolerance == 8)
-            switch (mfma_choice(a, write_factor, has_fixed, tolerance == 8))
+        if (tolerance == 7 || tolerance == 8)
+            switch (try_mfma(tolerance == 8))
             {
             case 1: *variant = "lqr_mfma<32,12,n40>"; return launch_mfma_32x12n40(a, s);
             case 2: *variant = "lqr_mfma<32,12>"; return launch_mfma_32x12(a, s);
@@ -177,6 +179,13 @@ namespace lexls
             case 1: *variant = "lqr_qtol<3,12,shift 7>"; return launch_qtol_3x12s7(a, s);
             case 2: *variant = "lqr_qtol<3,12>"; return launch_qtol_3x12(a, s);
             case 3: *variant = "lqr_qtol<2,12>"; return launch_qtol_2x12(a, s);
+            default: break;
+            }
+        if (tolerance == 1) // shapes lqr_qtol's four slices per wavefront do not hold
+            switch (try_mfma(false))
+            {
+            case 1: *variant = "lqr_mfma<32,12,n40>"; return launch_mfma_32x12n40(a, s);
+            case 2: *variant = "lqr_mfma<32,12>"; return launch_mfma_32x12(a, s);
             default: break;
             }
         if (a.reg_type != 0) // the regularization family: the register-resident kernel's REG instantiations (factor always kept)

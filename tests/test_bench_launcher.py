@@ -34,3 +34,14 @@ def test_self_launch_three_ranks_lsi_flag_travels():
 def test_single_rank_needs_no_launcher():
     line = run_dry(1)
     assert line["n_gpus"] == 1 and line["rank_id_sum"] == 0.0
+
+
+def test_a_rank_that_dies_takes_the_launcher_down():
+    """a rank that fails before the rendezvous must not leave the others waiting for their timeout: the launcher stops them and reports
+    the failing rank's code and stderr"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["LEXLS_BENCH_FAIL_RANK"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--dist-backend", "gloo", "--steps", "3"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 7
+    assert "rank 1 exited with code 7" in out.stderr

@@ -13,6 +13,7 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 DAT = os.path.join(GOLDEN, "test_01.dat")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("use_as,use_x", [(0, 0), (1, 0), (1, 1)])
@@ -628,3 +629,25 @@ def test_lock_step_batch_with_42_to_48_columns(hip, oracle):
             np.testing.assert_array_equal(r["x"][b], o["x"])
             np.testing.assert_array_equal(r["active"][b], np.concatenate(o["active"]))
             np.testing.assert_array_equal(r["v"][b], np.concatenate(o["v"]))
+
+
+def test_two_ranks_real_kernels_on_one_gpu():
+    """The most multi-GPU evidence a 1-GPU box can give: bench.py --gpus 2 started plainly spawns its two ranks
+    itself (fresh child processes, before anything touches the GPU), both ranks put their shard on device 0 and run the REAL kernels side by
+    side; gloo carries the barriers, the max-over-ranks time, the checksums and the scatter / gather of problem blocks and solutions (the
+    NCCL branch needs two devices)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8192
+    assert line["scatter_gather_ok"], line.get("scatter_gather")
+    assert len(line["shard_checksums"]) == 2 and all(np.isfinite(c) and c > 0 for c in line["shard_checksums"])
+    assert line["shard_checksums"][0] != line["shard_checksums"][1]  # two different shards (problem ids 0..4095 and 4096..8191)
+    assert line["value"] > 0

@@ -738,9 +738,10 @@ def test_regularization_variable_factor_and_least_norm_3(hip, oracle):
 
 
 def test_full_size_batch_4096(hip, oracle):
-    """BASELINE.json configs[2]: batch 4096 x (n=40, 5x12) against the oracle on all problems."""
+    """BASELINE.json configs[2]: batch 4096 x (n=40, 5x12) against the oracle on all problems — the batch bench.py times
+    (problem id -> seed 20260100 + id)."""
     n, dims, batch = 40, [12] * 5, 4096
-    lod = P.lse_batch_fast(20260100, batch, n, dims)
+    lod = P.lse_batch(20260100, batch, n, dims)
     ref = oracle.lse_run(lod, dims, n, nthreads=8)
     s = hip.BatchedLexLSE(batch, n, dims)
     s.set_kernel_policy(4)  # the bit-exact four-per-wavefront kernel (automatic dispatch: the tolerance-contract one, tests/test_gpu_qtol.py)

@@ -45,14 +45,49 @@ def test_ik_batches_and_wavefront_tails(hip, oracle, batch):
 
 
 def test_full_size_batch_4096_tolerance_contract(hip, oracle):
-    """BASELINE.json configs[2] on the kernel bench.py times: every one of the 4096 problems against the oracle"""
-    s, ref = check(hip, oracle, P.lse_batch_fast(20260100, 4096, N, DIMS))
+    """BASELINE.json configs[2] on the kernel bench.py times, on the batch it times (problem id -> seed 20260100 + id):
+    every one of the 4096 problems against the oracle"""
+    lod = P.lse_batch(20260100, 4096, N, DIMS)
+    s, ref = check(hip, oracle, lod)
     assert (ref["rank"] == [12, 12, 12, 4, 0]).all()
     # and against the bit-exact kernel of the same mapping: same pivots, x within the tolerance
-    e = solve(hip, P.lse_batch_fast(20260100, 4096, N, DIMS), policy=4)
+    e = solve(hip, lod, policy=4)
     assert e.last_kernel() == "lqr_quad<3,12,shift 7>"
     np.testing.assert_array_equal(e.get_column_permutations(), s.get_column_permutations())
     assert np.abs(e.get_x() - s.get_x()).max() <= TOL * max(1.0, float(np.abs(e.get_x()).max()))
+
+
+@pytest.mark.parametrize("policy,expect", [(0, "lqr_qtol<3,12,shift 7>"), (7, "lqr_mfma<32,12,n40>")])
+def test_config3_as_eight_shards_on_one_gpu(hip, oracle, policy, expect):
+    """BASELINE.json configs[3]: the 32768-problem batch (problem id -> seed 20260100 + id) as the eight 4096-problem shards that
+    `bench.py --gpus 8` gives its ranks, one after the other on the one GPU of this box: every shard against the oracle"""
+    s = hip.BatchedLexLSE(4096, N, DIMS)
+    s.set_kernel_policy(policy)
+    for shard in range(8):
+        lod = P.lse_batch(20260100 + 4096 * shard, 4096, N, DIMS)
+        ref = oracle.lse_run(lod, DIMS, N, nthreads=8)
+        s.setProblem(lod)
+        s.factorize_solve(keep_factor=False)
+        assert s.last_kernel() == expect
+        np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"])
+        r, fc, tr = s.getRanks()
+        np.testing.assert_array_equal(r, ref["rank"])
+        np.testing.assert_array_equal(fc, ref["fcol"])
+        assert np.abs(s.get_x() - ref["x"]).max() <= TOL * max(1.0, float(np.abs(ref["x"]).max()))
+
+
+@pytest.mark.parametrize("gap", [1e-3, 1e-6, 1e-9, 1e-11])
+def test_near_tied_norms_outside_the_packed_key_window(hip, oracle, gap):
+    """pairs of columns whose norms differ by a relative `gap` (a duplicate scaled by 1 + gap, BEHIND the original: position order would pick
+    the smaller one).  lqr_qtol replaces the low 12 mantissa bits of a norm by a position key for its one-butterfly decision: norms that agree in
+    their upper 40 mantissa bits (relative difference below 2^-40 = 9.1e-13) are ordered by position — contract (T) of include/lexls_hip.h
+    states that window.  Outside it the larger norm must win, as in the oracle.  (lqr_mfma compares whole doubles: tests/test_gpu_mfma.py
+    goes down to 1e-12.)"""
+    lod = P.lse_batch(4300, 24, N, DIMS)
+    for b in range(lod.shape[0]):
+        src, dst = (3 + b) % 20, 20 + (b % 19)
+        lod[b, dst, :] = lod[b, src, :] * (1.0 + gap)
+    check(hip, oracle, lod)
 
 
 @pytest.mark.parametrize("n,nobj,expect", [(2, 1, "lqr_qtol<2,12>"), (7, 2, "lqr_qtol<2,12>"), (12, 1, "lqr_qtol<2,12>"), (24, 3, "lqr_qtol<2,12>"),
