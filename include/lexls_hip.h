@@ -190,6 +190,12 @@ const char *lexls_lse_last_kernel(lexls_lse_t h);
  *                  (tiny pivots above the rank tolerance, rows / columns scaled over many decades), whose x moves by more than ~1e-11 when
  *                  its DATA move by one ulp, is solved to a small multiple of that sensitivity instead (scripts/soak_qtol.py: 21 k
  *                  random batches, 92 such problems beyond 1e-10, at most 20 x their one-ulp sensitivity; pivots and ranks exact in all).
+ *                  PIVOT RULE under (T).  The reference takes the first maximum of the down-dated column norms (lexlse.h:205-206).  lqr_mfma compares
+ *                  the norms by VALUE (whole doubles; equal values: the smallest position) — the reference's rule on this kernel's own norms.
+ *                  lqr_qtol compares them in ONE max butterfly on a packed key whose low 12 mantissa bits carry the position: two candidates whose
+ *                  norms agree in their upper 40 mantissa bits (relative difference below 2^-40 = 9.1e-13) are ordered BY POSITION, whatever their
+ *                  last 12 bits say.  Exact ties (duplicated columns) are ordered as the reference orders them by either kernel; norms that differ by
+ *                  1e-11 relative or more are ordered by value by both (tests/test_gpu_qtol.py, tests/test_gpu_mfma.py: near-tie cases).
  *   policy 0 = automatic dispatch.  (T) for x-only solves whose levels ALL have 12 rows, no fixed variables, no regularization, n <= 40 (the IK shape of
  *              BASELINE configs[2]/[3] and its smaller relatives):
  *              lqr_qtol, the bench kernel — and for problems beyond one CU's LDS (the step-per-pivot path with the trailing update on the matrix
@@ -204,7 +210,15 @@ const char *lexls_lse_last_kernel(lexls_lse_t h);
  *   4 = the bit-exact four-problems-per-wavefront kernel whenever the shape allows it (x-only solves; else as 3) (B);
  *   5 = automatic with (B) everywhere: small shapes as under LEXLS_QTOL=0, large problems on the bit-exact multi-launch path (ordered chains, two
  *       launches per pivot) — the policy for factor / sign parity;
- *   6 = the tolerance-contract kernel lqr_qtol wherever it serves (T), else as 0. */
+ *   6 = the tolerance-contract kernel lqr_qtol wherever it serves (T), else as 0;
+ *   7 = the matrix-core tolerance-contract kernel lqr_mfma (lexls_amd/csrc/lqr_mfma_impl.h: two problems per wavefront, two wavefronts per SIMD, the
+ *       Gauss step of lexlse.h:431-471 on v_mfma_f64_16x16x4_f64, finished levels kept in reduced form) wherever it serves (T) — x-only solves
+ *       whose levels all have 12 rows, n + 1 <= 48, no fixed variables / regularization, two workgroups' LDS slices per CU (n = 40: up to 5 levels) —
+ *       else as 6;  8 = the same kernel with one problem per wavefront (four wavefronts per SIMD);  9 = with four problems per wavefront (the IK
+ *       shape only).  Automatic dispatch (0) takes lqr_qtol first — the faster one on MI355X (41 us against 57 us per 4096 IK problems) — and
+ *       lqr_mfma for the shapes lqr_qtol's slices do not hold.
+ *   Policy 0 is therefore NOT bit-exact for those x-only solves; a caller that needs (B) everywhere sets policy 5 (per handle) or runs under
+ *   LEXLS_QTOL=0 (whole process; read at every factorization, so it may be changed between solves). */
 int lexls_lse_set_kernel_policy(lexls_lse_t h, int policy);
 
 /* ---- prefix reuse ------------------------------------------------------------------------------

@@ -316,6 +316,53 @@ namespace lexls
         // -----------------------------------------------------------------------------------------
         // factorize (+ solve)
         // -----------------------------------------------------------------------------------------
+        /// x = P x (lexlse.h:1044): the transpositions k <-> perm[k], last first, on x by position — read the other way round: variable i follows
+        /// them first to last from position i to its final position p, and x_i is what sits there.  Every thread for its own variables, on indices
+        /// only (one thread swapping entries behind a load of perm[k] each was 128 of the 150 us of configs[1]'s solve).  perm_l: LDS scratch of T
+        /// words, 16-BYTE ALIGNED (it is read four words at a time), that nothing else uses while this runs; xs: x by position (LDS)
+        template <int NT>
+        __device__ __forceinline__ void apply_permutation_by_following(const LseArgs &a, uint32_t b, const uint32_t *perm, uint32_t T, const double *xs, uint32_t *perm_l, uint32_t tid)
+        {
+            const uint32_t n = a.nVar;
+            for (uint32_t k = tid; k < T; k += NT) perm_l[k] = perm[k];
+            __syncthreads();
+            // (UV variables per thread and pass: independent index chains side by side)
+            auto follow = [&](auto uv_c, uint32_t i0) __attribute__((always_inline)) {
+                constexpr int UV = decltype(uv_c)::value;
+                uint32_t p[UV];
+#pragma unroll
+                for (int u = 0; u < UV; u++) p[u] = i0 + u * NT;
+                for (uint32_t k = 0; k + 4 <= T; k += 4)
+                {
+                    const uint4 pk4      = *reinterpret_cast<const uint4 *>(perm_l + k);
+                    const uint32_t pk[4] = {pk4.x, pk4.y, pk4.z, pk4.w};
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                        for (int u = 0; u < UV; u++) p[u] = (p[u] == k + kk) ? pk[kk] : ((p[u] == pk[kk]) ? k + kk : p[u]);
+                }
+                for (uint32_t k = T & ~3u; k < T; k++)
+                {
+                    const uint32_t pk = perm_l[k];
+#pragma unroll
+                    for (int u = 0; u < UV; u++) p[u] = (p[u] == k) ? pk : ((p[u] == pk) ? k : p[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < UV; u++)
+                    if (i0 + u * NT < n) a.x[(size_t)b * n + i0 + u * NT] = xs[p[u]];
+            };
+            const uint32_t rows = (n + NT - 1) / NT; // variables per thread (the last pass may reach beyond n: those are not stored)
+            uint32_t done       = 0;
+            for (; rows - done >= 4; done += 4) follow(std::integral_constant<int, 4>{}, tid + done * NT);
+            switch (rows - done)
+            {
+            case 3: follow(std::integral_constant<int, 3>{}, tid + done * NT); break;
+            case 2: follow(std::integral_constant<int, 2>{}, tid + done * NT); break;
+            case 1: follow(std::integral_constant<int, 1>{}, tid + done * NT); break;
+            default: break;
+            }
+        }
+
         template <int NT, bool LDSMAT>
         __global__ __launch_bounds__(NT) void lqr_generic_kernel(LseArgs a, int write_factor, int do_solve)
         {
@@ -973,50 +1020,8 @@ namespace lexls
                 }
                 acc += rank;
             }
-            // x = P x (lexlse.h:1044): the transpositions k <-> perm[k], last first, on x by position — read the other way round: variable i
-            // follows them first to last from position i to its final position p, and x_i is what sits there.  Every thread for its own
-            // variables, on indices only (one thread swapping entries behind a load of perm[k] each was 128 of the 150 us of configs[1]'s solve)
-            {
-                const uint32_t T  = a.totalrank[b];
-                uint32_t *perm_l  = reinterpret_cast<uint32_t *>(xs + ((n + 1u) & ~1u)); // (the diagonal's place: free now; 16-byte aligned)
-                for (uint32_t k = tid; k < T; k += NT) perm_l[k] = perm[k];
-                __syncthreads();
-                // (UV variables per thread and pass: independent index chains side by side)
-                auto follow = [&](auto uv_c, uint32_t i0) __attribute__((always_inline)) {
-                    constexpr int UV = decltype(uv_c)::value;
-                    uint32_t p[UV];
-#pragma unroll
-                    for (int u = 0; u < UV; u++) p[u] = i0 + u * NT;
-                    for (uint32_t k = 0; k + 4 <= T; k += 4)
-                    {
-                        const uint4 pk4      = *reinterpret_cast<const uint4 *>(perm_l + k);
-                        const uint32_t pk[4] = {pk4.x, pk4.y, pk4.z, pk4.w};
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++)
-#pragma unroll
-                            for (int u = 0; u < UV; u++) p[u] = (p[u] == k + kk) ? pk[kk] : ((p[u] == pk[kk]) ? k + kk : p[u]);
-                    }
-                    for (uint32_t k = T & ~3u; k < T; k++)
-                    {
-                        const uint32_t pk = perm_l[k];
-#pragma unroll
-                        for (int u = 0; u < UV; u++) p[u] = (p[u] == k) ? pk : ((p[u] == pk) ? k : p[u]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < UV; u++)
-                        if (i0 + u * NT < n) a.x[(size_t)b * n + i0 + u * NT] = xs[p[u]];
-                };
-                const uint32_t rows = (n + NT - 1) / NT; // variables per thread (the last pass may reach beyond n: those are not stored)
-                uint32_t done       = 0;
-                for (; rows - done >= 4; done += 4) follow(std::integral_constant<int, 4>{}, tid + done * NT);
-                switch (rows - done)
-                {
-                case 3: follow(std::integral_constant<int, 3>{}, tid + done * NT); break;
-                case 2: follow(std::integral_constant<int, 2>{}, tid + done * NT); break;
-                case 1: follow(std::integral_constant<int, 1>{}, tid + done * NT); break;
-                default: break;
-                }
-            }
+            // x = P x (lexlse.h:1044); scratch: the diagonal's place (free now), 16-byte aligned: xs = smem, an even number of doubles further on
+            apply_permutation_by_following<NT>(a, b, perm, a.totalrank[b], xs, reinterpret_cast<uint32_t *>(xs + ((n + 1u) & ~1u)), tid);
             SSTAMP(4)
 #ifdef LEXLS_SOLVE_STAMPS
             if (tid == 0)
@@ -1745,49 +1750,9 @@ namespace lexls
             __syncthreads();
             for (uint32_t i = tid; i < nVarRank; i += NT) xs[nf + i] = out[i];
             __syncthreads();
-            // x = P x (lexlse.h:1044): the transpositions k <-> perm[k], last first, on x by position — read the other way round: variable i
-            // follows them first to last from position i to its final position p, and x_i is what sits there.  Every thread for its own
-            // variables, on indices only (one thread swapping entries behind a load of perm[k] each was 128 of the 150 us of configs[1]'s solve)
-            {
-                const uint32_t T  = a.totalrank[b];
-                uint32_t *perm_l  = reinterpret_cast<uint32_t *>(xs + ((n + 1u) & ~1u)); // (the diagonal's place: free now; 16-byte aligned)
-                for (uint32_t k = tid; k < T; k += NT) perm_l[k] = perm[k];
-                __syncthreads();
-                // (UV variables per thread and pass: independent index chains side by side)
-                auto follow = [&](auto uv_c, uint32_t i0) __attribute__((always_inline)) {
-                    constexpr int UV = decltype(uv_c)::value;
-                    uint32_t p[UV];
-#pragma unroll
-                    for (int u = 0; u < UV; u++) p[u] = i0 + u * NT;
-                    for (uint32_t k = 0; k + 4 <= T; k += 4)
-                    {
-                        const uint4 pk4      = *reinterpret_cast<const uint4 *>(perm_l + k);
-                        const uint32_t pk[4] = {pk4.x, pk4.y, pk4.z, pk4.w};
-#pragma unroll
-                        for (int kk = 0; kk < 4; kk++)
-#pragma unroll
-                            for (int u = 0; u < UV; u++) p[u] = (p[u] == k + kk) ? pk[kk] : ((p[u] == pk[kk]) ? k + kk : p[u]);
-                    }
-                    for (uint32_t k = T & ~3u; k < T; k++)
-                    {
-                        const uint32_t pk = perm_l[k];
-#pragma unroll
-                        for (int u = 0; u < UV; u++) p[u] = (p[u] == k) ? pk : ((p[u] == pk) ? k : p[u]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < UV; u++)
-                        if (i0 + u * NT < n) a.x[(size_t)b * n + i0 + u * NT] = xs[p[u]];
-                };
-                uint32_t i0 = tid;
-                for (; i0 + 3 * NT < n + NT - 1 - ((n + NT - 1) % NT) + 0 && (n + NT - 1) / NT - (i0 - tid) / NT >= 4; i0 += 4 * NT) follow(std::integral_constant<int, 4>{}, i0);
-                switch (((n + NT - 1) / NT - (i0 - tid) / NT) & 3u)
-                {
-                case 3: follow(std::integral_constant<int, 3>{}, i0); break;
-                case 2: follow(std::integral_constant<int, 2>{}, i0); break;
-                case 1: follow(std::integral_constant<int, 1>{}, i0); break;
-                default: break;
-                }
-            }
+            // x = P x (lexlse.h:1044).  Scratch: xs = smem + n here, so the 16-byte alignment is counted from smem — behind x (n doubles from
+            // xs) rounded up to an even number of doubles FROM SMEM; it overlays `out`, which has been copied into xs above
+            apply_permutation_by_following<NT>(a, b, perm, a.totalrank[b], xs, reinterpret_cast<uint32_t *>(smem + ((2u * n + 1u) & ~1u)), tid);
         }
     } // namespace
 

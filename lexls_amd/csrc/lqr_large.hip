@@ -890,7 +890,8 @@ namespace lexls
         {
             uint32_t arrive; // monotonic over the pivots of the level
             uint32_t abort;
-            uint32_t pad[14];
+            uint32_t done;   // workgroups that have finished every pivot of the level without giving up: the commit waits for all G
+            uint32_t pad[13];
         };
         struct PersistCand
         {
@@ -1516,8 +1517,32 @@ namespace lexls
 #endif
             // ---- back to memory: the tile, the position map, the state — unless some workgroup gave up (then nobody commits: a workgroup that
             //      timed out did so long before any other could finish the level, every later hand-off needs its record) ----
+            // TWO-PHASE: the tile is committed IN PLACE, so "nobody commits if anyone gave up" must not rest on timing — a
+            // workgroup could run out of spins on the LAST pivot's hand-off after others had sampled `abort` and written their tiles, and the
+            // fall-back would start from a partly transformed level.  Every workgroup that got through the level arrives at `done`; a tile is
+            // written only once all G have arrived (nobody is left who could still give up) and `abort` is still clear.
             __syncthreads();
-            if (tid == 0) flag = __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0u : 1u;
+            if (tid == 0)
+            {
+                uint32_t ok = 0u;
+                if (!__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                {
+                    __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (uint32_t spin = 0; spin < (1u << 20); spin++)
+                    {
+                        if (__hip_atomic_load(&ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G)
+                        {
+                            ok = 1u;
+                            break;
+                        }
+                        if ((spin & 63u) == 63u && __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!ok) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the others' spins end; a late arriver finds it)
+                    else if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0u;
+                }
+                flag = ok;
+            }
             __syncthreads();
             if (!flag) return;
             flush_pending();

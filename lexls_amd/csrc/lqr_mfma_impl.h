@@ -421,9 +421,19 @@ namespace lexls
                                 }
                             }
                         }
-                        // this row block's entries at e's pivot positions -> scratch [pivot q][16 rows] (waits for the previous level's products)
+                        // Problem by problem: entries at e's pivot positions -> scratch [pivot q][16 rows] -> A operands (lane (row c16, k = gg)) -> its
+                        // matrix instructions.  The scratch round trip of one problem runs behind the matrix instructions of the other, here and
+                        // across the levels e: the matrix pipe is the only thing that stays in line
+                        auto run_tiles = [&](auto pp, auto t0c, const double (&Ao)[NV4]) __attribute__((always_inline)) {
+                            constexpr int p = decltype(pp)::value, T0 = decltype(t0c)::value;
 #pragma unroll
-                        for (int p = 0; p < G; p++)
+                            for (int ks = 0; ks < NV4; ks++)
+#pragma unroll
+                                for (int t = T0; t < NT; t++) C[p][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ao[ks], Bop[p][ks][t], C[p][t], 0, 0, 0);
+                        };
+                        MF_GSTAMP(5)
+                        for_each_index<0, G>([&](auto pp) __attribute__((always_inline)) {
+                            constexpr int p = decltype(pp)::value;
 #pragma unroll
                             for (int t = 0; t < NT; t++)
                             {
@@ -434,34 +444,25 @@ namespace lexls
                                     for (int v = 0; v < NV4; v++) D(sp[p] + o_pf + q * 128 + 8 * (gg + 4 * v)) = C[p][t][v];
                                 }
                             }
-                        mf_lds_fence(); // (lanes read what OTHER lanes stored: without the fence the compiler may move a lane's load above the store)
-                        MF_GSTAMP(2)
-                        // A operand = multipliers, lane (row c16, k = gg)
-                        double Aop[G][NV4];
-#pragma unroll
-                        for (int p = 0; p < G; p++)
+                            mf_lds_fence(); // (lanes read what OTHER lanes stored: without the fence the compiler may move a lane's load above the store)
+                            double Ao[NV4];
 #pragma unroll
                             for (int ks = 0; ks < NV4; ks++)
                             {
                                 const int q = 4 * ks + gg;
-                                Aop[p][ks]  = D((q < re[p] && c16 < MD) ? sp[p] + o_pf + q * 128 + 8 * c16 : sp[p] + o_mx);
+                                Ao[ks]      = D((q < re[p] && c16 < MD) ? sp[p] + o_pf + q * 128 + 8 * c16 : sp[p] + o_mx);
                             }
-                        // tiles in front of every problem's pivots of this level are not touched (wave-uniform choice of the first tile)
-                        auto run_tiles = [&](auto t0c) __attribute__((always_inline)) {
-                            constexpr int T0 = decltype(t0c)::value;
-#pragma unroll
-                            for (int ks = 0; ks < NV4; ks++)
-#pragma unroll
-                                for (int t = T0; t < NT; t++)
-#pragma unroll
-                                    for (int p = 0; p < G; p++) C[p][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[p][ks], Bop[p][ks][t], C[p][t], 0, 0, 0);
-                        };
-                        if (tmin == 0)
-                            run_tiles(std::integral_constant<int, 0>{});
-                        else if (tmin == 1)
-                            run_tiles(std::integral_constant<int, 1>{});
-                        else
-                            run_tiles(std::integral_constant<int, 2>{});
+                            MF_GSTAMP(6)
+                            // tiles in front of every problem's pivots of this level are not touched (wave-uniform choice of the first tile)
+                            if (tmin == 0)
+                                run_tiles(pp, std::integral_constant<int, 0>{}, Ao);
+                            else if (tmin == 1)
+                                run_tiles(pp, std::integral_constant<int, 1>{}, Ao);
+                            else
+                                run_tiles(pp, std::integral_constant<int, 2>{}, Ao);
+                            MF_GSTAMP(7)
+                        });
+                        MF_GSTAMP(2)
                         MF_GSTAMP(3)
                     });
                     // the eliminated rows, by position: [position][MD]
@@ -625,6 +626,14 @@ namespace lexls
                                 }
                             mf_lds_fence(); // (lanes read what another lane stored: without the fence the compiler may move a lane's load above the store)
                             double w[MD];
+#ifdef LEXLS_MFMA_DPP_BCAST
+                            // one 8-byte read per lane (lane l of every 16-lane row reads entry l), then row broadcasts: an eighth of the LDS traffic of
+                            // the all-lanes-read-everything form, twelve more vector instructions
+                            {
+                                const double wl_ = D(my + o_bc + 8 * ((lane & 15) < MD ? (lane & 15) : 0));
+                                for_each_index<0, MD>([&](auto rr) __attribute__((always_inline)) { w[decltype(rr)::value] = gbc<decltype(rr)::value>(wl_); });
+                            }
+#else
 #pragma unroll
                             for (int r = 0; r < MD; r += 2)
                             {
@@ -632,6 +641,7 @@ namespace lexls
                                 w[r]          = v.x;
                                 w[r + 1]      = v.y;
                             }
+#endif
                             const int ppos = (int)U32(my + o_bc + CB);
                             mf_lds_fence();
                             const double c0 = w[j];

@@ -18,4 +18,4 @@ print("per level:     Gauss   level start  Householder  level end")
 for k in range(5): print(f"  level {k}: " + "  ".join(f"{v:9.0f}" for v in lv[k]))
 print("levels total (first stamp -> after last level)", np.median(ws[::step, 8]), " solve", np.median(ws[::step, 9]))
 g = np.median(ws[::step, 32:40], axis=0)
-print("Gauss phase (sum over levels): wait for the level", g[0], " C tiles in", g[1], " multipliers to scratch", g[2], " operand reads + mfma", g[3], " C out", g[4])
+print("Gauss phase (sum over levels): wait for the level", g[0], " C tiles in", g[1], " [2]", g[2], " [3]", g[3], " C out", g[4], " B reads issued+landed [5]", g[5], " extraction + A reads landed [6]", g[6], " mfma issue [7]", g[7])

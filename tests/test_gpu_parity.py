@@ -737,6 +737,21 @@ def test_regularization_variable_factor_and_least_norm_3(hip, oracle):
         s.get_mu()  # X_mu / residual_mu exist with REGULARIZATION_TIKHONOV_1 only
 
 
+@pytest.mark.parametrize("n,dims", [(5, [2, 2]), (9, [3, 2, 3]), (23, [6, 5, 4]), (41, [7] * 4), (63, [9] * 5)])
+def test_least_norm_3_with_an_odd_number_of_variables(hip, oracle, n, dims):
+    """solveLeastNorm_3 ends in x = P x on an LDS scratch that must be 16-byte aligned whatever the parity of n (the copy of the
+    solve kernel's permutation block computed the scratch from a base that is n doubles into the LDS block — misaligned for odd n)"""
+    batch = 5
+    lod = P.lse_batch(700 + n, batch, n, dims)
+    ref3 = oracle.lse_run(lod, dims, n, solve_option=3, reg_type=1, reg_factors=[0.0] * len(dims))
+    s = hip.BatchedLexLSE(batch, n, dims)
+    s.setRegularization(1, [0.0] * len(dims))
+    s.setProblem(lod)
+    s.factorize()
+    s.solveLeastNorm_3()
+    np.testing.assert_array_equal(s.get_x(), ref3["x"])
+
+
 def test_full_size_batch_4096(hip, oracle):
     """BASELINE.json configs[2]: batch 4096 x (n=40, 5x12) against the oracle on all problems — the batch bench.py times
     (problem id -> seed 20260100 + id)."""
