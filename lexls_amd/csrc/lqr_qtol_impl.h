@@ -552,9 +552,11 @@ namespace lexls
                             double r       = dfma(-h, g, 0.5);
                             g              = dfma(g, r, g);
                             h              = dfma(h, r, h);
+#ifndef LEXLS_QTOL_ONE_NEWTON
                             r              = dfma(-h, g, 0.5);
                             g              = dfma(g, r, g);
                             h              = dfma(h, r, h);
+#endif
                         }
                         const bool neg    = c0 >= 0.0;       // beta = -sign(c0) sqrt(fresh)
                         const double beta = neg ? -g : g;

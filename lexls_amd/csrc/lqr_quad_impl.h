@@ -684,7 +684,10 @@ namespace lexls
             if constexpr (WF)
             {
                 // ---- the factor's free columns: T entries from the images, parked rows to their final positions ----
-                __builtin_amdgcn_s_waitcnt(0); // every factor store of this wavefront has been issued before the parked rows are read back
+                // (rows are parked by rank-deficient levels only: a wavefront without any neither waits for its factor stores to land before this pass
+                // nor between the pass's reads and stores — five drains of the store queue, 45 k of the 270 k cycles of the IK batch)
+                const bool any_parked = __ballot(parked_levels != 0) != 0ull;
+                if (any_parked) __builtin_amdgcn_s_waitcnt(0); // every factor store of this wavefront has landed before the parked rows are read back
                 int Fk = 0;
                 for (int k = 0; k < nObj; k++)
                 {
@@ -715,7 +718,7 @@ namespace lexls
                                 keep[s][p] = v;
                             }
                         }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // all parked rows are in registers before any of them is overwritten
+                        if (any_parked) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // all parked rows are in registers before any of them is overwritten
 #pragma unroll
                         for (int s = 0; s < NS; s++)
                         {
