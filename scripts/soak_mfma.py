@@ -1,0 +1,69 @@
+"""Soak (not part of the suite): the matrix-core tolerance-contract kernel lqr_mfma (policy 7 / 8) on random shapes — n = 2 .. 47, 1 .. 8 levels of 12 rows, any batch size,
+full-rank and rank-deficient (exact dependence, duplicated columns) — pivots / ranks / first columns exact, x within 1e-10 (contract T).
+usage: python scripts/soak_mfma.py [seconds] [policy]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import lexls_amd as hip
+from lexls_amd import problems as P
+from oracle import oracle_ctypes as oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+POLICY = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+rng = np.random.default_rng(20261007)
+t0, cases, kernels, worst, ill, ratio = time.time(), 0, {}, 0.0, 0, 0.0
+while time.time() - t0 < budget:
+    n = int(rng.integers(2, 48))
+    nobj = int(rng.integers(1, 9))
+    dims = [12] * nobj
+    B = int(rng.choice([1, 2, 3, 5, 17, 64, 200]))
+    kind = int(rng.integers(0, 4))
+    seed = int(rng.integers(0, 1 << 30))
+    if kind == 0:
+        lod = P.lse_batch_fast(seed, B, n, dims)
+    elif kind == 1:
+        ranks = [int(rng.integers(0, 13)) for _ in range(nobj)]
+        lod = np.stack([P.rank_deficient_problem(seed + b, n, dims, ranks) for b in range(B)])
+    elif kind == 2:  # duplicated columns: exact ties of the norms
+        lod = P.lse_batch_fast(seed, B, n, dims)
+        if n >= 4:
+            a, b2 = rng.choice(n, size=2, replace=False)
+            lod[:, a, :] = lod[:, b2, :]
+    else:  # badly scaled rows / columns
+        lod = P.lse_batch_fast(seed, B, n, dims)
+        lod[:, :n, :] *= (10.0 ** rng.uniform(-3, 3, size=n))[None, :, None]
+        lod *= (10.0 ** rng.uniform(-2, 2, size=lod.shape[2]))[None, None, :]
+    ref = oracle.lse_run(lod, dims, n, nthreads=4)
+    s = hip.BatchedLexLSE(B, n, dims)
+    s.set_kernel_policy(POLICY)
+    s.setProblem(lod)
+    s.factorize_solve(keep_factor=False)
+    k = s.last_kernel()
+    kernels[k] = kernels.get(k, 0) + 1
+    ctx = f"case {cases}: n={n} levels={nobj} B={B} kind={kind} seed={seed} kernel={k}"
+    r, fc, tr = s.getRanks()
+    np.testing.assert_array_equal(r, ref["rank"], err_msg=ctx)
+    np.testing.assert_array_equal(fc, ref["fcol"], err_msg=ctx)
+    np.testing.assert_array_equal(s.get_column_permutations(), ref["perm"], err_msg=ctx)
+    x = s.get_x()
+    assert np.isfinite(x).all(), ctx
+    errs = np.abs(x - ref["x"]).max(axis=1) / np.maximum(1.0, np.abs(ref["x"]).max(axis=1))
+    err = float(errs.max())
+    if err > 1e-10:
+        # an ill-conditioned problem (exact dependences can leave tiny pivots above the rank tolerance): the contract's 1e-10 is meant for
+        # problems whose own solution does not move more than that when the DATA move by one ulp — measured with the oracle itself
+        sens = np.zeros(B)
+        for rep in range(3):
+            pert = lod * (1.0 + 1.1e-16 * np.sign(np.random.default_rng(1000 * cases + rep).standard_normal(lod.shape)))
+            rp = oracle.lse_run(pert, dims, n, nthreads=4)
+            sens = np.maximum(sens, np.abs(rp["x"] - ref["x"]).max(axis=1) / np.maximum(1.0, np.abs(ref["x"]).max(axis=1)))
+        # (a random one-ulp perturbation is a LOWER estimate of what rounding can do to such a problem: two decades of room)
+        bad = errs > np.maximum(1e-10, 100.0 * sens)
+        ratio = max(ratio, float((errs[errs > 1e-10] / np.maximum(sens[errs > 1e-10], 1e-300)).max()))
+        assert not bad.any(), ctx + f" err {err:.3e}, one-ulp sensitivity of the same problems {sens[errs > 1e-10].tolist()}"
+        ill += int((errs > 1e-10).sum())
+    elif k.startswith("lqr_mfma"):
+        worst = max(worst, err)
+    s.close(); cases += 1
+print(f"soak ok: {cases} cases in {time.time() - t0:.0f} s; largest relative error of x on lqr_mfma {worst:.2e} ({ill} ill-conditioned problems beyond 1e-10, the largest at {ratio:.0f} x the problem's own sensitivity to one-ulp changes of its data); kernels: " + ", ".join(f"{k} x{v}" for k, v in sorted(kernels.items())))
