@@ -719,15 +719,26 @@ namespace lexls
                             }
                         }
                         if (any_parked) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // all parked rows are in registers before any of them is overwritten
+                        // (a full-rank level of MD rows — every level of the IK batch — is written as MD / 2 sixteen-byte stores per column instead of
+                        // MD masked eight-byte ones: same values, half the store instructions and memory transactions)
+                        const bool vec = (__ballot(hhran && !(rkk == MD && dimk == MD)) == 0ull) && ((cap | Fk) & 1) == 0 && (MD % 2) == 0;
 #pragma unroll
                         for (int s = 0; s < NS; s++)
                         {
                             const int P = 16 * s + gl;
                             if (mine[s])
                             {
+                                if (vec)
+                                {
 #pragma unroll
-                                for (int p = 0; p < MD; p++)
-                                    if (p < rkk || (parked && p < dimk)) out[Fk + p + (size_t)P * cap] = keep[s][p];
+                                    for (int p = 0; p < MD; p += 2) *reinterpret_cast<double2 *>(out + Fk + p + (size_t)P * cap) = make_double2(keep[s][p], keep[s][p + 1 < MD ? p + 1 : p]);
+                                }
+                                else
+                                {
+#pragma unroll
+                                    for (int p = 0; p < MD; p++)
+                                        if (p < rkk || (parked && p < dimk)) out[Fk + p + (size_t)P * cap] = keep[s][p];
+                                }
                             }
                         }
                     }
