@@ -162,9 +162,24 @@ namespace lexls
         gst[i] += t_ - gst_t0;                           \
         gst_t0 = t_;                                     \
     }
+#define MF_CSTAMP(i, val)                                                                              \
+    if constexpr (NS == 1)                                                                             \
+    {                                                                                                  \
+        int dummy_;                                                                                    \
+        asm volatile("v_mov_b32 %1, %2\n\ts_memtime %0" : "=s"(cst[i]), "=v"(dummy_) : "v"(val));   \
+    }
+#define MF_CSTAMP_COLLECT                                                              \
+    if constexpr (NS == 1)                                                             \
+    {                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             \
+        cacc[0] += cst[1] - cst[0]; cacc[1] += cst[2] - cst[1]; cacc[2] += cst[3] - cst[2]; \
+        cacc[3] += cst[4] - cst[3]; cacc[4] += cst[5] - cst[4]; cacc[5] += 1;          \
+    }
 #else
 #define MF_LSTAMP(ph)
 #define MF_GSTAMP(i)
+#define MF_CSTAMP(i, val)
+#define MF_CSTAMP_COLLECT
 #endif
 
         /// LP lanes per problem (32: two problems per wavefront, two wavefronts per SIMD; 64: one problem, four wavefronts per SIMD);
@@ -312,6 +327,7 @@ namespace lexls
             unsigned long long lst_t0 = clock64();
             const unsigned long long lst_t00 = lst_t0;
             unsigned long long gst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gst_t0 = 0;
+            unsigned long long cacc[6] = {0, 0, 0, 0, 0, 0}, cst[6] = {0, 0, 0, 0, 0, 0};
 #endif
 
             for (int k = 0; k < nObj; k++)
@@ -585,7 +601,9 @@ namespace lexls
                             int hl = __double2hiint(nrm[0]);
 #pragma unroll
                             for (int s = 1; s < NS; s++) hl = __double2hiint(nrm[s]) > hl ? __double2hiint(nrm[s]) : hl;
+                            MF_CSTAMP(0, hl)
                             const int mh = mf_grp_maxi<LP>(hl);
+                            MF_CSTAMP(1, mh)
                             bool iswin[NS];
                             unsigned long long mk = 0ull, two = 0ull;
 #pragma unroll
@@ -643,10 +661,14 @@ namespace lexls
                             }
 #endif
                             const int ppos = (int)U32(my + o_bc + CB);
+                            MF_CSTAMP(2, ppos)
                             mf_lds_fence();
                             const double c0 = w[j];
-                            // tail norm in three partial sums, fresh norm = c0^2 + tail (lexlse.h:210-211, :241)
-                            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+                            // The chain to the next decision first: the raw dot products w . a_s (they need nothing but the column) beside the tail norm,
+                            // then fresh norm -> 1/sqrt -> R_js -> down-dated norms; what only the rows' update needs (1 / (c0 - beta), the rank-one
+                            // update, the Jordan step) comes behind a scheduling barrier, in the shadow of the next step's butterfly and LDS round trip
+                            double dwv[NS];
+                            double t0 = 0.0, t1 = 0.0, t2 = 0.0; // tail norm in three partial sums, fresh norm = c0^2 + tail (lexlse.h:210-211, :241)
 #pragma unroll
                             for (int r = j + 1; r < MD; r++)
                             {
@@ -654,7 +676,22 @@ namespace lexls
                                 if ((r - j) % 3 == 2) t1 = dfma(w[r], w[r], t1);
                                 if ((r - j) % 3 == 0) t2 = dfma(w[r], w[r], t2);
                             }
+#pragma unroll
+                            for (int s = 0; s < NS; s++)
+                            {
+                                double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+                                for (int r = j + 1; r < MD; r++)
+                                {
+                                    if ((r - j) & 1)
+                                        d0 = dfma(w[r], blk[s][r], d0);
+                                    else
+                                        d1 = dfma(w[r], blk[s][r], d1);
+                                }
+                                dwv[s] = dfma(c0, blk[s][j], d0 + d1);
+                            }
                             const double fresh = dfma(c0, c0, (t0 + t1) + t2);
+                            MF_CSTAMP(3, __double2hiint(fresh))
                             const bool cont    = act && !(fresh < a.tol); // rank test on the squared norm (lexlse.h:214)
                             if (cont) // a level that has stopped leaves its block, norms and maps alone (its lanes sit out)
                             {
@@ -671,27 +708,24 @@ namespace lexls
                                     hq             = dfma(hq, r, hq);
                                 }
                                 const bool neg    = c0 >= 0.0; // beta = -sign(c0) sqrt(fresh)
-                                const double beta = neg ? -gq : gq;
                                 const double ibet = (neg ? -2.0 : 2.0) * hq; // 1 / beta
-                                const double rden = mf_rcp1(c0 - beta);
-                                // every column: R_js = (w . a_s) / beta, rows below a_s += gs w, row j normalised, Jordan step on the rows above
+                                double tv[NS];
 #pragma unroll
                                 for (int s = 0; s < NS; s++)
                                 {
-                                    double d0 = 0.0, d1 = 0.0;
+                                    tv[s]  = dwv[s] * ibet;               // R_js = (w . a_s) / beta
+                                    nrm[s] = dfma(-tv[s], tv[s], nrm[s]); // lexlse.h:262-266
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                const double beta = neg ? -gq : gq;
+                                const double rden = mf_rcp1(c0 - beta);
+                                // every column: rows below a_s += gs w, row j normalised, Jordan step on the rows above
 #pragma unroll
-                                    for (int r = j + 1; r < MD; r++)
-                                    {
-                                        if ((r - j) & 1)
-                                            d0 = dfma(w[r], blk[s][r], d0);
-                                        else
-                                            d1 = dfma(w[r], blk[s][r], d1);
-                                    }
-                                    const double dw = dfma(c0, blk[s][j], d0 + d1);
-                                    const double t  = dw * ibet;              // R_js
+                                for (int s = 0; s < NS; s++)
+                                {
+                                    const double t  = tv[s];
                                     const double gs = (t - blk[s][j]) * rden; // a_s[r] += gs w[r] (= a_s - tau v v.a_s, lexlse.h:243-246)
                                     const double u  = t * ibet;               // R_js / R_jj
-                                    nrm[s]          = dfma(-t, t, nrm[s]);    // lexlse.h:262-266
 #pragma unroll
                                     for (int r = j + 1; r < MD; r++) blk[s][r] = dfma(gs, w[r], blk[s][r]);
                                     blk[s][j] = u;
@@ -710,6 +744,9 @@ namespace lexls
                                 ColIndex += 1;
                                 rank += 1;
                             }
+                            MF_CSTAMP(4, __double2hiint(nrm[0]))
+                            MF_CSTAMP(5, __double2hiint(blk[0][MD - 1]))
+                            MF_CSTAMP_COLLECT
                             const bool full = cont && ColIndex == n;
                             exh             = exh || full;
                             go              = cont && !full;
@@ -842,6 +879,8 @@ namespace lexls
                 lst_t0 = t_;
                 if (gl == 0 && live)
                     for (int i_ = 0; i_ < 8; i_++) a.lambda[(size_t)b * (n + cap) + 32 + i_] = (double)gst[i_];
+                if (gl == 0 && live)
+                    for (int i_ = 0; i_ < 6; i_++) a.lambda[(size_t)b * (n + cap) + 44 + i_] = (double)cacc[i_];
             }
 #endif
             // ---- results ----

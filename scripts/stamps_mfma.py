@@ -19,3 +19,7 @@ for k in range(5): print(f"  level {k}: " + "  ".join(f"{v:9.0f}" for v in lv[k]
 print("levels total (first stamp -> after last level)", np.median(ws[::step, 8]), " solve", np.median(ws[::step, 9]))
 g = np.median(ws[::step, 32:40], axis=0)
 print("Gauss phase (sum over levels): wait for the level", g[0], " C tiles in", g[1], " [2]", g[2], " [3]", g[3], " C out", g[4], " B reads issued+landed [5]", g[5], " extraction + A reads landed [6]", g[6], " mfma issue [7]", g[7])
+c = np.median(ws[::step, 44:50], axis=0)
+if c[5] > 0:
+    print("pivot steps with one live slot (%d steps), cycles per step: norms ready -> high-word maximum %.0f | -> winner's column + position in every lane (store, LDS, read) %.0f | -> fresh norm %.0f | -> norms down-dated %.0f | -> rows below updated %.0f | sum %.0f"
+          % (c[5], c[0] / c[5], c[1] / c[5], c[2] / c[5], c[3] / c[5], c[4] / c[5], c[:5].sum() / c[5]))
