@@ -30,17 +30,53 @@ namespace lexls
             uint32_t dim;
         };
 
+// Diagnostic build only (-DLEXLS_WAVE_STAMPS): shader-clock totals of the routines' phases, accumulated by thread 0 behind the kernel's own stamps
+#ifdef LEXLS_WAVE_STAMPS
+#define REG_STAMP(v, i, t)                                \
+    if ((v).stamp && (t) == 0)                            \
+    {                                                     \
+        const double now_ = (double)clock64();            \
+        (v).stamp[i] += now_ - (v).stamp[15];             \
+        (v).stamp[15] = now_;                             \
+    }
+#else
+#define REG_STAMP(v, i, t)
+#endif
+
         struct RegView
         {
+            double *stamp = nullptr;
+            double fk     = 0.0;   // the level's factor when the caller fetched it ahead (has_fk)
+            bool has_fk   = false;
             double *W;   // the problem matrix (LDS or HBM), column-major
             size_t ld;
             uint32_t n, nf;
-            double *NS;  // n x (n+1), ld = n
+            double *NS;  // n x (n+1), leading dimension ldns (n in the handle's scratch; odd in an LDS window: rows of a column pair fall on different banks)
             double *D, *D0, *d, *out, *scal, *cg; // cg: 10 n doubles for the CGLS vectors
-            __device__ double &ns(uint32_t i, uint32_t j) const { return NS[i + (size_t)j * n]; }
+            uint32_t ldns, ldd;
+            double *Dg;   // the work matrix in the handle's scratch (ld = n): what D points at when the order exceeds the LDS window
+            double *Dl;   // LDS window ldl x ldl of the register-resident kernel (NULL: none)
+            uint32_t ldl;
+            __device__ double &ns(uint32_t i, uint32_t j) const { return NS[i + (size_t)j * ldns]; }
             __device__ double &w(uint32_t i, uint32_t j) const { return W[i + j * ld]; }
-            __device__ double &dd(uint32_t i, uint32_t j) const { return D[i + (size_t)j * n]; }
+            __device__ double &dd(uint32_t i, uint32_t j) const { return D[i + (size_t)j * ldd]; }
             __device__ double &d0(uint32_t i, uint32_t j) const { return D0[i + (size_t)j * n]; }
+            /// the work matrix of order N: the LDS window when it holds it (uniform per workgroup)
+            __device__ RegView with_order(uint32_t N) const
+            {
+                RegView r = *this;
+                if (Dl && N <= ldl)
+                {
+                    r.D   = Dl;
+                    r.ldd = ldl;
+                }
+                else
+                {
+                    r.D   = Dg;
+                    r.ldd = n;
+                }
+                return r;
+            }
         };
 
         __device__ inline RegView reg_view(const LseArgs &a, uint32_t b, double *W, size_t ld, uint32_t nf)
@@ -53,7 +89,12 @@ namespace lexls
             v.n    = n;
             v.nf   = nf;
             v.NS   = base;
+            v.ldns = n;
             v.D    = base + (size_t)n * (n + 1);
+            v.Dg   = v.D;
+            v.ldd  = n;
+            v.Dl   = nullptr;
+            v.ldl  = 0;
             v.D0   = v.D + (size_t)n * n;
             v.d    = v.D0 + (size_t)n * n;
             v.out  = v.d + n;
@@ -62,10 +103,103 @@ namespace lexls
             return v;
         }
 
+        __device__ __forceinline__ double reg_rdlane(double v, int lane)
+        {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+            return __hiloint2double(hi, lo);
+        }
+
+        /// acc + sum of x[i]^2, i = 0 .. len-1 in that order, by ONE wavefront (len <= 64): one load per lane, then the ordered fma chain on
+        /// values read across lanes — every lane ends with the same sum (what thread 0's loop over the vector gave, without its load per term)
+        __device__ __forceinline__ double reg_wave_sumsq(const double *x, uint32_t len, uint32_t lane, double acc)
+        {
+            const double xi = lane < len ? x[lane] : 0.0;
+            for (uint32_t i = 0; i < len; i++)
+            {
+                const double t = reg_rdlane(xi, (int)i);
+                acc            = rfma(t, t, acc);
+            }
+            return acc;
+        }
+
+        /// reg_cholesky_solve for ONE wavefront (the register-resident kernel), N <= 64: lane i owns row i of the lower triangle and d_i.
+        /// Panels of 16 columns at a time in registers; a finished column's entries reach the other lanes by v_readlane, the columns of
+        /// earlier panels come back from the work matrix as the lane's OWN row (no lane reads what another lane wrote until the backward
+        /// substitution) — so the 3 N dependent steps (square root / division each) cost their arithmetic, not a memory round trip plus a loop
+        /// of unknown trip count each, which is where the routine's time went.  Same operations on the same operands in the same order as
+        /// the workgroup form below (entry (i, j) receives the products k = 0 .. j-1 in that order; substitutions column by column), so the
+        /// results are the same bits.  The panel loops have run-time trip counts and a fixed body: ~70 registers, a few KB of code.
+        __device__ __noinline__ void reg_cholesky_solve_wave(const RegView &v, uint32_t N, uint32_t lane)
+        {
+            constexpr int PB = 16;
+            const bool on    = lane < N;
+            double row[PB];
+            for (uint32_t c0 = 0; c0 < N; c0 += PB)
+            {
+#pragma unroll
+                for (int jj = 0; jj < PB; jj++) row[jj] = (on && c0 + jj <= lane && c0 + jj < N) ? v.dd(lane, c0 + jj) : 0.0;
+                for (uint32_t k = 0; k < c0; k++) // the columns of the panels before: own entry from the matrix, the panel rows' entries from their lanes
+                {
+                    const double lik = (on && lane >= c0) ? v.dd(lane, k) : 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < PB; jj++) row[jj] = rfma(-lik, reg_rdlane(lik, (int)(c0 + jj) & 63), row[jj]);
+                }
+#pragma unroll
+                for (int kk = 0; kk < PB; kk++)
+                    if (c0 + kk < N) // uniform
+                    {
+                        const double lkk = sqrt(reg_rdlane(row[kk], (int)(c0 + kk)));
+                        const double lik = (lane == c0 + kk) ? lkk : row[kk] / lkk; // (zeros above the diagonal and beyond N)
+                        row[kk]          = lik;
+#pragma unroll
+                        for (int jj = kk + 1; jj < PB; jj++) row[jj] = rfma(-lik, reg_rdlane(lik, (int)(c0 + jj) & 63), row[jj]);
+                    }
+#pragma unroll
+                for (int jj = 0; jj < PB; jj++)
+                    if (on && c0 + jj <= lane && c0 + jj < N) v.dd(lane, c0 + jj) = row[jj];
+            }
+            double di = on ? v.d[lane] : 0.0;
+            for (uint32_t c0 = 0; c0 < N; c0 += PB)
+            {
+#pragma unroll
+                for (int jj = 0; jj < PB; jj++) row[jj] = (on && c0 + jj <= lane && c0 + jj < N) ? v.dd(lane, c0 + jj) : 0.0;
+#pragma unroll
+                for (int jj = 0; jj < PB; jj++)
+                    if (c0 + jj < N)
+                    {
+                        const uint32_t j = c0 + jj;
+                        const double yj  = reg_rdlane(di, (int)j) / reg_rdlane(row[jj], (int)j);
+                        di               = (lane == j) ? yj : (lane > j ? rfma(-row[jj], yj, di) : di);
+                    }
+            }
+            __syncthreads(); // the factor's columns are read across lanes from here on
+            for (uint32_t c0 = ((N - 1) / PB) * PB; N > 0; c0 -= PB)
+            {
+#pragma unroll
+                for (int jj = 0; jj < PB; jj++) row[jj] = (on && c0 + jj >= lane && c0 + jj < N) ? v.dd(c0 + jj, lane) : 0.0;
+#pragma unroll
+                for (int jj = PB - 1; jj >= 0; jj--)
+                    if (c0 + jj < N)
+                    {
+                        const uint32_t j = c0 + jj;
+                        const double zj  = reg_rdlane(di, (int)j) / reg_rdlane(row[jj], (int)j);
+                        di               = (lane == j) ? zj : (lane < j ? rfma(-row[jj], zj, di) : di);
+                    }
+                if (c0 == 0) break;
+            }
+            if (on) v.d[lane] = di;
+            __syncthreads();
+        }
+
         /// LLT of the lower triangle of D (N x N) in place, then D z = d in place (oracle: cholesky_solve)
         template <int NT>
         __device__ void reg_cholesky_solve(const RegView &v, uint32_t N, uint32_t tid)
         {
+            if constexpr (NT == 64)
+            {
+                if (N <= 64) return reg_cholesky_solve_wave(v, N, tid);
+            }
             for (uint32_t j = 0; j < N; j++)
             {
                 if (tid == 0)
@@ -177,10 +311,11 @@ namespace lexls
         }
 
         template <int NT>
-        __device__ void reg_tikhonov_1(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, double f, uint32_t tid)
+        __device__ void reg_tikhonov_1(const RegView &v0, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, double f, uint32_t tid)
         {
             const double mu   = f * f;
-            const uint32_t m0 = Fc - v.nf, N = RC + rank;
+            const uint32_t m0 = Fc - v0.nf, N = RC + rank;
+            const RegView v   = v0.with_order(N);
             reg_lower_RtR<NT>(v, F, Fc, rank, tid);
             for (uint32_t e = tid; e < RC * RC; e += NT) // Tk'*Tk (lower)
             {
@@ -235,10 +370,11 @@ namespace lexls
         }
 
         template <int NT>
-        __device__ void reg_tikhonov_2(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, double f, uint32_t tid)
+        __device__ void reg_tikhonov_2(const RegView &v0, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, double f, uint32_t tid)
         {
             const double mu   = f * f;
-            const uint32_t m0 = Fc - v.nf, N = m0 + rank, Wd = RC + rank;
+            const uint32_t m0 = Fc - v0.nf, N = m0 + rank, Wd = RC + rank;
+            const RegView v   = v0.with_order(N);
             reg_lower_RRt_TTt<NT>(v, F, Fc, rank, RC, tid);
             for (uint32_t e = tid; e < m0 * m0; e += NT) // mu * up*up' (lower)
             {
@@ -273,12 +409,15 @@ namespace lexls
         }
 
         template <int NT>
-        __device__ void reg_R(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, double f, bool with_z, uint32_t tid)
+        __device__ void reg_R(const RegView &v0, uint32_t F, uint32_t Fc, uint32_t rank, double f, bool with_z, uint32_t tid)
         {
             const double mu   = f * f;
-            const uint32_t m0 = with_z ? Fc - v.nf : 0;
+            const uint32_t m0 = with_z ? Fc - v0.nf : 0;
+            const RegView v   = v0.with_order(rank);
+            REG_STAMP(v, 0, tid)
             reg_lower_RtR<NT>(v, F, Fc, rank, tid);
             __syncthreads();
+            REG_STAMP(v, 1, tid)
             for (uint32_t e = tid; e < rank * rank; e += NT)
             {
                 const uint32_t i = e % rank, j = e / rank;
@@ -305,15 +444,19 @@ namespace lexls
                     v.d[i] = reg_Rt_rhs(v, F, Fc, i);
             }
             __syncthreads();
+            REG_STAMP(v, 2, tid)
             reg_cholesky_solve<NT>(v, rank, tid);
+            REG_STAMP(v, 3, tid)
             for (uint32_t i = tid; i < rank; i += NT) v.out[i] = reg_R_times_d(v, F, Fc, rank, i);
             reg_store_rhs<NT>(v, F, rank, v.out, tid);
+            REG_STAMP(v, 4, tid)
         }
 
         template <int NT>
-        __device__ void reg_RT_NO_Z(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, double f, uint32_t tid)
+        __device__ void reg_RT_NO_Z(const RegView &v0, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, double f, uint32_t tid)
         {
             const double mu = f * f;
+            const RegView v = v0.with_order(rank);
             reg_lower_RRt_TTt<NT>(v, F, Fc, rank, RC, tid);
             __syncthreads();
             for (uint32_t i = tid; i < rank; i += NT)
@@ -380,14 +523,21 @@ namespace lexls
             __syncthreads();
             compute_s();
             for (uint32_t i = tid; i < N; i += NT) pv[i] = sv[i];
-            if (tid == 0)
+            double gamma;
+            if constexpr (NT == 64)
+                gamma = reg_wave_sumsq(sv, N, tid, 0.0);
+            else
             {
-                double g = 0.0;
-                for (uint32_t i = 0; i < N; i++) g = rfma(sv[i], sv[i], g);
-                v.scal[1] = g;
+                if (tid == 0)
+                {
+                    double g = 0.0;
+                    for (uint32_t i = 0; i < N; i++) g = rfma(sv[i], sv[i], g);
+                    v.scal[1] = g;
+                }
+                __syncthreads();
+                gamma = v.scal[1];
             }
             __syncthreads();
-            double gamma = v.scal[1];
             uint32_t iter = 0;
             while (sqrt(gamma) > 1e-12 && iter < max_iter) // uniform: gamma is read from memory by every thread
             {
@@ -405,16 +555,22 @@ namespace lexls
                 }
                 for (uint32_t i = tid; i < N; i += NT) q3[i] = f * pv[i];
                 __syncthreads();
-                if (tid == 0)
+                double alpha;
+                if constexpr (NT == 64)
+                    alpha = gamma / reg_wave_sumsq(q3, N, tid, reg_wave_sumsq(q2, m0, tid, reg_wave_sumsq(q1, rank, tid, 0.0)));
+                else
                 {
-                    double qq = 0.0;
-                    for (uint32_t i = 0; i < rank; i++) qq = rfma(q1[i], q1[i], qq);
-                    for (uint32_t k = 0; k < m0; k++) qq = rfma(q2[k], q2[k], qq);
-                    for (uint32_t i = 0; i < N; i++) qq = rfma(q3[i], q3[i], qq);
-                    v.scal[2] = gamma / qq;
+                    if (tid == 0)
+                    {
+                        double qq = 0.0;
+                        for (uint32_t i = 0; i < rank; i++) qq = rfma(q1[i], q1[i], qq);
+                        for (uint32_t k = 0; k < m0; k++) qq = rfma(q2[k], q2[k], qq);
+                        for (uint32_t i = 0; i < N; i++) qq = rfma(q3[i], q3[i], qq);
+                        v.scal[2] = gamma / qq;
+                    }
+                    __syncthreads();
+                    alpha = v.scal[2];
                 }
-                __syncthreads();
-                const double alpha = v.scal[2];
                 for (uint32_t i = tid; i < N; i += NT)
                 {
                     x[i]  = rfma(alpha, pv[i], x[i]);
@@ -424,15 +580,20 @@ namespace lexls
                 for (uint32_t k = tid; k < m0; k += NT) r2[k] = rfma(-alpha, q2[k], r2[k]);
                 __syncthreads();
                 compute_s();
-                if (tid == 0)
-                {
-                    double g = 0.0;
-                    for (uint32_t i = 0; i < N; i++) g = rfma(sv[i], sv[i], g);
-                    v.scal[1] = g;
-                }
-                __syncthreads();
                 const double gamma_previous = gamma;
-                gamma                       = v.scal[1];
+                if constexpr (NT == 64)
+                    gamma = reg_wave_sumsq(sv, N, tid, 0.0);
+                else
+                {
+                    if (tid == 0)
+                    {
+                        double g = 0.0;
+                        for (uint32_t i = 0; i < N; i++) g = rfma(sv[i], sv[i], g);
+                        v.scal[1] = g;
+                    }
+                    __syncthreads();
+                    gamma = v.scal[1];
+                }
                 const double beta           = gamma / gamma_previous;
                 for (uint32_t i = tid; i < N; i += NT) pv[i] = rfma(beta, pv[i], sv[i]);
                 __syncthreads();
@@ -554,17 +715,18 @@ namespace lexls
 
         /// dispatch of lexlse.h:277-395 for one level; called by every thread of the workgroup (uniform arguments)
         template <int NT>
-        __device__ void regularize_level(const LseArgs &a, uint32_t b, double *W, size_t ld, uint32_t nf, uint32_t ObjIndex, uint32_t F, uint32_t Fc,
-                                         uint32_t rank, uint32_t RC, uint32_t tid, const RegLevels *lv = nullptr)
+        __device__ __noinline__ void regularize_level(const LseArgs &a, uint32_t b, const RegView &v, uint32_t ObjIndex, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC,
+                                         uint32_t tid, const RegLevels *lv = nullptr)
         {
-            const RegView v = reg_view(a, b, W, ld, nf);
-            if (tid == 0) // lexlse.h:277-311: constant or conditioning-dependent factor
+            double f;
+            if (a.reg_variable == 0.0) // lexlse.h:277-311: the constant factor — every thread reads it (no hand-off through memory)
+                f = v.has_fk ? v.fk : a.reg_factor[(size_t)b * a.nObj + ObjIndex];
+            else
             {
-                const double fk = a.reg_factor[(size_t)b * a.nObj + ObjIndex];
-                double f        = fk;
-                if (a.reg_variable != 0.0)
+                if (tid == 0) // the conditioning-dependent factor
                 {
-                    f = 0.0;
+                    const double fk = v.has_fk ? v.fk : a.reg_factor[(size_t)b * a.nObj + ObjIndex];
+                    f               = 0.0;
                     if (rank > 0)
                     {
                         double ce = 0.0;
@@ -588,12 +750,13 @@ namespace lexls
                             f *= fk;
                         }
                     }
+                    v.scal[0] = f;
                 }
-                v.scal[0] = f;
+                __syncthreads();
+                f = v.scal[0];
             }
-            __syncthreads();
-            const double f     = v.scal[0];
             const bool nonzero = !(fabs(f - 0.0) < 1e-15);
+            REG_STAMP(v, 0, tid)
             switch (a.reg_type)
             {
             case 1: // REGULARIZATION_TIKHONOV
@@ -638,6 +801,13 @@ namespace lexls
                 break;
             default: break;
             }
+            REG_STAMP(v, 5, tid)
+        }
+        template <int NT>
+        __device__ void regularize_level(const LseArgs &a, uint32_t b, double *W, size_t ld, uint32_t nf, uint32_t ObjIndex, uint32_t F, uint32_t Fc,
+                                         uint32_t rank, uint32_t RC, uint32_t tid, const RegLevels *lv = nullptr)
+        {
+            regularize_level<NT>(a, b, reg_view(a, b, W, ld, nf), ObjIndex, F, Fc, rank, RC, tid, lv);
         }
     } // namespace
 } // namespace lexls

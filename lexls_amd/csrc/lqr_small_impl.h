@@ -22,6 +22,7 @@
 // division sequence.  LDS per wave: the transposition scratch and the compact [R_k T_k | rhs_k]
 // images the back-substitution needs (~10 KB), so ~12 waves fit a CU.
 #pragma once
+#include <cstdlib>
 #include "lqr_wave_common.h"
 #include "lexls_regularize.h"
 
@@ -57,7 +58,7 @@ namespace lexls
         // compact LDS image [R T | rhs] as their matrix view; the accumulated null-space basis lives in the handle's scratch and follows
         // the column swaps.  Own instantiations (lqr_small_*_fR.hip): the common path does not carry the calls.
         template <int NC, int MD, bool EXACT, bool WF, bool REG = false>
-        __global__ __launch_bounds__(64, LEXLS_WAVE_OCC) void lqr_wave_kernel(LseArgs a, uint32_t img_doubles)
+        __global__ __launch_bounds__(64, LEXLS_WAVE_OCC) void lqr_wave_kernel(LseArgs a, uint32_t img_doubles, uint32_t reg_cfg)
         {
             constexpr bool write_factor = WF; // factor kept in HBM (get_lexqr / dual solve) or x-only traffic
             extern __shared__ double smem[];
@@ -82,6 +83,44 @@ namespace lexls
             uint8_t *phys_s  = reinterpret_cast<uint8_t *>(meta + 4 * nObj); // 64: physical column at each final position
             uint8_t *slotmap = phys_s + 64;           // nObj*64: position of each physical column when level k was stored
             uint16_t *offs   = reinterpret_cast<uint16_t *>(slotmap + 64 * nObj); // 64: image offsets of the solved columns
+            // REG: the regularization routines' vectors, their work matrix and the null-space basis in LDS behind everything else, as far as
+            // the host found room (reg_cfg: bits 0-7 order of the work-matrix window, 0 = none; bit 8 basis in LDS).  What does not fit stays in
+            // the handle's scratch, where the generic kernel keeps all of it: same routines, same arithmetic, other address space.
+            RegView rv{};
+            double *NSp     = nullptr; // the null-space basis as the pivot loop sees it
+            uint32_t ldns   = 0;
+            double reg_fk   = 0.0;     // lane k: level k's factor
+            bool reg_basis  = false;   // types whose damping or least-norm solution reads the basis (lexlse.h:2592: the others never accumulate it)
+            if constexpr (REG)
+            {
+                double *rbase = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(offs + 64) + 15) & ~(uintptr_t)15);
+                rv            = reg_view(a, b, nullptr, 1, 0);
+                rv.d          = rbase;
+                rv.out        = rv.d + n;
+                rv.scal       = rv.out + n;
+                rbase         = rv.scal + 8;
+                if (a.reg_type == 2 || a.reg_type == 6)
+                {
+                    rv.cg = rbase;
+                    rbase += 10 * n;
+                }
+                const uint32_t ldl = reg_cfg & 0xffu;
+                if (ldl)
+                {
+                    rv.Dl  = rbase;
+                    rv.ldl = ldl;
+                    rbase += ldl * ldl;
+                }
+                if (reg_cfg & 0x100u)
+                {
+                    rv.NS   = rbase;
+                    rv.ldns = (uint32_t)n | 1u;
+                }
+                NSp       = rv.NS;
+                ldns      = rv.ldns;
+                reg_fk    = lane < nObj ? a.reg_factor[(size_t)b * nObj + lane] : 0.0; // (fetched here: not a memory latency per level)
+                reg_basis = a.reg_type == 1 || a.reg_type == 2 || a.reg_type == 3 || a.reg_type == 8;
+            }
             STAMP_DECL
 
             const uint32_t *dims = a.dims + (size_t)b * nObj;
@@ -137,8 +176,8 @@ namespace lexls
 
             if constexpr (REG) // initialize(): null_space.setZero() (lexlse.h:1686)
             {
-                double *NS = a.reg_scratch + (size_t)b * reg_scratch_doubles((uint32_t)n);
-                for (int e = lane; e < n * (n + 1); e += 64) NS[e] = 0.0;
+                if (reg_basis)
+                    for (int e = lane; e < (int)ldns * (n + 1); e += 64) NSp[e] = 0.0;
             }
             int pos        = (lane < n) ? lane : (lane == n ? n : 0x3fffffff);
             int rowlim     = 64; // factor output: rows of this lane's physical column that the row-per-lane image T still owns (all, until it is pivoted)
@@ -335,14 +374,13 @@ namespace lexls
                         if (lane == 0) perm_s[ColIndex] = (uint32_t)ppos;
                         if constexpr (REG)
                         {
-                            if (ppos != ColIndex) // lexlse.h:229-231: the rows of the null-space basis above this level's first column swap too
+                            if (ppos != ColIndex && reg_basis) // lexlse.h:229-231: the rows of the null-space basis above this level's first column swap too
                             {
-                                double *NS = a.reg_scratch + (size_t)b * reg_scratch_doubles((uint32_t)n);
                                 for (int i = lane; i < Fc; i += 64)
                                 {
-                                    const double t0               = NS[i + (size_t)ColIndex * n];
-                                    NS[i + (size_t)ColIndex * n] = NS[i + (size_t)ppos * n];
-                                    NS[i + (size_t)ppos * n]     = t0;
+                                    const double t0                   = NSp[i + (size_t)ColIndex * ldns];
+                                    NSp[i + (size_t)ColIndex * ldns] = NSp[i + (size_t)ppos * ldns];
+                                    NSp[i + (size_t)ppos * ldns]     = t0;
                                 }
                             }
                         }
@@ -451,14 +489,13 @@ namespace lexls
                         if (lane == 0) perm_s[ColIndex] = (uint32_t)ppos;
                         if constexpr (REG)
                         {
-                            if (ppos != ColIndex) // lexlse.h:229-231: the rows of the null-space basis above this level's first column swap too
+                            if (ppos != ColIndex && reg_basis) // lexlse.h:229-231: the rows of the null-space basis above this level's first column swap too
                             {
-                                double *NS = a.reg_scratch + (size_t)b * reg_scratch_doubles((uint32_t)n);
                                 for (int i = lane; i < Fc; i += 64)
                                 {
-                                    const double t0               = NS[i + (size_t)ColIndex * n];
-                                    NS[i + (size_t)ColIndex * n] = NS[i + (size_t)ppos * n];
-                                    NS[i + (size_t)ppos * n]     = t0;
+                                    const double t0                   = NSp[i + (size_t)ColIndex * ldns];
+                                    NSp[i + (size_t)ColIndex * ldns] = NSp[i + (size_t)ppos * ldns];
+                                    NSp[i + (size_t)ppos * ldns]     = t0;
                                 }
                             }
                         }
@@ -656,8 +693,22 @@ namespace lexls
                     __syncthreads(); // the image is in place (and so is everything the swaps wrote to the null-space basis)
                     __threadfence_block();
                     // matrix view of the routines: w(F + r, Fc + c) = img[c * stride + r] (columns in position order, the rhs at position n)
-                    double *Wv = img - ((size_t)F + (size_t)Fc * (size_t)stride);
-                    regularize_level<64>(a, b, Wv, (size_t)(stride > 0 ? stride : 1), (uint32_t)nf, (uint32_t)k, (uint32_t)F, (uint32_t)Fc, (uint32_t)rank, (uint32_t)(n - ColIndex), (uint32_t)lane);
+                    rv.W  = img - ((size_t)F + (size_t)Fc * (size_t)stride);
+                    rv.ld = (size_t)(stride > 0 ? stride : 1);
+                    rv.nf     = (uint32_t)nf;
+                    rv.fk     = rdlane(reg_fk, k & 63);
+                    rv.has_fk = k < 64;
+#ifdef LEXLS_WAVE_STAMPS
+                    rv.stamp = a.lambda + (size_t)b * (n + cap) + 16;
+                    if (lane == 0)
+                    {
+                        if (k == 0)
+                            for (int i_ = 0; i_ < 15; i_++) rv.stamp[i_] = 0.0;
+                        rv.stamp[15] = (double)clock64();
+                    }
+                    __syncthreads();
+#endif
+                    regularize_level<64>(a, b, rv, (uint32_t)k, (uint32_t)F, (uint32_t)Fc, (uint32_t)rank, (uint32_t)(n - ColIndex), (uint32_t)lane);
                     __syncthreads();
                     if (rank > 0 && lane == n) // the damped right-hand side is what the factor keeps (and what the Gauss step below subtracts)
                     {
@@ -850,6 +901,14 @@ namespace lexls
             STAMP(9)
 
             // ---- results ----
+            if constexpr (REG) // the null-space basis goes where solveLeastNorm_3 reads it (lexlse.h:93): the handle's scratch, ld = n
+            {
+                if (reg_basis && (reg_cfg & 0x100u))
+                {
+                    double *NSg = a.reg_scratch + (size_t)b * reg_scratch_doubles((uint32_t)n);
+                    for (int e = lane; e < n * (n + 1); e += 64) NSg[e] = NSp[(e % n) + (size_t)(e / n) * ldns];
+                }
+            }
             if (write_factor) // get_lexqr layout: column = FINAL position of the physical column
             {
 #pragma unroll
@@ -887,7 +946,41 @@ namespace lexls
             // worst case of sum_k (n+1-Fc_k) * even(rank_k) over rank distributions with rank_k <= MD
             const uint32_t n   = a.nVar;
             const uint32_t img = (n * n) / 2 + n + (n * MD) / 2 + a.nObj * (n + 1) + 64 + MD * MD; // (+ zeros behind the last image: a padded level reads MD columns of it)
-            const size_t lds   = 8 * ((size_t)NC * MD + 128 + img + 64) + 4 * (64 + 4 * (size_t)a.nObj) + 64 + 64 * (size_t)a.nObj + 128 + 16;
+            size_t lds         = 8 * ((size_t)NC * MD + 128 + img + 64) + 4 * (64 + 4 * (size_t)a.nObj) + 64 + 64 * (size_t)a.nObj + 128 + 16;
+            uint32_t reg_cfg   = 0;
+            if constexpr (REG)
+            {
+                // the routines' vectors always; then their work matrix (order bounded by the type: the damped triangle alone for R / R_NO_Z /
+                // RT_NO_Z, under n/2 + the largest level for TIKHONOV — tikhonov_2 is taken while Fc + rank <= n/2, tikhonov_1 has order n - Fc —,
+                // n for TIKHONOV_2) and the null-space basis, each while LEXLS_REG_LDS_WAVES wavefronts (default 8: the occupancy is worth more than either, measured) still share a CU's LDS
+                static const size_t share = [] {
+                    const char *e = std::getenv("LEXLS_REG_LDS_WAVES");
+                    const long w  = e ? std::atol(e) : 8;
+                    return kMaxLdsBytes / (size_t)(w < 1 ? 1 : (w > 8 ? 8 : w));
+                }();
+                const bool cg = a.reg_type == 2 || a.reg_type == 6;
+                lds           = ((lds + 15) & ~(size_t)15) + 16 + 8 * (2 * (size_t)n + 8 + (cg ? 10 * (size_t)n : 0));
+                uint32_t order = 0;
+                switch (a.reg_type)
+                {
+                case 3: case 4: case 5: order = MD; break;
+                case 1: order = n / 2 + MD + 1 < n ? n / 2 + MD + 1 : n; break;
+                case 8: order = n; break;
+                default: break;
+                }
+                if (order > 255) order = 0;
+                if (order && lds + 8 * (size_t)order * order <= share)
+                {
+                    reg_cfg |= order;
+                    lds += 8 * (size_t)order * order;
+                }
+                const bool basis = a.reg_type == 1 || a.reg_type == 2 || a.reg_type == 3 || a.reg_type == 8;
+                if (basis && lds + 8 * (size_t)(n | 1u) * (n + 1) <= share)
+                {
+                    reg_cfg |= 0x100u;
+                    lds += 8 * (size_t)(n | 1u) * (n + 1);
+                }
+            }
             if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
             if (lds > 64 * 1024)
             {
@@ -895,7 +988,7 @@ namespace lexls
                 if (e != hipSuccess) return e;
             }
             if (REG && !a.reg_scratch) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((lqr_wave_kernel<NC, MD, EXACT, WF, REG>), dim3(a.batch), dim3(64), lds, s, a, img);
+            hipLaunchKernelGGL((lqr_wave_kernel<NC, MD, EXACT, WF, REG>), dim3(a.batch), dim3(64), lds, s, a, img, reg_cfg);
             return hipGetLastError();
         }
 
