@@ -599,6 +599,57 @@ extern "C"
         return LEXLS_OK;
     }
 
+    /* internal (the lock-step LexLSI driver): ALL remaining resident iterations in one persistent launch — per instance l-QR (rows gathered by
+     * reference, levels above the changed one read back) -> removal sweep -> lsi_iterate_body, until the instance stops (at most `count`
+     * iterations).  Same preparation and the same bookkeeping as lexls_internal_round_resident + lexls_internal_arm_resume +
+     * lexls_lse_factorize_solve(h, 1) + lexls_lse_sensitivity_resident per stage.  Returns 1 (nothing done, nothing changed) when the shape has no
+     * persistent instantiation: the driver then enqueues the stage's three kernels as before. */
+    int lexls_internal_resident_fused(lexls_lse_t h, int has_fixed, int count, double tolW, double tolC, const void *resident_args, size_t resident_args_bytes)
+    {
+        CHECK_HANDLE(h);
+        if (!h->d_cdata || !h->d_in_owned) return fail(LEXLS_ERR_INVALID, "resident_fused: needs resident constraint data and one uploaded round");
+        if (h->force_generic != 0 || h->reg_type != 0 || std::getenv("LEXLS_LSI_NO_FUSED")) return 1;
+        HIP_TRY(hipSetDevice(h->device));
+        // what lexls_internal_round_resident would set — on a copy of the fields first: nothing changes when the launch is not taken
+        uint32_t max_level = 0;
+        for (uint32_t v : h->maxdim) max_level = v > max_level ? v : max_level;
+        {
+            lexls_lse_s probe    = *h; // (plain fields and pointers; the vectors are copied, the probe owns nothing it frees)
+            probe.max_rows       = h->cap ? h->cap : 1;
+            probe.max_level_dim  = max_level;
+            probe.min_level_dim  = 0;
+            probe.dims_set       = true;
+            probe.has_fixed      = has_fixed != 0;
+            probe.has_skip       = true;
+            probe.fused_gather   = true;
+            probe.d_in           = h->d_in_owned;
+            probe.resume_armed   = h->resume_enabled;
+            const LseArgs pa     = probe.args();
+            const char *variant  = "";
+            if (!wave_kernel_supports(pa, probe.max_rows, max_level, probe.has_fixed)) return 1;
+            const hipError_t e = launch_lsi_fused(pa, max_level, probe.has_fixed, h->d_objidx, tolW, tolC, h->sens_scan, resident_args, resident_args_bytes, count, h->stream, &variant);
+            if (e == hipErrorNotSupported) return 1;
+            HIP_TRY(e);
+            h->last_kernel = variant;
+        }
+        h->level_max.assign(h->maxdim.begin(), h->maxdim.end());
+        h->max_rows      = h->cap ? h->cap : 1;
+        h->max_level_dim = max_level;
+        h->min_level_dim = 0;
+        h->dims_set      = true;
+        h->has_fixed     = has_fixed != 0;
+        h->has_skip      = true;
+        h->fused_gather  = true;
+        h->d_in          = h->d_in_owned;
+        h->resume_armed  = false;
+        h->resume_valid  = h->resume_enabled && h->d_resume_state != nullptr;
+        h->factor_valid  = true;
+        h->factor_epoch++;
+        h->x_epoch       = h->factor_epoch;
+        h->factor_in_hbm = true;
+        return LEXLS_OK;
+    }
+
     static int upload_round(lexls_lse_t h, const void *h_in, int gather, bool trusted);
     int lexls_lse_upload_round(lexls_lse_t h, const void *h_in, int gather) { return upload_round(h, h_in, gather, false); }
     /* internal (not in include/lexls_hip.h): the lock-step LexLSI driver of this library fills the block itself — variable indices and

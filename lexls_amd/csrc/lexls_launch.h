@@ -16,6 +16,7 @@ namespace lexls
     hipError_t launch_residual(const LseArgs &a, hipStream_t s);
     hipError_t launch_sensitivity(const LseArgs &a, const int32_t *d_obj_index, int32_t obj_all, double tolW, double tolC, hipStream_t s, bool scan_up = false,
                                   uint32_t sweep_level_dim_hint = 0); // hint = largest level dimension of the batch (enables the single-sweep kernel)
+    bool sensitivity_sweep_serves(const LseArgs &a, uint32_t sweep_level_dim_hint); // launch_sensitivity takes the one-wavefront-per-problem sweep for these arguments
     hipError_t launch_leastnorm(const LseArgs &a, hipStream_t s);
     hipError_t launch_leastnorm2(const LseArgs &a, hipStream_t s);
     hipError_t launch_leastnorm3(const LseArgs &a, hipStream_t s);
@@ -31,6 +32,14 @@ namespace lexls
     /// only; 7 / 8 = lqr_mfma with two / one problem per wavefront, else lqr_qtol
     hipError_t launch_lqr_wave(const LseArgs &a, uint32_t max_level_dim, bool write_factor, bool has_fixed, int left_looking, hipStream_t s,
                                const char **variant, int tolerance = 0);
+
+    /// The resident active-set iterations of a lock-step LexLSI batch as one persistent launch (lsi_fused_impl.h): l-QR (the register-resident wave
+    /// kernel's body, rows gathered by reference) -> removal sweep -> iteration, per instance until it stops or `count` iterations are done.
+    /// resident_args: the driver's ResidentArgs (lexls_lsi_device.h).  hipErrorNotSupported: the shape has no persistent instantiation (the caller
+    /// enqueues the three kernels per stage instead); the conditions are those under which launch_lqr_wave(a, ..., factor kept, left_looking < 0)
+    /// takes the same register-resident instantiation and launch_sensitivity the sweep
+    hipError_t launch_lsi_fused(const LseArgs &a, uint32_t max_level_dim, bool has_fixed, const int32_t *d_obj_index, double tolW, double tolC, bool scan_up,
+                                const void *resident_args, size_t resident_args_bytes, int count, hipStream_t s, const char **variant);
 
     // lqr_large.hip — problems too large for one CU's LDS: one launch per stage, the whole chip per problem
     bool generic_fits_lds(const LseArgs &a, uint32_t max_rows);

@@ -7,6 +7,8 @@ namespace lexls
 {
     hipError_t launch_wave_41x12e_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_41x12e_f(const LseArgs &a, hipStream_t s);
+    hipError_t launch_lsi_fused_41x12e(const LseArgs &a, uint32_t sweep_level_dim, const int32_t *d_obj_index, double tolW, double tolC, bool scan_up, const void *resident_args,
+                                       size_t resident_args_bytes, int count, hipStream_t s);
     hipError_t launch_wave_41x12_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_41x12_f(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_64x16_x(const LseArgs &a, hipStream_t s);
@@ -254,5 +256,19 @@ namespace lexls
         }
         *variant = "lqr_wave<64,16>";
         return write_factor ? launch_wave_64x16_f(a, s) : launch_wave_64x16_x(a, s);
+    }
+
+    hipError_t launch_lsi_fused(const LseArgs &a, uint32_t max_level_dim, bool has_fixed, const int32_t *d_obj_index, double tolW, double tolC, bool scan_up,
+                                const void *resident_args, size_t resident_args_bytes, int count, hipStream_t s, const char **variant)
+    {
+        const uint32_t nc = a.nVar + 1;
+        if (a.reg_type != 0 || !a.g_cdata || !wave_dispatch_is_register_resident(a, max_level_dim, has_fixed, -1) || !sensitivity_sweep_serves(a, max_level_dim))
+            return hipErrorNotSupported;
+        if (max_level_dim <= 12 && nc == 41) // (launch_lqr_wave: "lqr_wave<41,12,exact>")
+        {
+            *variant = "lsi_fused<lqr_wave<41,12,exact>>";
+            return launch_lsi_fused_41x12e(a, max_level_dim, d_obj_index, tolW, tolC, scan_up, resident_args, resident_args_bytes, count, s);
+        }
+        return hipErrorNotSupported;
     }
 } // namespace lexls

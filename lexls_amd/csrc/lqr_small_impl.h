@@ -57,13 +57,14 @@ namespace lexls
         // damped by lexls_regularize.h's routines — the same ones, in the same order, the generic kernel calls — working on the level's
         // compact LDS image [R T | rhs] as their matrix view; the accumulated null-space basis lives in the handle's scratch and follows
         // the column swaps.  Own instantiations (lqr_small_*_fR.hip): the common path does not carry the calls.
+        // The kernel's body is a device function of the problem index: lqr_wave_kernel below runs it once per workgroup, the persistent LexLSI
+        // kernel (lsi_fused_impl.h) once per active-set iteration of its instance.
         template <int NC, int MD, bool EXACT, bool WF, bool REG = false>
-        __global__ __launch_bounds__(64, LEXLS_WAVE_OCC) void lqr_wave_kernel(LseArgs a, uint32_t img_doubles, uint32_t reg_cfg)
+        __device__ __forceinline__ void lqr_wave_body(const LseArgs &a, uint32_t img_doubles, uint32_t reg_cfg, const uint32_t b)
         {
             constexpr bool write_factor = WF; // factor kept in HBM (get_lexqr / dual solve) or x-only traffic
             extern __shared__ double smem[];
             const int lane       = threadIdx.x;
-            const uint32_t b     = blockIdx.x;
             const int n          = EXACT ? NC - 1 : (int)a.nVar;
             const int cap        = (int)a.cap;
             const int nObj       = (int)a.nObj;
@@ -307,24 +308,49 @@ namespace lexls
                         const int R   = dim - counter; // compile-time when FULL
                         const int row = F + counter;
 
-                        // -- pivot: first maximum (by position) of the down-dated norms (lexlse.h:205-206) --
-                        const bool cand      = (lane < n) && (pos >= ColIndex);
-                        const double key     = cand ? nrm : -INFINITY;
-                        const double maxv    = wave_max(key);
-                        unsigned long long m = __ballot(cand && key == maxv);
-                        int pl               = (int)__builtin_ctzll(m);
-                        if (__builtin_popcountll(m) > 1)
+#ifdef LEXLS_WAVE_LDS_HANDOFF
+                        // (the sums the winner will hand over — every lane on its own column — are independent of the decision: issued ahead of it,
+                        //  they run inside the butterfly's latency)
+                        double fr = 0.0, tl = 0.0;
+#pragma unroll
+                        for (int r = 0; r < MD; r++)
                         {
-                            int bestpos = 0x7fffffff;
-                            while (m)
+                            if (r >= counter) fr = dfma(hh[r], hh[r], fr);
+                            if (r > counter) tl = dfma(hh[r], hh[r], tl);
+                        }
+#endif
+                        // -- pivot: first maximum (by position) of the down-dated norms (lexlse.h:205-206) --
+                        //    Decided on the norms' HIGH WORDS first (signed-integer order = the order of non-negative doubles; one v_max_i32_dpp per
+                        //    butterfly stage): a unique lane with the largest high word holds the largest norm.  Two lanes with that high word, or
+                        //    no non-negative norm among the candidates, take the comparison of whole doubles and the position rule — the same lane either way.
+                        const bool cand = (lane < n) && (pos >= ColIndex);
+                        const int khi   = cand ? __double2hiint(nrm) : (int)0x80000000;
+                        const int mhi   = wave_maxi(khi);
+                        int pl;
+                        {
+                            const unsigned long long mk = __builtin_amdgcn_uicmp((unsigned)khi, (unsigned)mhi, 32 /* == */);
+                            if (mhi >= 0 && __builtin_popcountll(mk) == 1)
+                                pl = (int)__builtin_ctzll(mk);
+                            else
                             {
-                                const int l = (int)__builtin_ctzll(m);
-                                m &= m - 1;
-                                const int p2 = __builtin_amdgcn_readlane(pos, l);
-                                if (p2 < bestpos)
+                                const double key     = cand ? nrm : -INFINITY;
+                                const double maxv    = wave_max(key);
+                                unsigned long long m = __ballot(cand && key == maxv);
+                                pl                   = (int)__builtin_ctzll(m);
+                                if (__builtin_popcountll(m) > 1)
                                 {
-                                    bestpos = p2;
-                                    pl      = l;
+                                    int bestpos = 0x7fffffff;
+                                    while (m)
+                                    {
+                                        const int l = (int)__builtin_ctzll(m);
+                                        m &= m - 1;
+                                        const int p2 = __builtin_amdgcn_readlane(pos, l);
+                                        if (p2 < bestpos)
+                                        {
+                                            bestpos = p2;
+                                            pl      = l;
+                                        }
+                                    }
                                 }
                             }
                         }
@@ -335,13 +361,6 @@ namespace lexls
                         // -- fresh norm of the pivot column and the Householder tail norm (lexlse.h:210-211, :241), every lane on its own column;
                         //    the pivot's lane hands [fresh, tail | its column] to the wave through LDS (one write burst, two reads: in-order
                         //    within the wave, no barrier) — it replaced ~60 v_readlane / 20 v_writelane per pivot with their SGPR hazards --
-                        double fr = 0.0, tl = 0.0;
-#pragma unroll
-                        for (int r = 0; r < MD; r++)
-                        {
-                            if (r >= counter) fr = dfma(hh[r], hh[r], fr);
-                            if (r > counter) tl = dfma(hh[r], hh[r], tl);
-                        }
                         {
                             const int ce = counter & ~1; // (folds: the pivot loop is unrolled)
                             if (lane == pl)
@@ -936,17 +955,35 @@ namespace lexls
             STAMP(10)
             STAMP_WRITE
         }
+
+        template <int NC, int MD, bool EXACT, bool WF, bool REG = false>
+        __global__ __launch_bounds__(64, LEXLS_WAVE_OCC) void lqr_wave_kernel(LseArgs a, uint32_t img_doubles, uint32_t reg_cfg)
+        {
+            lqr_wave_body<NC, MD, EXACT, WF, REG>(a, img_doubles, reg_cfg, blockIdx.x);
+        }
     } // namespace
 
     namespace
     {
+        /// doubles of the compact level images: worst case of sum_k (n+1-Fc_k) * even(rank_k) over rank distributions with rank_k <= MD
+        template <int MD>
+        inline uint32_t wave_img_doubles(const LseArgs &a)
+        {
+            const uint32_t n = a.nVar;
+            return (n * n) / 2 + n + (n * MD) / 2 + a.nObj * (n + 1) + 64 + MD * MD; // (+ zeros behind the last image: a padded level reads MD columns of it)
+        }
+        template <int NC, int MD>
+        inline size_t wave_lds_bytes(const LseArgs &a, uint32_t img)
+        {
+            return 8 * ((size_t)NC * MD + 128 + img + 64) + 4 * (64 + 4 * (size_t)a.nObj) + 64 + 64 * (size_t)a.nObj + 128 + 16;
+        }
+
         template <int NC, int MD, bool EXACT, bool WF, bool REG = false>
         hipError_t launch_wave_t2(const LseArgs &a, hipStream_t s)
         {
-            // worst case of sum_k (n+1-Fc_k) * even(rank_k) over rank distributions with rank_k <= MD
             const uint32_t n   = a.nVar;
-            const uint32_t img = (n * n) / 2 + n + (n * MD) / 2 + a.nObj * (n + 1) + 64 + MD * MD; // (+ zeros behind the last image: a padded level reads MD columns of it)
-            size_t lds         = 8 * ((size_t)NC * MD + 128 + img + 64) + 4 * (64 + 4 * (size_t)a.nObj) + 64 + 64 * (size_t)a.nObj + 128 + 16;
+            const uint32_t img = wave_img_doubles<MD>(a);
+            size_t lds         = wave_lds_bytes<NC, MD>(a, img);
             uint32_t reg_cfg   = 0;
             if constexpr (REG)
             {

@@ -36,6 +36,28 @@ namespace lexls
             return vmax(v, __hiloint2double(hi2, lo2));
         }
 
+        template <int CTRL>
+        __device__ __forceinline__ int dpp_maxi(int v)
+        {
+            const int o = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); // folds into v_max_i32_dpp
+            return o > v ? o : v;
+        }
+        /// signed maximum over the 64 lanes, wave-uniform: butterfly inside the 16-lane DPP rows, then v_permlane16_swap / v_permlane32_swap (both
+        /// operands the same value: whichever rows the instruction exchanges, the two results hold the two partners of every lane)
+        __device__ __forceinline__ int wave_maxi(int v)
+        {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            v = dpp_maxi<0xB1>(v);  // quad_perm [1,0,3,2]
+            v = dpp_maxi<0x4E>(v);  // quad_perm [2,3,0,1]
+            v = dpp_maxi<0x141>(v); // row_half_mirror
+            v = dpp_maxi<0x140>(v); // row_mirror
+            const u2 r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+            v          = (int)r.x > (int)r.y ? (int)r.x : (int)r.y;
+            const u2 q = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+            v          = (int)q.x > (int)q.y ? (int)q.x : (int)q.y;
+            return __builtin_amdgcn_readfirstlane(v);
+        }
+
         /// maximum over the 64 lanes, returned as a wave-uniform value: butterfly inside each 16-lane DPP row, then the four
         /// row results are combined through SGPRs (two more DPP steps — row_bcast:15 / row_bcast:31 — need fewer instructions
         /// but lengthen the dependent chain: measured slower)
