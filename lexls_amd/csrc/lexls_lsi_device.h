@@ -248,54 +248,107 @@ namespace
     /// u16 [act | inact | inact_pos] and u8 [ctr_state]
     __host__ __device__ inline size_t resident_lds_per_wave(uint32_t SD, uint32_t total) { return (8 * (size_t)SD + 7 * (size_t)total + 2 * STEP_MAX_OBJ + 15) & ~size_t(15); }
 
-    /// one instance's wavefront: b = the instance, wib = the wavefront's slice of the dynamic LDS
-    __device__ __forceinline__ void lsi_iterate_body(const ResidentArgs &a, const uint32_t b, const uint32_t wib)
+    /// LDS of one instance's wavefront and its slices of the resident arrays
+    struct ResidentView
+    {
+        double *dx_s, *adx_s, *dv_s;
+        uint16_t *na, *act, *ina, *ipos;
+        uint8_t *cs;
+        double *st;
+        const double *data;
+        const uint32_t *var;
+        uint8_t *g_cs;
+        uint16_t *g_act, *g_ina, *g_ipos, *g_na;
+        int32_t *info;
+    };
+    __device__ __forceinline__ ResidentView resident_view(const ResidentArgs &a, const uint32_t b, const uint32_t wib)
     {
         extern __shared__ double smem[];
-        const uint32_t lane = threadIdx.x & 63u;
-        if (!a.alive[b]) return;
         const StepShape &sh = a.sh;
         const uint32_t n = sh.n, total = sh.total;
-        char *wl      = reinterpret_cast<char *>(smem) + (size_t)wib * resident_lds_per_wave(sh.SD, total);
-        double *dx_s  = reinterpret_cast<double *>(wl);
-        double *adx_s = dx_s + n;
-        double *dv_s  = adx_s + total;
-        uint16_t *na   = reinterpret_cast<uint16_t *>(dv_s + total); // the working sets are edited in LDS and written back
-        uint16_t *act  = na + STEP_MAX_OBJ;
-        uint16_t *ina  = act + total;
-        uint16_t *ipos = ina + total;
-        uint8_t *cs    = reinterpret_cast<uint8_t *>(ipos + total);
-        double *st         = a.state + (size_t)b * sh.SD;
-        const double *data = a.cdata + (size_t)b * sh.per_data;
-        const uint32_t *var = a.var + (size_t)b * sh.dim0;
-        uint8_t *g_cs    = a.ctr_state + (size_t)b * total;
-        uint16_t *g_act  = a.act + (size_t)b * total;
-        uint16_t *g_ina  = a.inact + (size_t)b * total;
-        uint16_t *g_ipos = a.inact_pos + (size_t)b * total;
-        uint16_t *g_na   = a.na + (size_t)b * STEP_MAX_OBJ;
-        int32_t *info    = a.info + (size_t)b * 8;
-        for (uint32_t g = lane; g < total; g += 64)
+        ResidentView v;
+        char *wl = reinterpret_cast<char *>(smem) + (size_t)wib * resident_lds_per_wave(sh.SD, total);
+        v.dx_s   = reinterpret_cast<double *>(wl);
+        v.adx_s  = v.dx_s + n;
+        v.dv_s   = v.adx_s + total;
+        v.na     = reinterpret_cast<uint16_t *>(v.dv_s + total); // the working sets are edited in LDS and written back
+        v.act    = v.na + STEP_MAX_OBJ;
+        v.ina    = v.act + total;
+        v.ipos   = v.ina + total;
+        v.cs     = reinterpret_cast<uint8_t *>(v.ipos + total);
+        v.st     = a.state + (size_t)b * sh.SD;
+        v.data   = a.cdata + (size_t)b * sh.per_data;
+        v.var    = a.var + (size_t)b * sh.dim0;
+        v.g_cs   = a.ctr_state + (size_t)b * total;
+        v.g_act  = a.act + (size_t)b * total;
+        v.g_ina  = a.inact + (size_t)b * total;
+        v.g_ipos = a.inact_pos + (size_t)b * total;
+        v.g_na   = a.na + (size_t)b * STEP_MAX_OBJ;
+        v.info   = a.info + (size_t)b * 8;
+        return v;
+    }
+    __device__ __forceinline__ void resident_load_lists(const ResidentArgs &a, const ResidentView &v, const uint32_t lane)
+    {
+        for (uint32_t g = lane; g < a.sh.total; g += 64)
         {
-            act[g]  = g_act[g];
-            ina[g]  = g_ina[g];
-            ipos[g] = g_ipos[g];
-            cs[g]   = g_cs[g];
+            v.act[g]  = v.g_act[g];
+            v.ina[g]  = v.g_ina[g];
+            v.ipos[g] = v.g_ipos[g];
+            v.cs[g]   = v.g_cs[g];
         }
-        if (lane < STEP_MAX_OBJ) na[lane] = g_na[lane];
-        const int32_t found_i = a.sens[(size_t)b * 3], rm_pos = a.sens[(size_t)b * 3 + 1], rm_lvl = a.sens[(size_t)b * 3 + 2];
-        const int32_t nfact   = info[4] + 1; // lexlsi.h:1172
-        const int32_t niter = info[1], nact = info[2], ndeact = info[3];
-        const uint32_t trank = a.totalrank[b];
+        if (lane < STEP_MAX_OBJ) v.na[lane] = v.g_na[lane];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         asm volatile("" ::: "memory");
+    }
 
+    /// what the step of an iteration found (every lane holds it)
+    struct StepVerdict
+    {
         double alpha;
         int blk_obj;
         uint32_t blk_ctr, blk_type;
-        lsi_step_wave(sh, data, var, a.x_lse + (size_t)b * n, st, st, cs, ipos, dx_s, adx_s, dv_s, alpha, blk_obj, blk_ctr, blk_type);
+    };
+
+    /// first half of a resident iteration: the step and the ratio test on the solution of the equality problem (lsi_step_wave); the state moves.
+    /// The instance must be alive.
+    __device__ __forceinline__ StepVerdict lsi_iterate_step(const ResidentArgs &a, const uint32_t b, const uint32_t wib)
+    {
+        const uint32_t lane   = threadIdx.x & 63u;
+        const ResidentView v  = resident_view(a, b, wib);
+        resident_load_lists(a, v, lane);
+        StepVerdict r;
+        lsi_step_wave(a.sh, v.data, v.var, a.x_lse + (size_t)b * a.sh.n, v.st, v.st, v.cs, v.ipos, v.dx_s, v.adx_s, v.dv_s, r.alpha, r.blk_obj, r.blk_ctr, r.blk_type);
+        return r;
+    }
+
+    /// second half: ONE working-set change (the blocking constraint joins, or the constraint the removal search named leaves, or the instance
+    /// stops), the counters, the next equality problem.  The removal search's verdict (a.sens) is read only when the step was not blocked —
+    /// a caller that runs the search between the two halves may skip it for a blocked step, as the reference does (lexlsi.h:1181-1232).
+    /// RELOAD: the working-set lists are not in LDS any more (something else used it since lsi_iterate_step)
+    template <bool RELOAD>
+    __device__ __forceinline__ void lsi_iterate_finish(const ResidentArgs &a, const uint32_t b, const uint32_t wib, const StepVerdict &verdict)
+    {
+        const uint32_t lane  = threadIdx.x & 63u;
+        const StepShape &sh  = a.sh;
+        const uint32_t n = sh.n, total = sh.total;
+        const ResidentView v = resident_view(a, b, wib);
+        if (RELOAD) resident_load_lists(a, v, lane);
+        uint16_t *na = v.na, *act = v.act, *ina = v.ina, *ipos = v.ipos;
+        uint8_t *cs  = v.cs;
+        const double *data  = v.data;
+        const uint32_t *var = v.var;
+        int32_t *info       = v.info;
+        const int blk_obj       = verdict.blk_obj;
+        const uint32_t blk_ctr  = verdict.blk_ctr, blk_type = verdict.blk_type;
+        const bool blocked      = blk_obj >= 0;
+        const int32_t found_i = blocked ? 0 : a.sens[(size_t)b * 3], rm_pos = blocked ? -1 : a.sens[(size_t)b * 3 + 1], rm_lvl = blocked ? -2 : a.sens[(size_t)b * 3 + 2];
+        const int32_t nfact   = info[4] + 1; // lexlsi.h:1172
+        const int32_t niter = info[1], nact = info[2], ndeact = info[3];
+        const uint32_t trank = a.totalrank[b];
+        (void)n;
 
         // ---- one working-set change (lexlsi.h:1181-1232) and the counters; lane 0 on the LDS copy ----
-        const bool blocked = blk_obj >= 0, removed = !blocked && found_i != 0;
+        const bool removed = !blocked && found_i != 0;
         const bool done    = (!blocked && !removed) || nfact >= a.max_factorizations; // lexlsi.h:236-240
         if (lane == 0)
         {
@@ -347,12 +400,12 @@ namespace
         asm volatile("" ::: "memory");
         for (uint32_t g = lane; g < total; g += 64) // (a change touches a handful of entries; the lists are short: all of them go back)
         {
-            g_act[g]  = act[g];
-            g_ina[g]  = ina[g];
-            g_ipos[g] = ipos[g];
-            g_cs[g]   = cs[g];
+            v.g_act[g]  = act[g];
+            v.g_ina[g]  = ina[g];
+            v.g_ipos[g] = ipos[g];
+            v.g_cs[g]   = cs[g];
         }
-        if (lane < STEP_MAX_OBJ) g_na[lane] = na[lane];
+        if (lane < STEP_MAX_OBJ) v.g_na[lane] = na[lane];
         if (done) return;
 
         // ---- the next equality problem (lexlsi.h:968-982, objective.h:434-494), lane = active constraint ----
@@ -388,6 +441,14 @@ namespace
             }
         }
         for (uint32_t r = counter + lane; r < a.cap; r += 64) a.row_ld[(size_t)b * a.cap + r] = 0u;
+    }
+
+    /// one instance's wavefront: b = the instance, wib = the wavefront's slice of the dynamic LDS
+    __device__ __forceinline__ void lsi_iterate_body(const ResidentArgs &a, const uint32_t b, const uint32_t wib)
+    {
+        if (!a.alive[b]) return;
+        const StepVerdict verdict = lsi_iterate_step(a, b, wib);
+        lsi_iterate_finish<false>(a, b, wib, verdict);
     }
 
     __global__ __launch_bounds__(256) void lsi_iterate_kernel(ResidentArgs a)

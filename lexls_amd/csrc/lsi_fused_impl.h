@@ -1,6 +1,7 @@
 // The resident active-set iterations of a lock-step LexLSI batch as ONE launch: every instance's wavefront runs
 //     l-QR of its equality problem (lqr_wave_body, rows gathered by reference, levels above the changed one read back)
-//     -> removal search (sensitivity_sweep_body) -> step, working-set change, next problem (lsi_iterate_body)
+//     -> step + ratio test (lsi_iterate_step) -> removal search if nothing blocked the step (sensitivity_sweep_body)
+//     -> working-set change, counters, next problem (lsi_iterate_finish)
 // until the instance stops (lexlsi.h:1144-1265 per iteration) — the bodies of the three kernels the driver otherwise launches per stage
 // (lexls_lsi_capi.hip: enqueue_resident), unchanged, so the trajectories are the same bits.  What the single launch removes: three kernel
 // prologues / epilogues per stage (4.3 us each: the duration of a launch whose instances all skip), the lock step itself (an instance no
@@ -53,7 +54,11 @@ namespace lexls
             const FusedArgs &fa = fused_args(kernarg);
             sensitivity_sweep_body<SMD>(fa.a, fa.obj_index, 0, fa.tolW, fa.tolC, fa.scan_up, b);
         }
-        __device__ __noinline__ void fused_phase_iterate(unsigned long long kernarg, uint32_t b) { lsi_iterate_body(fused_args(kernarg).ra, b, 0u); }
+        __device__ __noinline__ StepVerdict fused_phase_step(unsigned long long kernarg, uint32_t b) { return lsi_iterate_step(fused_args(kernarg).ra, b, 0u); }
+        __device__ __noinline__ void fused_phase_finish(unsigned long long kernarg, uint32_t b, StepVerdict verdict)
+        {
+            lsi_iterate_finish<true>(fused_args(kernarg).ra, b, 0u, verdict);
+        }
 
         /// what one phase wrote to HBM is read by the next one of the SAME wavefront: its stores must have left the wavefront and the vector
         /// cache must not serve lines it held before them
@@ -77,9 +82,14 @@ namespace lexls
                 if (!fa.ra.alive[b]) break; // (wave-uniform; lsi_iterate_body clears it when the instance stops, at the latest after max_factorizations)
                 fused_phase_lqr<NC, MD, EXACT>(kernarg, b);
                 fused_phase_fence();
-                fused_phase_sweep<SMD>(kernarg, b);
+                const StepVerdict verdict = fused_phase_step(kernarg, b);
                 fused_phase_fence();
-                fused_phase_iterate(kernarg, b);
+                if (verdict.blk_obj < 0) // the removal search only behind a step that nothing blocked (lexlsi.h:1181-1232; the per-stage launches run it
+                {                        // speculatively for every instance and ignore it for the blocked ones)
+                    fused_phase_sweep<SMD>(kernarg, b);
+                    fused_phase_fence();
+                }
+                fused_phase_finish(kernarg, b, verdict);
                 fused_phase_fence();
             }
         }
