@@ -329,7 +329,11 @@ namespace lexls
                         int pl;
                         {
                             const unsigned long long mk = __builtin_amdgcn_uicmp((unsigned)khi, (unsigned)mhi, 32 /* == */);
+#ifdef LEXLS_WAVE_F64_DECISION
+                            if (false)
+#else
                             if (mhi >= 0 && __builtin_popcountll(mk) == 1)
+#endif
                                 pl = (int)__builtin_ctzll(mk);
                             else
                             {

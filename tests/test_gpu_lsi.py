@@ -546,6 +546,40 @@ def test_config5_full_size_lock_step_batch(hip, oracle, monkeypatch, resident):
         np.testing.assert_array_equal(warm["v"][b], np.concatenate(o["v"]), err_msg=str(b))
 
 
+def test_persistent_launch_equals_the_stage_by_stage_path(hip, monkeypatch):
+    """the resident iterations as ONE persistent launch (lsi_fused_impl.h: per instance l-QR -> step -> removal search behind an unblocked
+    step -> working-set change, until the instance stops) against the three launches per lock-step stage (LEXLS_LSI_NO_FUSED=1): same x, v,
+    working sets and counters, bit for bit — on the IK shape the persistent kernel is instantiated for, ragged working sets, a batch that is
+    not a multiple of anything"""
+    n, dims, batch = 40, [12] * 5, 197
+    base = lexlsi.pack_batch(n, [P.lsi_problem(20267700 + b, n, dims) for b in range(batch)])
+    pert = lexlsi.pack_batch(n, [P.lsi_problem(20267700 + b, n, dims, perturb=0.9) for b in range(batch)])
+    out = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("LEXLS_LSI_NO_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("LEXLS_LSI_NO_FUSED", "1")
+        srv = lexlsi.LsiBatch(n, base.dims, base.types, batch)
+        try:
+            cold = srv.run(base)
+            guess = np.where(cold["active"] == 3, 0, cold["active"]).astype(np.uint8)
+            warm = srv.run(pert, active_guess=guess, x0=cold["x"])
+            out[fused] = (cold, warm, srv.stats())
+        finally:
+            srv.close()
+    for which in (0, 1):
+        a, b = out[True][which], out[False][which]
+        assert all(i["status"] == 0 for i in a["info"])
+        assert [i for i in a["info"]] == [i for i in b["info"]]
+        np.testing.assert_array_equal(a["x"], b["x"])
+        np.testing.assert_array_equal(a["v"], b["v"])
+        np.testing.assert_array_equal(a["active"], b["active"])
+    # the persistent launch counts the iterations its longest-running instance needed; the stage-by-stage path enqueues stages in chunks of eight
+    longest = max(i["factorizations"] for i in out[True][1]["info"])
+    assert longest - 1 <= out[True][2]["device_step"] <= out[False][2]["device_step"]
+
+
 def test_front_end_debug_output(hip, oracle):
     """The fifth output of the MEX front end through lexls_lsi_solve_debug (`frontend.lexlsi(..., debug=True)`): working-set log with its
     step lengths / multipliers, final working set in order, the multiplier matrices of getLambda, factor, data and xStar of the last
