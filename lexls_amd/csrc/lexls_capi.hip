@@ -613,6 +613,7 @@ extern "C"
         // what lexls_internal_round_resident would set — on a copy of the fields first: nothing changes when the launch is not taken
         uint32_t max_level = 0;
         for (uint32_t v : h->maxdim) max_level = v > max_level ? v : max_level;
+        if (h->nVar + 1 > 41 && h->nVar + 1 <= 48 && max_level <= 12) return 1; // (42..48 columns: the four-per-wavefront kernel behind a gather launch, as lexls_internal_round_resident decides)
         {
             lexls_lse_s probe    = *h; // (plain fields and pointers; the vectors are copied, the probe owns nothing it frees)
             probe.max_rows       = h->cap ? h->cap : 1;

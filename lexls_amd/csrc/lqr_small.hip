@@ -7,8 +7,13 @@ namespace lexls
 {
     hipError_t launch_wave_41x12e_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_41x12e_f(const LseArgs &a, hipStream_t s);
-    hipError_t launch_lsi_fused_41x12e(const LseArgs &a, uint32_t sweep_level_dim, const int32_t *d_obj_index, double tolW, double tolC, bool scan_up, const void *resident_args,
-                                       size_t resident_args_bytes, int count, hipStream_t s);
+#define LEXLS_DECLARE_LSI_FUSED(NAME)                                                                                                                            \
+    hipError_t NAME(const LseArgs &a, uint32_t sweep_level_dim, const int32_t *d_obj_index, double tolW, double tolC, bool scan_up, const void *resident_args, \
+                    size_t resident_args_bytes, int count, hipStream_t s);
+    LEXLS_DECLARE_LSI_FUSED(launch_lsi_fused_41x12e)
+    LEXLS_DECLARE_LSI_FUSED(launch_lsi_fused_41x12)
+    LEXLS_DECLARE_LSI_FUSED(launch_lsi_fused_64x16)
+#undef LEXLS_DECLARE_LSI_FUSED
     hipError_t launch_wave_41x12_x(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_41x12_f(const LseArgs &a, hipStream_t s);
     hipError_t launch_wave_64x16_x(const LseArgs &a, hipStream_t s);
@@ -264,11 +269,18 @@ namespace lexls
         const uint32_t nc = a.nVar + 1;
         if (a.reg_type != 0 || !a.g_cdata || !wave_dispatch_is_register_resident(a, max_level_dim, has_fixed, -1) || !sensitivity_sweep_serves(a, max_level_dim))
             return hipErrorNotSupported;
-        if (max_level_dim <= 12 && nc == 41) // (launch_lqr_wave: "lqr_wave<41,12,exact>")
+        // (the register-resident instantiation launch_lqr_wave takes for these arguments)
+        if (max_level_dim <= 12 && nc == 41)
         {
             *variant = "lsi_fused<lqr_wave<41,12,exact>>";
             return launch_lsi_fused_41x12e(a, max_level_dim, d_obj_index, tolW, tolC, scan_up, resident_args, resident_args_bytes, count, s);
         }
-        return hipErrorNotSupported;
+        if (max_level_dim <= 12 && nc <= 41)
+        {
+            *variant = "lsi_fused<lqr_wave<41,12>>";
+            return launch_lsi_fused_41x12(a, max_level_dim, d_obj_index, tolW, tolC, scan_up, resident_args, resident_args_bytes, count, s);
+        }
+        *variant = "lsi_fused<lqr_wave<64,16>>";
+        return launch_lsi_fused_64x16(a, max_level_dim, d_obj_index, tolW, tolC, scan_up, resident_args, resident_args_bytes, count, s);
     }
 } // namespace lexls

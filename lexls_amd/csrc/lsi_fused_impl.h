@@ -113,7 +113,7 @@ namespace lexls
             const size_t l3 = resident_lds_per_wave(fa.ra.sh.SD, fa.ra.sh.total);
             lds             = lds > l2 ? lds : l2;
             lds             = lds > l3 ? lds : l3;
-            if (lds > 64 * 1024) return hipErrorInvalidValue;
+            if (lds > 64 * 1024) return hipErrorNotSupported; // (the caller falls back to the three launches per stage)
             if (sweep_level_dim <= 12)
                 hipLaunchKernelGGL((lsi_fused_kernel<NC, MD, EXACT, 12>), dim3(a.batch), dim3(64), lds, s, fa);
             else
