@@ -415,6 +415,22 @@ namespace
                 hipMemcpyAsync(rstate_host.data(), d_rstate, 8 * (size_t)B * rshape.SD, hipMemcpyDeviceToHost, stream) != hipSuccess ||
                 hipStreamSynchronize(stream) != hipSuccess)
                 throw Exception("download of the resident state failed");
+            if (fused_all && std::getenv("LEXLS_FUSED_STAMPS_DUMP")) // (a -DLEXLS_FUSED_STAMPS build leaves its phase clocks in the multiplier buffer)
+            {
+                std::vector<double> lam((size_t)B * (n + cap));
+                hip_check(lexls_lse_get_lambda(h, lam.data()));
+                hip_check(lexls_lse_synchronize(h));
+                double sum[6] = {0, 0, 0, 0, 0, 0}, most[6] = {0, 0, 0, 0, 0, 0};
+                for (uint32_t b = 0; b < B; b++)
+                {
+                    const double *o = lam.data() + (size_t)b * (n + cap);
+                    for (int i = 0; i < 6; i++) sum[i] += o[i];
+                    if (o[4] > most[4])
+                        for (int i = 0; i < 6; i++) most[i] = o[i];
+                }
+                std::fprintf(stderr, "persistent launch, cycles per iteration [l-QR | step | removal search (per iteration) | finish], iterations, searches: all instances %.0f | %.0f | %.0f | %.0f, %.0f, %.0f; the longest-running one %.0f | %.0f | %.0f | %.0f, %.0f, %.0f\n",
+                             sum[0] / sum[4], sum[1] / sum[4], sum[2] / sum[4], sum[3] / sum[4], sum[4], sum[5], most[0] / most[4], most[1] / most[4], most[2] / most[4], most[3] / most[4], most[4], most[5]);
+            }
             if (fused_all) // the persistent launch: the stages it ran = the iterations of the instance that ran longest (statistics only)
             {
                 int32_t most = 0;

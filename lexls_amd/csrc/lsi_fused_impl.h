@@ -77,21 +77,49 @@ namespace lexls
         {
             const uint32_t b                = blockIdx.x;
             const unsigned long long kernarg = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr(); // (FusedArgs is the only parameter: offset 0)
+            // Diagnostic build only (-DLEXLS_FUSED_STAMPS): shader-clock totals of the phases of this instance's iterations, left in the multiplier
+            // buffer (which the product build's last removal search owns): l-QR, step, removal search, finish, iterations, searches run
+#ifdef LEXLS_FUSED_STAMPS
+            long long fst[4] = {0, 0, 0, 0}, fst0 = clock64(), fn_it = 0, fn_sw = 0;
+#define FUSED_STAMP(i) { const long long t_ = clock64(); fst[i] += t_ - fst0; fst0 = t_; }
+#else
+#define FUSED_STAMP(i)
+#endif
             for (int it = 0; it < fa.count; it++)
             {
                 if (!fa.ra.alive[b]) break; // (wave-uniform; lsi_iterate_body clears it when the instance stops, at the latest after max_factorizations)
                 fused_phase_lqr<NC, MD, EXACT>(kernarg, b);
                 fused_phase_fence();
+                FUSED_STAMP(0)
                 const StepVerdict verdict = fused_phase_step(kernarg, b);
                 fused_phase_fence();
+                FUSED_STAMP(1)
                 if (verdict.blk_obj < 0) // the removal search only behind a step that nothing blocked (lexlsi.h:1181-1232; the per-stage launches run it
                 {                        // speculatively for every instance and ignore it for the blocked ones)
                     fused_phase_sweep<SMD>(kernarg, b);
                     fused_phase_fence();
+#ifdef LEXLS_FUSED_STAMPS
+                    fn_sw++;
+#endif
                 }
+                FUSED_STAMP(2)
                 fused_phase_finish(kernarg, b, verdict);
                 fused_phase_fence();
+                FUSED_STAMP(3)
+#ifdef LEXLS_FUSED_STAMPS
+                fn_it++;
+#endif
             }
+#ifdef LEXLS_FUSED_STAMPS
+            if (threadIdx.x == 0)
+            {
+                double *o = fa.a.lambda + (size_t)b * (fa.a.nVar + fa.a.cap);
+                for (int i = 0; i < 4; i++) o[i] = (double)fst[i];
+                o[4] = (double)fn_it;
+                o[5] = (double)fn_sw;
+            }
+#endif
+#undef FUSED_STAMP
         }
 
         template <int NC, int MD, bool EXACT>
