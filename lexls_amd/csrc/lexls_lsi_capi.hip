@@ -789,9 +789,12 @@ namespace
         /// f(b) for b in [0, count); returns when all are done; rethrows the first exception.
         /// The stages of a batch solve follow each other every ~50 us: a condition-variable wake-up per stage would cost more than
         /// the stage's host work, so idle workers spin on the generation counter for a while (spin_seconds) before they go to sleep.
-        void run(uint32_t count_, const std::function<void(uint32_t)> &f)
+        /// light: a job of a few microseconds per element (copies, releases): when the workers have gone to sleep (the GPU ran for
+        /// milliseconds meanwhile) waking sixteen threads through the condition variable costs more than running it here
+        void run(uint32_t count_, const std::function<void(uint32_t)> &f, bool light = false)
         {
-            if (th.empty() || count_ < 128)
+            while (pending.load(std::memory_order_acquire) != 0) relax(); // (a prewake() still being acknowledged)
+            if (th.empty() || count_ < 128 || (light && sleepers.load() != 0))
             {
                 for (uint32_t b = 0; b < count_; b++) f(b);
                 return;
@@ -811,6 +814,24 @@ namespace
             while (pending.load(std::memory_order_acquire) != 0) relax(); // every worker acknowledges every generation
             job = nullptr;
             if (err) std::rethrow_exception(err);
+        }
+
+        /// wakes sleeping workers ahead of a run() that is about to come (they spin again for spin_seconds): the wake-up latency of the
+        /// condition variable (~0.1-0.3 ms for the last of sixteen threads) then overlaps what the caller does in between
+        void prewake()
+        {
+            if (th.empty() || sleepers.load() == 0) return;
+            while (pending.load(std::memory_order_acquire) != 0) relax();
+            static const std::function<void(uint32_t)> nothing = [](uint32_t) {};
+            job   = &nothing;
+            count = 0;
+            next.store(0);
+            pending.store(static_cast<uint32_t>(th.size()), std::memory_order_relaxed);
+            gen.fetch_add(1);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                cv_start.notify_all();
+            }
         }
 
     private:
@@ -1029,6 +1050,7 @@ struct lexls_lsi_batch_s
         const int32_t *h_types = types.data();
         WorkerPool &pool       = *this->pool;
         const double t_begin   = BatchCtx::now();
+        pool.prewake(); // (the workers went to sleep between two solves; they are needed in ~0.1 ms)
         // Cycling handling relaxes bounds in the host copy of the constraint data (cycling.h:32-65, objective.h:774-790): such a run
         // assembles its problems on the host from that copy instead of gathering rows of the resident (unrelaxed) device copy
         const bool run_gather = gather && !par.cycling_handling_enabled;
@@ -1256,6 +1278,9 @@ struct lexls_lsi_batch_s
                     hipStreamSynchronize(ctx.stream) != hipSuccess)
                     throw Exception("download of the final state failed");
             }
+        bool every_instance_resident = run_resident; // (then the job below is four small copies per instance)
+        for (uint32_t g = 0; g < nGroups && every_instance_resident; g++)
+            for (uint32_t k = 0; k < grp[g]->B && every_instance_resident; k++) every_instance_resident = grp[g]->is_resident[k] != 0;
         pool.run(batch, [&](uint32_t b) {
             if (run_resident)
             {
@@ -1286,7 +1311,7 @@ struct lexls_lsi_batch_s
                     if (h_v) std::copy(st + nVar, st + nVar + total, h_v + (size_t)b * total);
                 }
             }
-        });
+        }, every_instance_resident);
         int rounds_fs = 0, rounds_sens = 0, rounds_step = 0;
         double t_enq = 0.0, t_wait = 0.0;
         for (uint32_t g = 0; g < nGroups; g++)
@@ -1322,7 +1347,9 @@ struct lexls_lsi_batch_s
             h_rounds2[1] = rounds_sens;
         }
         last_stats[0] = rounds_fs, last_stats[1] = rounds_sens, last_stats[2] = rounds_step, last_stats[3] = (int32_t)nGroups;
-        pool.run(batch, [&](uint32_t b) { lsi[b].reset(); }); // a thousand LexLSI objects (dozens of vectors each): freed in parallel, not serially on return
+        bool any_left = false;
+        for (uint32_t b = 0; b < batch && !any_left; b++) any_left = lsi[b] != nullptr;
+        if (any_left) pool.run(batch, [&](uint32_t b) { lsi[b].reset(); }); // a thousand LexLSI objects (dozens of vectors each): freed in parallel, not serially on return
     }
 };
 
