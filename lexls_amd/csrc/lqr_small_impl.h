@@ -365,6 +365,28 @@ namespace lexls
                         // -- fresh norm of the pivot column and the Householder tail norm (lexlse.h:210-211, :241), every lane on its own column;
                         //    the pivot's lane hands [fresh, tail | its column] to the wave through LDS (one write burst, two reads: in-order
                         //    within the wave, no barrier) — it replaced ~60 v_readlane / 20 v_writelane per pivot with their SGPR hazards --
+#ifndef LEXLS_WAVE_SCALARS_BY_LDS
+                        // the three scalars of the step straight from the pivot's lane (six v_readlane): the square root below starts on them while
+                        // the column — needed one entry per lane, only by the division behind the root — is still on its way through LDS
+                        {
+                            const int ce = counter & ~1; // (folds: the pivot loop is unrolled)
+                            if (lane == pl)
+                            {
+#pragma unroll
+                                for (int r = 0; r < MD; r += 2)
+                                    if (r >= ce) *reinterpret_cast<double2 *>(EX + 2 + r) = make_double2(hh[r], hh[r + 1]);
+                            }
+                        }
+                        const double fresh = rdlane(fr, pl);
+                        const double c0    = rdlane(hh[counter], pl);
+                        const double2 ft   = make_double2(fresh, rdlane(tl, pl));
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        asm volatile("" ::: "memory");
+                        const int l16       = lane & 15;
+                        const double spread = EX[2 + (l16 < MD ? l16 : MD - 1)];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        asm volatile("" ::: "memory");
+#else
                         {
                             const int ce = counter & ~1; // (folds: the pivot loop is unrolled)
                             if (lane == pl)
@@ -384,6 +406,7 @@ namespace lexls
                         const double spread = EX[2 + (l16 < MD ? l16 : MD - 1)];
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         asm volatile("" ::: "memory");
+#endif
                         if (lane == pl) nrm = fresh;
                         if (fresh < a.tol) // rank test on the squared norm (lexlse.h:214)
                         {
