@@ -535,17 +535,25 @@ def side_config4_lsi(device_index, with_cpu, total=1024):
                             "frac": float(f.sum()) * flops / dt / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "note": "flops of a full 60 x 41 problem per factorization (upper bound)"}}
         if with_cpu:
             from oracle import oracle_ctypes as oc
-            # instances of the same batch through the oracle-backed host driver, one thread, for ~3 s (problem generation not timed)
-            nf, tc, m = 0, 0.0, 0
-            while tc < 3.0 and m < total:
-                objs = P.lsi_problem(20260500 + m, n, dims, perturb=0.9)
-                t0 = time.perf_counter()
-                ro = oc.lsi_run(n, objs, active_guess=np.split(guess[m], np.cumsum(base.dims)[:-1]), x0=cold["x"][m])
-                tc += time.perf_counter() - t0
-                nf += int(ro["info"]["factorizations"])
-                m += 1
-            out["cpu_baseline"] = {"value": nf / tc, "unit": "factorizations/s", "cores": 1, "kind": "port",
-                                   "sample": f"{m} instances of the same warm-started batch ({nf} factorizations, {tc:.2f} s) through the host driver over the oracle, one thread"}
+            # the whole warm-started batch through the oracle-backed host driver (oracle_lsi_time_batch: instances dealt out to host threads inside the
+            # library, nothing of Python in the timed region), on the thread count that delivers most, and on one thread for the per-core figure
+            share = host_cpu_share()
+            hw = max(1, oc.hardware_threads())
+            best = (0.0, 1, 0, 0.0)
+            for cand in sorted({int(round(share["effective_cores"])), 2 * int(round(share["effective_cores"])), 4 * int(round(share["effective_cores"]))}):
+                if cand < 1 or cand > hw:
+                    continue
+                nf, tc = 0, 0.0
+                while tc < 2.0:  # (sustained: one pass is ~15 ms, a burst the cgroup's CPU quota does not throttle yet)
+                    a, b = oc.lsi_time_batch(pert, guess, cold["x"], cand)
+                    nf, tc = nf + a, tc + b
+                if nf / tc > best[0]:
+                    best = (nf / tc, cand, nf, tc)
+            nf1, tc1 = oc.lsi_time_batch(pert, guess, cold["x"], 1)
+            out["cpu_baseline"] = {"value": best[0], "unit": "factorizations/s", "cores": int(round(min(best[1], share["effective_cores"]))), "threads": best[1], "kind": "port",
+                                   **share, "single_thread": nf1 / tc1,
+                                   "sample": f"the same warm-started batch of {total} instances, repeated for {best[3]:.1f} s ({best[2]} factorizations on {best[1]} std::threads; one pass on one thread: {tc1:.2f} s) "
+                                             f"through the host driver over the oracle, instances dealt out inside the library"}
         return out
     except Exception as exc:  # noqa: BLE001
         return {"error": f"{type(exc).__name__}: {exc}"}

@@ -255,6 +255,63 @@ extern "C"
 
     int oracle_hardware_threads() { return static_cast<int>(std::thread::hardware_concurrency()); }
 
+    /// `batch` LexLSI problems of one structure (packed as lexls_lsi_batch_run takes them: data batch x per_data, var_index batch x dims[0],
+    /// active_guess batch x total, x0 batch x nVar), default parameters, on `nthreads` host threads (instances dealt out dynamically); what comes
+    /// back is the count of factorizations and the wall time of the solves — bench.py's CPU figure for configs[4] on the host's cores
+    int oracle_lsi_time_batch(uint32_t batch, uint32_t nVar, uint32_t nObj, const uint32_t *dims, const int32_t *types, const double *data, const uint32_t *var_index,
+                              const uint8_t *active_guess, const double *x0, int nthreads, int64_t *factorizations, double *seconds)
+    {
+        try
+        {
+            uint64_t per_data = 0, total = 0;
+            for (uint32_t k = 0; k < nObj; k++)
+            {
+                per_data += (uint64_t)dims[k] * (types[k] == 1 ? 2 : nVar + 2);
+                total += dims[k];
+            }
+            const uint32_t dim0 = (nObj && types[0] == 1) ? dims[0] : 0;
+            std::atomic<uint32_t> next(0);
+            std::atomic<int64_t> nf(0);
+            std::atomic<bool> failed(false);
+            auto work = [&]() {
+                std::vector<double> x(nVar), v(total);
+                std::vector<uint8_t> act(total);
+                for (;;)
+                {
+                    const uint32_t b = next.fetch_add(1);
+                    if (b >= batch) break;
+                    try
+                    {
+                        runner::LsiProblem p = {nVar, nObj, dims, types, data + (size_t)b * per_data, (var_index && dim0) ? var_index + (size_t)b * dim0 : nullptr,
+                                                active_guess ? active_guess + (size_t)b * total : nullptr, x0 ? x0 + (size_t)b * nVar : nullptr};
+                        ParametersLexLSI par;
+                        runner::LsiInfo info;
+                        runner::solve<OLSI>(p, par, x.data(), &info, act.data(), v.data());
+                        nf.fetch_add(info.factorizations);
+                    }
+                    catch (...)
+                    {
+                        failed.store(true);
+                    }
+                }
+            };
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<std::thread> th;
+            for (int i = 1; i < nthreads; i++) th.emplace_back(work);
+            work();
+            for (auto &t : th) t.join();
+            *seconds        = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            *factorizations = nf.load();
+            if (failed.load()) throw Exception("oracle_lsi_time_batch: an instance failed");
+            return 0;
+        }
+        catch (const std::exception &e)
+        {
+            g_err = e.what();
+            return 1;
+        }
+    }
+
     /// LexLSI on flat arrays (layout: include/lexls/lsi_runner.h).  params: [max_fact, tol_lin_dep, tol_wrong, tol_correct, tol_feas,
     /// cycling(0/1), cycling_max, cycling_relax, deactivate_first_wrong_sign(0/1), use_resumable_form(0/1)] or NULL for defaults.
     int oracle_lsi_run(uint32_t nVar, uint32_t nObj, const uint32_t *dims, const int32_t *types, const double *data, const uint32_t *var_index,

@@ -138,6 +138,21 @@ def lsi_run(nvar, objectives, active_guess=None, x0=None, v0=None, regularizatio
     return dict(x=x, info=dict(zip(keys, info.tolist())), active=np.split(active, np.cumsum(dims)[:-1]), v=np.split(v, np.cumsum(dims)[:-1]))
 
 
+def lsi_time_batch(packed, active_guess, x0, nthreads):
+    """a packed batch (lexls_amd.lexlsi.PackedBatch) of LexLSI problems through the oracle-backed driver on `nthreads` host threads, default parameters:
+    (factorizations, seconds of the solves) — bench.py's CPU figure for configs[4]"""
+    nf, sec = C.c_int64(0), C.c_double(0.0)
+    guess = None if active_guess is None else np.ascontiguousarray(active_guess, np.uint8)
+    x0a = None if x0 is None else np.ascontiguousarray(x0, np.float64)
+    vi = packed.var_index if packed.var_index is not None and np.size(packed.var_index) else None
+    rc = lib().oracle_lsi_time_batch(C.c_uint32(packed.batch), C.c_uint32(packed.nvar), C.c_uint32(len(packed.dims)), _p(np.ascontiguousarray(packed.dims, np.uint32), _u32p),
+                                     _p(np.ascontiguousarray(packed.types, np.int32), _i32p), _p(packed.data, _dp), _p(vi, _u32p), _p(guess, _u8p), _p(x0a, _dp),
+                                     C.c_int(int(nthreads)), C.byref(nf), C.byref(sec))
+    if rc:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    return int(nf.value), float(sec.value)
+
+
 def lsi_run_debug(nvar, objectives, active_guess=None, x0=None, v0=None, regularization_factors=None, max_log=4096, **params):
     """lsi_run plus the debug structure of the MEX front end (oracle_lsi_run_debug): the oracle-backed twin of lexls_lsi_solve_debug"""
     from lexls_amd.lexlsi import debug_buffers, debug_structure

@@ -402,3 +402,16 @@ def test_front_end_debug_structure(oracle):
     final = {(e["obj_index"], e["ctr_index"]): e["ctr_type"] for e in d["active_ctr"]}
     assert final == {(k, j): int(t) for k, a in enumerate(r["active"]) for j, t in enumerate(a) if t}
     assert d["lexqr"].shape == (16, 21)  # the simple bounds of objective 0 are fixed variables, not rows
+
+
+def test_threaded_lsi_batch_timing_counts_the_same_factorizations(oracle):
+    """oracle_lsi_time_batch (bench.py's CPU figure for configs[4]: the packed batch dealt out to host threads inside the library) runs the
+    same solves as one lsi_run per instance: equal factorization counts, whatever the number of threads"""
+    from lexls_amd import lexlsi, problems as P
+    n, dims, batch = 12, [4, 5, 3], 9
+    problems = [P.lsi_problem(4100 + i, n, dims) for i in range(batch)]
+    packed = lexlsi.pack_batch(n, problems)
+    expected = sum(oracle.lsi_run(n, objs)["info"]["factorizations"] for objs in problems)
+    for threads in (1, 3):
+        nf, seconds = oracle.lsi_time_batch(packed, None, None, threads)
+        assert nf == expected and seconds > 0.0
