@@ -697,6 +697,31 @@ namespace lexls
                     if (__ballot(hhran) != 0ull)
                     {
                         const bool parked = (parked_levels >> k) & 1;
+#ifndef LEXLS_QUAD_PLACE_BY_COLUMN
+                        // every level of the IK batch: full rank, MD rows.  The T entries of the columns that were free at the level's end go out as runs of
+                        // consecutive lanes — lane = (column, pair of rows) in column-major order, 16 lanes = 2 2/3 columns' 96-byte segments — so that a
+                        // store instruction writes a few contiguous pieces instead of 64 sixteen-byte ones at a 480-byte stride
+                        if ((__ballot(hhran && !(rkk == MD && dimk == MD)) == 0ull) && ((cap | Fk) & 1) == 0 && (MD % 2) == 0)
+                        {
+                            constexpr int HP = MD / 2;
+                            const int f      = hhran ? n - (Fck + rkk) : 0; // free columns when level k ended (uniform in the row)
+                            const int trips  = rows_max((f * HP + 15) >> 4);
+                            for (int t = 0; t < trips; t++)
+                            {
+                                const int idx = 16 * t + gl;
+                                const int j   = idx / HP, c = idx - j * HP;
+                                if (j < f)
+                                {
+                                    const int P = Fck + rkk + j;
+                                    const int e = (int)B8(o_emap + 8 * (int)B8(o_phys + P) + k);
+                                    const double v0 = D(o_img + 8 * (okk + (2 * c) * wkk + e)), v1 = D(o_img + 8 * (okk + (2 * c + 1) * wkk + e));
+                                    *reinterpret_cast<double2 *>(out + Fk + 2 * c + (size_t)P * cap) = make_double2(v0, v1);
+                                }
+                            }
+                            Fk += dimk;
+                            continue;
+                        }
+#endif
                         double keep[NS][MD];
                         int src[NS];
                         bool mine[NS];
