@@ -576,6 +576,13 @@ namespace lexls
                     const int wk = n + 1 - Fc;
                     // stores that do not apply go to a dump slot (the hand-off block is idle here): no divergent regions
                     const int dump = o_ex;
+                    // (WF) a level of MD rows and full rank in every problem of the wavefront — every level of the IK batch —: its factor rows (the
+                    // pivot columns down to their diagonals, the right-hand side) leave from the image below as runs of consecutive lanes, see there
+#ifndef LEXLS_QUAD_LEVEL_STORES_BY_COLUMN
+                    const bool level_runs = WF && (__ballot(work && !(rank == MD && dim == MD && !exh0 && ((cap | F) & 1) == 0)) == 0ull);
+#else
+                    const bool level_runs = false;
+#endif
 #pragma unroll
                     for (int s = 0; s < NS; s++)
                     {
@@ -598,7 +605,7 @@ namespace lexls
                             // positions hold nothing else — and move to the final one at the end (rows above: from the image)
                             const bool parked = work && !exh0 && rank != dim && ColIndex < n;
                             if (parked) parked_levels |= 1 << k;
-                            if (work && P0 >= 0 && P0 <= n && (P0 == n || (!exh0 && P0 >= Fc)))
+                            if (!level_runs && work && P0 >= 0 && P0 <= n && (P0 == n || (!exh0 && P0 >= Fc)))
                             {
                                 const int pe = pos[s];
                                 double *dst  = out + F + (size_t)pe * cap;
@@ -613,6 +620,33 @@ namespace lexls
                         const bool piv = work && P0 >= Fc && P0 < Fc + rank;
                         rp[s]          = sel(piv, o_img + 8 * (imgoff + (P0 - Fc) * wk), rp[s]);
                         rq[s]          = sel(piv, 0x0c0c0c00 | k, rq[s]);
+                    }
+                    if constexpr (WF)
+                    {
+                        if (level_runs)
+                        {
+                            // lane = (column j of the level's MD pivot columns or the right-hand side, pair of rows c): R(2c, j), R(2c+1, j) from the image
+                            // just written; a pivot column's rows below its diagonal hold the essential part already (left at pivot time)
+                            constexpr int HP = MD / 2;
+                            quad_lds_fence();
+                            for (int t = 0; t < ((MD + 1) * HP + 15) / 16; t++)
+                            {
+                                const int idx = 16 * t + gl;
+                                const int j   = idx / HP, c = idx - j * HP;
+                                if (work && j <= MD)
+                                {
+                                    const bool rhs = j == MD;
+                                    const int e    = rhs ? n - Fc : j;
+                                    const int pe   = rhs ? n : Fc + j;
+                                    double *dst    = out + F + 2 * c + (size_t)pe * cap;
+                                    const double v0 = D(o_img + 8 * (imgoff + (2 * c) * wk + e)), v1 = D(o_img + 8 * (imgoff + (2 * c + 1) * wk + e));
+                                    if (rhs || 2 * c + 1 <= j)
+                                        *reinterpret_cast<double2 *>(dst) = make_double2(v0, v1);
+                                    else if (2 * c == j)
+                                        dst[0] = v0;
+                                }
+                            }
+                        }
                     }
                 }
                 STAMP(6)
