@@ -282,7 +282,12 @@ int lexls_lsi_batch_create(lexls_lsi_batch_t *out, int device, uint32_t batch, u
 int lexls_lsi_batch_run(lexls_lsi_batch_t b, const double *h_data, const uint32_t *h_var_index, const uint8_t *h_active_guess, const double *h_x0,
                         const double *h_v0 /* batch x sum(dims) initial residuals (set_v0, lexlsi.cpp:571-588) or NULL */, const double *h_reg_factors, const double *h_params, uint32_t nparams, double *h_x, int32_t *h_info6, uint8_t *h_active,
                         double *h_v, int32_t *h_rounds2);
-/* of the last lexls_lsi_batch_run: {factorize+solve stages, sensitivity stages, stages whose iteration step ran on the device, groups}.
+/* How a run executes: phase 1 of every instance on the host; from then on the instance's active-set iterations are resident on the
+ * device (LEXLS_LSI_RESIDENT=0: host logic, lock-step stages).  Where the batch's shape has a persistent instantiation (the register-resident l-QR shapes:
+ * nVar + 1 <= 41 with levels of up to 12 rows, nVar + 1 <= 64 with levels of up to 16 — except 42..48 columns), everything behind the first resident
+ * stage is ONE launch: per instance l-QR -> step -> removal search behind an unblocked step -> working-set change, until the instance stops
+ * (LEXLS_LSI_NO_FUSED=1, read per run: three launches per lock-step stage instead; same results bit for bit).
+ * of the last lexls_lsi_batch_run: {factorize+solve stages, sensitivity stages, stages whose iteration step ran on the device, groups}.
  * The step of an iteration (A*dx, ratio test, update of x / v / A*x: lexlsi.h:987-1029, :1234-1240) runs on the device
  * next to the equality solve when the batch is created with LEXLS_LSI_DEVICE_STEP=1 in the environment; off by default. */
 int lexls_lsi_batch_stats(lexls_lsi_batch_t b, int32_t *h_stats4);
