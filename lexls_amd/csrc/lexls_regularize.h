@@ -482,11 +482,13 @@ namespace lexls
             double *x = v.cg, *r1 = x + n, *r2 = r1 + n, *r3 = r2 + n, *q1 = r3 + n, *q2 = q1 + n, *q3 = q2 + n, *sv = q3 + n, *pv = sv + n;
             auto T_times = [&](const double *vec, uint32_t i) {
                 double t = 0.0;
+                #pragma unroll 4
                 for (uint32_t c = 0; c < RC; c++) t = rfma(v.w(F + i, Fc + rank + c), vec[rank + c], t);
                 return t;
             };
             auto R_times = [&](const double *vec, uint32_t i) {
                 double rr = 0.0;
+                #pragma unroll 4
                 for (uint32_t j = i; j < rank; j++) rr = rfma(v.w(F + i, Fc + j), vec[j], rr);
                 return rr;
             };
@@ -494,12 +496,15 @@ namespace lexls
                 for (uint32_t i = tid; i < N; i += NT)
                 {
                     double acc = 0.0;
+                    #pragma unroll 4
                     for (uint32_t k = 0; k < m0; k++) acc = rfma(v.ns(k, Fc + i), r2[k], acc);
                     double sval = with_z ? (acc + r3[i]) * f : f * r3[i];
                     double add  = 0.0;
                     if (i < rank)
+                        #pragma unroll 4
                         for (uint32_t k = 0; k <= i; k++) add = rfma(v.w(F + k, Fc + i), r1[k], add);
                     else
+                        #pragma unroll 4
                         for (uint32_t k = 0; k < rank; k++) add = rfma(v.w(F + k, Fc + i), r1[k], add);
                     sv[i] = sval + add;
                 }
@@ -516,6 +521,7 @@ namespace lexls
             for (uint32_t k = tid; k < m0; k += NT)
             {
                 double acc = 0.0;
+                #pragma unroll 4
                 for (uint32_t i = 0; i < N; i++) acc = rfma(v.ns(k, Fc + i), x[i], acc);
                 r2[k] = (v.ns(k, n) - acc) * f;
             }
@@ -531,6 +537,7 @@ namespace lexls
                 if (tid == 0)
                 {
                     double g = 0.0;
+                    #pragma unroll 4
                     for (uint32_t i = 0; i < N; i++) g = rfma(sv[i], sv[i], g);
                     v.scal[1] = g;
                 }
@@ -550,6 +557,7 @@ namespace lexls
                 for (uint32_t k = tid; k < m0; k += NT)
                 {
                     double acc = 0.0;
+                    #pragma unroll 4
                     for (uint32_t i = 0; i < N; i++) acc = rfma(v.ns(k, Fc + i), pv[i], acc);
                     q2[k] = acc * f;
                 }
@@ -563,8 +571,11 @@ namespace lexls
                     if (tid == 0)
                     {
                         double qq = 0.0;
+                        #pragma unroll 4
                         for (uint32_t i = 0; i < rank; i++) qq = rfma(q1[i], q1[i], qq);
+                        #pragma unroll 4
                         for (uint32_t k = 0; k < m0; k++) qq = rfma(q2[k], q2[k], qq);
+                        #pragma unroll 4
                         for (uint32_t i = 0; i < N; i++) qq = rfma(q3[i], q3[i], qq);
                         v.scal[2] = gamma / qq;
                     }
@@ -588,6 +599,7 @@ namespace lexls
                     if (tid == 0)
                     {
                         double g = 0.0;
+                        #pragma unroll 4
                         for (uint32_t i = 0; i < N; i++) g = rfma(sv[i], sv[i], g);
                         v.scal[1] = g;
                     }
