@@ -338,6 +338,7 @@ namespace lexls
                 const uint32_t i = e % N, j = e / N;
                 if (i < j) continue;
                 double acc = 0.0;
+                #pragma unroll 4
                 for (uint32_t r = 0; r < m0; r++) acc = rfma(v.ns(r, Fc + i), v.ns(r, Fc + j), acc);
                 double t = rfma(mu, acc, v.dd(i, j));
                 if (i == j) t += mu;
@@ -355,6 +356,7 @@ namespace lexls
                     base = acc;
                 }
                 double acc = 0.0;
+                #pragma unroll 4
                 for (uint32_t r = 0; r < m0; r++) acc = rfma(v.ns(r, Fc + i), v.ns(r, v.n), acc);
                 v.d[i] = rfma(mu, acc, base);
             }
@@ -381,6 +383,7 @@ namespace lexls
                 const uint32_t s2 = e % m0, t = e / m0;
                 if (s2 < t) continue;
                 double acc = 0.0;
+                #pragma unroll 4
                 for (uint32_t c = 0; c < Wd; c++) acc = rfma(v.ns(s2, Fc + c), v.ns(t, Fc + c), acc);
                 v.dd(rank + s2, rank + t) = mu * acc;
             }
@@ -388,8 +391,10 @@ namespace lexls
             {
                 const uint32_t s2 = e % m0, i = e / m0;
                 double a1 = 0.0;
+                #pragma unroll 4
                 for (uint32_t c = i; c < rank; c++) a1 = rfma(v.ns(s2, Fc + c), v.w(F + i, Fc + c), a1);
                 double a2 = 0.0;
+                #pragma unroll 4
                 for (uint32_t c = 0; c < RC; c++) a2 = rfma(v.ns(s2, Fc + rank + c), v.w(F + i, Fc + rank + c), a2);
                 v.dd(rank + s2, i) = rfma(f, a2, f * a1);
             }
@@ -426,6 +431,7 @@ namespace lexls
                 if (with_z)
                 {
                     double acc = 0.0;
+                    #pragma unroll 4
                     for (uint32_t r = 0; r < m0; r++) acc = rfma(v.ns(r, Fc + i), v.ns(r, Fc + j), acc);
                     t = rfma(mu, acc, t);
                 }
@@ -437,6 +443,7 @@ namespace lexls
                 if (with_z)
                 {
                     double acc = 0.0;
+                    #pragma unroll 4
                     for (uint32_t r = 0; r < m0; r++) acc = rfma(v.ns(r, Fc + i), v.ns(r, v.n), acc);
                     v.d[i] = mu * acc + reg_Rt_rhs(v, F, Fc, i);
                 }
@@ -631,6 +638,7 @@ namespace lexls
                 for (uint32_t p = 0; p < rank; p++)
                 {
                     double sv = v.ns(i, Fc + p);
+                    #pragma unroll 4
                     for (uint32_t q = 0; q < p; q++) sv = rfma(-v.ns(i, Fc + q), v.w(F + q, Fc + p), sv);
                     v.ns(i, Fc + p) = sv * (1.0 / v.w(F + p, Fc + p));
                 }
@@ -639,6 +647,7 @@ namespace lexls
             {
                 const uint32_t i = e % rows, k = e / rows;
                 double t = v.ns(i, Fc + rank + k);
+                #pragma unroll 4
                 for (uint32_t p = 0; p < rank; p++) t = rfma(-v.ns(i, Fc + p), v.w(F + p, Fc + rank + k), t);
                 v.ns(i, Fc + rank + k) = t;
             }
