@@ -189,14 +189,15 @@ const char *lexls_lse_last_kernel(lexls_lse_t h);
  *                  (relative to max(1, |x|_inf)) — on problems whose own solution is determined that well.  An ill-conditioned problem
  *                  (tiny pivots above the rank tolerance, rows / columns scaled over many decades), whose x moves by more than ~1e-11 when
  *                  its DATA move by one ulp, is solved to a small multiple of that sensitivity instead (scripts/soak_qtol.py: 21 k
- *                  random batches, 92 such problems beyond 1e-10, at most 20 x their one-ulp sensitivity; pivots and ranks exact in all).
+ *                  random batches, 92 such problems beyond 1e-10, at most 20 x their one-ulp sensitivity — 47 x once levels of eight rows
+ *                  joined the soak, its bound is 100 x —; pivots and ranks exact in all).
  *                  PIVOT RULE under (T).  The reference takes the first maximum of the down-dated column norms (lexlse.h:205-206).  lqr_mfma compares
  *                  the norms by VALUE (whole doubles; equal values: the smallest position) — the reference's rule on this kernel's own norms.
  *                  lqr_qtol compares them in ONE max butterfly on a packed key whose low 12 mantissa bits carry the position: two candidates whose
  *                  norms agree in their upper 40 mantissa bits (relative difference below 2^-40 = 9.1e-13) are ordered BY POSITION, whatever their
  *                  last 12 bits say.  Exact ties (duplicated columns) are ordered as the reference orders them by either kernel; norms that differ by
  *                  1e-11 relative or more are ordered by value by both (tests/test_gpu_qtol.py, tests/test_gpu_mfma.py: near-tie cases).
- *   policy 0 = automatic dispatch.  (T) for x-only solves whose levels ALL have 12 rows, no fixed variables, no regularization, n <= 40 (the IK shape of
+ *   policy 0 = automatic dispatch.  (T) for x-only solves whose levels ALL have 12 rows (or ALL 8: round 4), no fixed variables, no regularization, n <= 40 (the IK shape of
  *              BASELINE configs[2]/[3] and its smaller relatives):
  *              lqr_qtol, the bench kernel — and for problems beyond one CU's LDS (the step-per-pivot path with the trailing update on the matrix
  *              cores; there the reflector of a row that exactly repeats a row of an earlier level may come out with the opposite SIGN — that row of R

@@ -49,6 +49,10 @@ namespace lexls
     size_t launch_qtol_3x12_lds(uint32_t nVar, uint32_t nObj);
     hipError_t launch_qtol_2x12(const LseArgs &a, hipStream_t s);
     size_t launch_qtol_2x12_lds(uint32_t nVar, uint32_t nObj);
+    hipError_t launch_qtol_3x8(const LseArgs &a, hipStream_t s);
+    size_t launch_qtol_3x8_lds(uint32_t nVar, uint32_t nObj);
+    hipError_t launch_qtol_2x8(const LseArgs &a, hipStream_t s);
+    size_t launch_qtol_2x8_lds(uint32_t nVar, uint32_t nObj);
     hipError_t launch_mfma_32x12n40(const LseArgs &a, hipStream_t s);
     size_t launch_mfma_32x12n40_lds(uint32_t nVar, uint32_t nObj);
     hipError_t launch_mfma_32x12(const LseArgs &a, hipStream_t s);
@@ -71,12 +75,18 @@ namespace lexls
     }
 
     /// which instantiation of the tolerance-contract four-per-wavefront kernel (lqr_qtol_impl.h) serves these arguments (0: none): x-only
-    /// solves of batches in which every level of every problem has exactly 12 rows, no fixed variables, no regularization, n + 1 <= 48 —
+    /// solves of batches in which every level of every problem has exactly 12 (or exactly 8) rows, no fixed variables, no regularization, n + 1 <= 48 —
     /// 1: n = 40, the IK shape of BASELINE configs[2]/[3] (n a compile-time constant, columns right-aligned in the slots); 2: other n with
     /// 33 .. 48 columns; 3: up to 32 columns
     static int qtol_choice(const LseArgs &a, bool write_factor, bool has_fixed)
     {
-        if (write_factor || has_fixed || a.reg_type != 0 || a.uniform_dim != 12 || a.nObj > 8 || (a.cap & 1u) != 0 || (reinterpret_cast<uintptr_t>(a.in) & 15u) != 0 || a.g_cdata) return 0;
+        if (write_factor || has_fixed || a.reg_type != 0 || (a.uniform_dim != 12 && a.uniform_dim != 8) || a.nObj > 8 || (a.cap & 1u) != 0 || (reinterpret_cast<uintptr_t>(a.in) & 15u) != 0 || a.g_cdata) return 0;
+        if (a.uniform_dim == 8) // levels of eight rows (round 4): 4: 33 .. 48 columns, 5: up to 32
+        {
+            if (a.nVar + 1 <= 32) return (a.nVar >= 2 && launch_qtol_2x8_lds(a.nVar, a.nObj) <= kMaxLdsBytes) ? 5 : 0;
+            if (a.nVar + 1 <= 48) return launch_qtol_3x8_lds(a.nVar, a.nObj) <= kMaxLdsBytes ? 4 : 0;
+            return 0;
+        }
         if (a.nVar == 40) return launch_qtol_3x12s7_lds(a.nVar, a.nObj) <= kMaxLdsBytes ? 1 : 0;
         if (a.nVar + 1 <= 32) return (a.nVar >= 2 && launch_qtol_2x12_lds(a.nVar, a.nObj) <= kMaxLdsBytes) ? 3 : 0;
         if (a.nVar + 1 <= 48) return launch_qtol_3x12_lds(a.nVar, a.nObj) <= kMaxLdsBytes ? 2 : 0;
@@ -186,6 +196,8 @@ namespace lexls
             case 1: *variant = "lqr_qtol<3,12,shift 7>"; return launch_qtol_3x12s7(a, s);
             case 2: *variant = "lqr_qtol<3,12>"; return launch_qtol_3x12(a, s);
             case 3: *variant = "lqr_qtol<2,12>"; return launch_qtol_2x12(a, s);
+            case 4: *variant = "lqr_qtol<3,8>"; return launch_qtol_3x8(a, s);
+            case 5: *variant = "lqr_qtol<2,8>"; return launch_qtol_2x8(a, s);
             default: break;
             }
         if (tolerance == 1) // shapes lqr_qtol's four slices per wavefront do not hold

@@ -1,4 +1,4 @@
-"""Soak (not part of the suite): the tolerance-contract kernel on random shapes it serves — n = 2 .. 40, 1 .. 8 levels of 12 rows, any batch size,
+"""Soak (not part of the suite): the tolerance-contract kernel on random shapes it serves — n = 2 .. 40, 1 .. 8 levels of 12 (or 8) rows, any batch size,
 full-rank and rank-deficient (exact dependence, duplicated columns) — pivots / ranks / first columns exact, x within 1e-10 (contract T).
 usage: python scripts/soak_qtol.py [seconds]"""
 import os, sys, time
@@ -15,14 +15,15 @@ t0, cases, kernels, worst, ill, ratio = time.time(), 0, {}, 0.0, 0, 0.0
 while time.time() - t0 < budget:
     n = int(rng.integers(2, 41))
     nobj = int(rng.integers(1, 9))
-    dims = [12] * nobj
+    md = int(rng.choice([12, 12, 8]))  # (levels of eight rows: the round-4 instantiations)
+    dims = [md] * nobj
     B = int(rng.choice([1, 2, 3, 5, 17, 64, 200]))
     kind = int(rng.integers(0, 4))
     seed = int(rng.integers(0, 1 << 30))
     if kind == 0:
         lod = P.lse_batch_fast(seed, B, n, dims)
     elif kind == 1:
-        ranks = [int(rng.integers(0, 13)) for _ in range(nobj)]
+        ranks = [int(rng.integers(0, md + 1)) for _ in range(nobj)]
         lod = np.stack([P.rank_deficient_problem(seed + b, n, dims, ranks) for b in range(B)])
     elif kind == 2:  # duplicated columns: exact ties of the norms
         lod = P.lse_batch_fast(seed, B, n, dims)

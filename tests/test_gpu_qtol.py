@@ -104,6 +104,28 @@ def test_other_numbers_of_variables(hip, oracle, n, nobj, expect):
     check(hip, oracle, lod, dims, expect=expect, n=n)
 
 
+@pytest.mark.parametrize("n,nobj,expect", [(5, 1, "lqr_qtol<2,8>"), (16, 2, "lqr_qtol<2,8>"), (24, 3, "lqr_qtol<2,8>"), (31, 5, "lqr_qtol<2,8>"),
+                                            (32, 4, "lqr_qtol<3,8>"), (40, 5, "lqr_qtol<3,8>"), (40, 8, "lqr_qtol<3,8>"), (36, 6, "lqr_qtol<3,8>")])
+def test_levels_of_eight_rows(hip, oracle, n, nobj, expect):
+    """the tolerance-contract kernel's instantiations for levels of EIGHT rows (round 4: dims [8] x k, e.g. wider hierarchies of smaller tasks):
+    same contract — pivots / ranks / first columns exact, x within 1e-10 — full rank, wavefront tails, exact dependences inside levels, duplicated
+    columns (first maximum by position), scaled data"""
+    dims = [8] * nobj
+    for batch in (1, 5, 66):
+        check(hip, oracle, P.lse_batch(9700 + 10 * n + batch, batch, n, dims), dims, expect=expect, n=n)
+    ranks = [max(1, min(8, n - 8 * k) - 2) if k % 2 == 0 else 8 for k in range(nobj)]
+    lod = np.stack([P.rank_deficient_problem(9800 + n + b, n, dims, ranks) for b in range(13)])
+    check(hip, oracle, lod, dims, expect=expect, n=n)
+    lod = P.lse_batch(9900 + n, 16, n, dims)
+    if n >= 8:
+        lod[:, n - 1, :] = lod[:, 0, :]
+        lod[:, n // 2, :] = lod[:, 1, :]
+    check(hip, oracle, lod, dims, expect=expect, n=n)
+    lod = P.lse_batch(9950 + n, 16, n, dims)
+    lod[:, :n, :] *= (10.0 ** (3 * (P.uniform(7, n) * 2 - 1)))[None, :, None]
+    check(hip, oracle, lod, dims, expect=expect, n=n)
+
+
 @pytest.mark.parametrize("ranks", [(9, 12, 7, 12, 12), (3, 3, 3, 3, 3), (12, 1, 12, 1, 12), (12, 12, 12, 2, 12), (1, 1, 1, 1, 1)])
 def test_rank_deficient_levels(hip, oracle, ranks):
     """exact linear dependence inside levels (the reference's define_problem.m construction): the rank break of lexlse.h:214"""
@@ -165,7 +187,7 @@ def test_dispatch_rules(hip, oracle):
     r.setProblem(lod)
     r.factorize_solve(keep_factor=False)
     assert not r.last_kernel().startswith("lqr_qtol")
-    for n2, dims2 in ((44, [12] * 5), (40, [8] * 5), (30, [16, 16])):
+    for n2, dims2 in ((44, [12] * 5), (40, [6] * 5), (30, [16, 16])):
         lod2 = P.lse_batch(32, 8, n2, dims2)
         o = hip.BatchedLexLSE(8, n2, dims2)
         o.setProblem(lod2)
