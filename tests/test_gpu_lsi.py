@@ -580,6 +580,34 @@ def test_persistent_launch_equals_the_stage_by_stage_path(hip, monkeypatch):
     assert longest - 1 <= out[True][2]["device_step"] <= out[False][2]["device_step"]
 
 
+@pytest.mark.parametrize("n,dims,simple_bounds,limit", [(40, [12] * 5, True, 7), (24, [6, 9, 4, 11], False, 0), (55, [16, 14, 16, 12], True, 0), (12, [5, 7], False, 3)])
+def test_persistent_launch_other_shapes_and_limits(hip, oracle, monkeypatch, n, dims, simple_bounds, limit):
+    """the persistent launch on its three instantiations (41 x 12 exact, 41 x 12, 64 x 16), cold starts, a factorization limit that stops instances
+    inside the launch (MAX_NUMBER_OF_FACTORIZATIONS_EXCEEDED): every instance against the oracle-backed driver, and against the stage path"""
+    batch = 37
+    problems = [P.lsi_problem(20268800 + b, n, dims, simple_bounds=simple_bounds) for b in range(batch)]
+    kw = {"max_number_of_factorizations": limit} if limit else {}
+    out = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("LEXLS_LSI_NO_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("LEXLS_LSI_NO_FUSED", "1")
+        out[fused] = lexlsi.lsi_batch_solve(n, problems, **kw)
+    a, b = out[True], out[False]
+    assert [i for i in a["info"]] == [i for i in b["info"]]
+    np.testing.assert_array_equal(a["x"], b["x"])
+    np.testing.assert_array_equal(a["v"], b["v"])
+    np.testing.assert_array_equal(a["active"], b["active"])
+    if limit:
+        assert any(i["status"] != 0 for i in a["info"])  # the limit bites
+    for k in range(0, batch, 6):
+        o = oracle.lsi_run(n, problems[k], **kw)
+        assert a["info"][k] == o["info"], k
+        np.testing.assert_array_equal(a["x"][k], o["x"], err_msg=str(k))
+        np.testing.assert_array_equal(a["active"][k], np.concatenate(o["active"]), err_msg=str(k))
+
+
 def test_front_end_debug_output(hip, oracle):
     """The fifth output of the MEX front end through lexls_lsi_solve_debug (`frontend.lexlsi(..., debug=True)`): working-set log with its
     step lengths / multipliers, final working set in order, the multiplier matrices of getLambda, factor, data and xStar of the last
