@@ -68,7 +68,22 @@ int main(int argc, char **argv)
         const LexLS::dVectorType &v  = lse.get_v();
         std::printf("LexLSE: ranks %u %u, x = [%.6f %.6f %.6f %.6f], |v| of level 0 = %.3e\n", (unsigned)lse.getRank(0), (unsigned)lse.getRank(1), xe(0),
                     xe(1), xe(2), xe(3), std::sqrt(v(0) * v(0) + v(1) * v(1) + v(2) * v(2)));
-        return (status == LexLS::PROBLEM_SOLVED && err < 1e-9) ? 0 : 1;
+        // the multipliers of both objectives: the one-argument overload (lexlse.h:770-861) against the deciding one with zero tolerances
+        bool lambda_ok = true;
+        for (LexLS::Index k = 0; k < 2; k++)
+        {
+            lse.ObjectiveSensitivity(k);
+            const LexLS::dVectorType la = lse.getWorkspace();
+            LexLS::Index ctr = 0;
+            int obj          = 0;
+            LexLS::RealScalar worst = 0;
+            lse.ObjectiveSensitivity(k, ctr, obj, 0.0, 0.0, worst);
+            const LexLS::dVectorType &lb = lse.getWorkspace();
+            const LexLS::Index nl        = k == 0 ? 3 : 5;
+            for (LexLS::Index i = 0; i < nl; i++) lambda_ok = lambda_ok && la(i) == lb(i);
+        }
+        std::printf("LexLSE: multipliers of the one-argument overload %s\n", lambda_ok ? "agree" : "DIFFER");
+        return (status == LexLS::PROBLEM_SOLVED && err < 1e-9 && lambda_ok) ? 0 : 1;
     }
     catch (const std::exception &e)
     {

@@ -38,6 +38,7 @@
 #include <lexls_hip.h>
 
 #include <cstring>
+#include <limits>
 
 namespace LexLS
 {
@@ -332,8 +333,22 @@ namespace LexLS
                 fetch_mu();
                 return residual_mu;
             }
-            /// lexlse.h:770-861: the debug overload that prints every multiplier; use getWorkspace() after the overloads above
-            void ObjectiveSensitivity(Index) { throw Exception("lexls_hip: the printing overload of ObjectiveSensitivity is not provided"); }
+            /// lexlse.h:770-861: the overload "to form the matrix of Lagrange multipliers (for debugging purposes)": the multipliers of objective
+            /// ObjIndex, from the residual of the factorization, into the workspace ([lambda_fixed; lambda], read them with getWorkspace()) — no
+            /// removal decision, no CORRECT_SIGN_OF_LAMBDA marks.  Served by the same device routine as the deciding overload with tolerances no
+            /// multiplier can meet (it neither marks nor finds a candidate) and the scan over the following objectives switched off for the call.
+            /// (The reference's by-product for the experimental regularization type 7 — residual_mu instead of the factorization's residual,
+            /// :800-811 — is not provided.)
+            void ObjectiveSensitivity(Index ObjIndex)
+            {
+                if (ObjIndex >= nObj) throw Exception("ObjIndex >= nObj");
+                const double never = std::numeric_limits<double>::infinity();
+                if (sens_scan) check(lexls_lse_set_sensitivity_scan(h, 0));
+                const int rc = lexls_lse_sensitivity(h, NULL, static_cast<int32_t>(ObjIndex), never, never);
+                if (sens_scan) check(lexls_lse_set_sensitivity_scan(h, 1));
+                check(rc);
+                lambda_pending = true;
+            }
             const dVectorType &getWorkspace()
             {
                 if (lambda_pending)

@@ -237,6 +237,7 @@ def test_cpp_drop_in_example(hip, tmp_path):
     r = subprocess.run([exe, os.path.join(GOLDEN, "test_01.dat")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "LexLSI: status 0" in r.stdout and "LexLSE: ranks 3 1" in r.stdout, r.stdout
+    assert "multipliers of the one-argument overload agree" in r.stdout, r.stdout
 
 
 def test_cpp_resolve_active_set_reproduces_factor_and_solution(hip, tmp_path):
