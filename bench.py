@@ -326,7 +326,24 @@ def bench_lsi(args, world, rank, device_index, coll_device, torch, dist):
     if nsolved != total:
         raise SystemExit(f"bench --workload lsi: only {nsolved} of {total} instances solved — refusing to report a number")
     if rank == 0:
+        extra = {}
+        flops = P.flop_model(n, dims)["total"]  # per factorization of a full problem (an upper bound: working sets hold fewer rows)
+        rate = fsum * args.steps / elapsed
+        extra["roofline"] = {"bound": "fp64", "achieved": rate * flops / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rate * flops / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                             "traffic": None, "note": "flops of a full 60 x 41 problem per factorization (upper bound); the path is a latency chain per instance (DESIGN.md 3.5)"}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_ctypes as oc
+            share = host_cpu_share()
+            cores = max(1, int(round(share["effective_cores"])))
+            nfc, tcc = 0, 0.0
+            while tcc < 2.0:  # (sustained: one pass is a burst the cgroup's CPU quota does not throttle yet)
+                a_, b_ = oc.lsi_time_batch(pert, guess, cold["x"], 4 * cores)
+                nfc, tcc = nfc + a_, tcc + b_
+            extra["cpu_baseline"] = {"value": nfc / tcc, "unit": "factorizations/s", "cores": cores, "threads": 4 * cores, "kind": "port", **share,
+                                     "sample": f"the same warm-started batch of {total} instances, repeated for {tcc:.1f} s ({nfc} factorizations) through the host driver over the oracle, "
+                                               f"instances dealt out to {4 * cores} std::threads inside the library"}
         print(json.dumps({
+            **extra,
             "metric": "batched fp64 l-QR factorizations/s (LexLSI lock-step batch: factorize+solve+removal search per active-set iteration)",
             "value": fsum * args.steps / elapsed, "unit": "factorizations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
