@@ -251,14 +251,27 @@ namespace lexls
             __syncthreads();
         }
 
+        /// entry e of the lower triangle (diagonal included) of an N x N matrix, column by column: e -> (i, j), i >= j.  The loops over a symmetric
+        /// matrix's entries run over these N (N + 1) / 2 — not over N^2 with the upper half skipped, which idles half the lanes' trips
+        __device__ __forceinline__ void reg_lower_entry(uint32_t e, uint32_t N, uint32_t &i, uint32_t &j)
+        {
+            const float twoNp1 = (float)(2u * N + 1u);
+            uint32_t jj        = (uint32_t)((twoNp1 - sqrtf(twoNp1 * twoNp1 - 8.0f * (float)e)) * 0.5f);
+            if (jj >= N) jj = N - 1u;
+            while (jj > 0u && jj * N - (jj * (jj - 1u)) / 2u > e) jj--;                       // (the float estimate may be one off)
+            while (jj + 1u < N && (jj + 1u) * N - ((jj + 1u) * jj) / 2u <= e) jj++;
+            j = jj;
+            i = jj + (e - (jj * N - (jj * (jj - 1u)) / 2u));
+        }
+
         /// lower triangle of R^T R into D
         template <int NT>
         __device__ void reg_lower_RtR(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t tid)
         {
-            for (uint32_t e = tid; e < rank * rank; e += NT)
+            for (uint32_t e = tid; e < rank * (rank + 1) / 2; e += NT)
             {
-                const uint32_t i = e % rank, j = e / rank;
-                if (i < j) continue;
+                uint32_t i, j;
+                reg_lower_entry(e, rank, i, j);
                 double acc = 0.0;
                 for (uint32_t k = 0; k <= j; k++) acc = rfma(v.w(F + k, Fc + i), v.w(F + k, Fc + j), acc);
                 v.dd(i, j) = acc;
@@ -268,10 +281,10 @@ namespace lexls
         template <int NT>
         __device__ void reg_lower_RRt_TTt(const RegView &v, uint32_t F, uint32_t Fc, uint32_t rank, uint32_t RC, uint32_t tid)
         {
-            for (uint32_t e = tid; e < rank * rank; e += NT)
+            for (uint32_t e = tid; e < rank * (rank + 1) / 2; e += NT)
             {
-                const uint32_t i = e % rank, j = e / rank;
-                if (i < j) continue;
+                uint32_t i, j;
+                reg_lower_entry(e, rank, i, j);
                 double acc = 0.0;
                 for (uint32_t k = i; k < rank; k++) acc = rfma(v.w(F + i, Fc + k), v.w(F + j, Fc + k), acc);
                 double t = 0.0;
@@ -317,10 +330,10 @@ namespace lexls
             const uint32_t m0 = Fc - v0.nf, N = RC + rank;
             const RegView v   = v0.with_order(N);
             reg_lower_RtR<NT>(v, F, Fc, rank, tid);
-            for (uint32_t e = tid; e < RC * RC; e += NT) // Tk'*Tk (lower)
+            for (uint32_t e = tid; e < RC * (RC + 1) / 2; e += NT) // Tk'*Tk (lower)
             {
-                const uint32_t a = e % RC, b2 = e / RC;
-                if (a < b2) continue;
+                uint32_t a, b2;
+                reg_lower_entry(e, RC, a, b2);
                 double acc = 0.0;
                 for (uint32_t k = 0; k < rank; k++) acc = rfma(v.w(F + k, Fc + rank + a), v.w(F + k, Fc + rank + b2), acc);
                 v.dd(rank + a, rank + b2) = acc;
@@ -333,10 +346,10 @@ namespace lexls
                 v.dd(rank + a, j) = acc;
             }
             __syncthreads();
-            for (uint32_t e = tid; e < N * N; e += NT) // += mu * up'*up ; + mu on the diagonal
+            for (uint32_t e = tid; e < N * (N + 1) / 2; e += NT) // += mu * up'*up ; + mu on the diagonal
             {
-                const uint32_t i = e % N, j = e / N;
-                if (i < j) continue;
+                uint32_t i, j;
+                reg_lower_entry(e, N, i, j);
                 double acc = 0.0;
                 #pragma unroll 4
                 for (uint32_t r = 0; r < m0; r++) acc = rfma(v.ns(r, Fc + i), v.ns(r, Fc + j), acc);
@@ -378,10 +391,10 @@ namespace lexls
             const uint32_t m0 = Fc - v0.nf, N = m0 + rank, Wd = RC + rank;
             const RegView v   = v0.with_order(N);
             reg_lower_RRt_TTt<NT>(v, F, Fc, rank, RC, tid);
-            for (uint32_t e = tid; e < m0 * m0; e += NT) // mu * up*up' (lower)
+            for (uint32_t e = tid; e < m0 * (m0 + 1) / 2; e += NT) // mu * up*up' (lower)
             {
-                const uint32_t s2 = e % m0, t = e / m0;
-                if (s2 < t) continue;
+                uint32_t s2, t;
+                reg_lower_entry(e, m0, s2, t);
                 double acc = 0.0;
                 #pragma unroll 4
                 for (uint32_t c = 0; c < Wd; c++) acc = rfma(v.ns(s2, Fc + c), v.ns(t, Fc + c), acc);
@@ -423,10 +436,10 @@ namespace lexls
             reg_lower_RtR<NT>(v, F, Fc, rank, tid);
             __syncthreads();
             REG_STAMP(v, 1, tid)
-            for (uint32_t e = tid; e < rank * rank; e += NT)
+            for (uint32_t e = tid; e < rank * (rank + 1) / 2; e += NT)
             {
-                const uint32_t i = e % rank, j = e / rank;
-                if (i < j) continue;
+                uint32_t i, j;
+                reg_lower_entry(e, rank, i, j);
                 double t = v.dd(i, j);
                 if (with_z)
                 {
