@@ -190,7 +190,8 @@ const char *lexls_lse_last_kernel(lexls_lse_t h);
  *                  (tiny pivots above the rank tolerance, rows / columns scaled over many decades), whose x moves by more than ~1e-11 when
  *                  its DATA move by one ulp, is solved to a small multiple of that sensitivity instead (scripts/soak_qtol.py: 21 k
  *                  random batches, 92 such problems beyond 1e-10, at most 20 x their one-ulp sensitivity — 47 x once levels of eight rows
- *                  joined the soak, its bound is 100 x —; pivots and ranks exact in all).
+ *                  joined the soak, 91 x on lqr_mfma's soak; the soaks' bound is 100 x, a random one-ulp perturbation being a LOWER
+ *                  estimate of what rounding does to such a problem —; pivots and ranks exact in all).
  *                  PIVOT RULE under (T).  The reference takes the first maximum of the down-dated column norms (lexlse.h:205-206).  lqr_mfma compares
  *                  the norms by VALUE (whole doubles; equal values: the smallest position) — the reference's rule on this kernel's own norms.
  *                  lqr_qtol compares them in ONE max butterfly on a packed key whose low 12 mantissa bits carry the position: two candidates whose
